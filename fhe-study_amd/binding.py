@@ -1,0 +1,265 @@
+"""ctypes binding of libfhe_ntt.so (include/fhe_ntt.h).
+
+This is plumbing only: every call goes straight to the C ABI, which runs the HIP
+kernels.  There is no Python/numpy compute path and no CPU fallback — if the
+library is missing, or no GPU is present, calls raise.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfhe_ntt.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["capi.hip", "ntt_kernels.hip"]
+HEADERS = ["ntt_kernels.hpp", "zq_device.hpp", os.path.join("..", "..", "include", "fhe_ntt.h")]
+
+FHE_OK = 0
+FHE_E_BAD_N = -1
+FHE_E_BAD_Q = -2
+FHE_E_NO_ROOT = -3
+FHE_E_NULL = -4
+FHE_E_HIP = -5
+FHE_E_NO_DEVICE = -6
+FHE_E_PARAM_MISMATCH = -7
+FHE_E_NOT_CANONICAL = -8
+FHE_E_INVALID = -9
+
+# every symbol include/fhe_ntt.h declares (tests check the .so exports them all)
+EXPORTS = [
+    "fhe_ntt_plan_get", "fhe_ntt_plan_info", "fhe_ntt_plan_tables",
+    "fhe_ntt_forward", "fhe_ntt_inverse", "fhe_rq_mul", "fhe_rq_mul_checked",
+    "fhe_rq_pointwise_mul", "fhe_rq_check_canonical",
+    "fhe_ntt_forward_dev", "fhe_ntt_inverse_dev", "fhe_rq_mul_dev",
+    "fhe_rq_mul_workspace_bytes", "fhe_rq_pointwise_mul_dev", "fhe_fill_synthetic_dev",
+    "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
+    "fhe_ntt_kernel_timing_reset",
+    "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
+]
+
+
+class FheError(RuntimeError):
+    """A non-zero return of the C ABI — the situations in which the reference panics."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"fhe_ntt error {code}: {msg}")
+        self.code = code
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 → fhe-study_amd/libfhe_ntt.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-result", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_u64 = ctypes.c_uint64
+_p64 = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no fallback path")
+    L = ctypes.CDLL(LIB_PATH)
+    L.fhe_ntt_plan_get.argtypes = [_u64, _u64, ctypes.POINTER(_vp)]
+    L.fhe_ntt_plan_info.argtypes = [_vp, _p64, _p64, _p64, _p64]
+    L.fhe_ntt_plan_tables.argtypes = [_vp, _p64, _p64]
+    L.fhe_ntt_forward.argtypes = [_vp, _vp, _vp, _sz]
+    L.fhe_ntt_inverse.argtypes = [_vp, _vp, _vp, _sz]
+    L.fhe_rq_mul.argtypes = [_vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _sz]
+    L.fhe_rq_mul_checked.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz]
+    L.fhe_rq_pointwise_mul.argtypes = [_vp, _vp, _vp, _vp, _sz]
+    L.fhe_rq_check_canonical.argtypes = [_vp, _vp, _sz]
+    L.fhe_ntt_forward_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]
+    L.fhe_ntt_inverse_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]
+    L.fhe_rq_mul_dev.argtypes = [_vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp]
+    L.fhe_rq_mul_workspace_bytes.argtypes = [_vp, _sz]
+    L.fhe_rq_mul_workspace_bytes.restype = _sz
+    L.fhe_rq_pointwise_mul_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_fill_synthetic_dev.argtypes = [_u64, _u64, _u64, _sz, _vp, _vp]
+    L.fhe_ntt_set_batch_tile.argtypes = [_sz]
+    L.fhe_ntt_kernel_timing_enable.argtypes = [_int]
+    L.fhe_ntt_kernel_timing_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), _p64, _int]
+    L.fhe_ntt_kernel_timing_reset.argtypes = []
+    L.fhe_ntt_device_count.argtypes = []
+    L.fhe_last_error.restype = ctypes.c_char_p
+    L.fhe_ntt_version.restype = ctypes.c_char_p
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int and name not in ("fhe_last_error", "fhe_ntt_version"):
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != FHE_OK:
+        raise FheError(rc, load_library().fhe_last_error().decode())
+
+
+def _host(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(_vp)
+
+
+class Plan:
+    """(q,n)-keyed plan — the reference's `roots(q,n)` cache entry, arith/src/ntt.rs:18-38."""
+
+    def __init__(self, q, n):
+        L = load_library()
+        h = _vp()
+        _check(L.fhe_ntt_plan_get(int(q), int(n), ctypes.byref(h)))
+        self.handle = h
+        self.q, self.n = int(q), int(n)
+
+    def info(self):
+        q, n, psi, ninv = _u64(), _u64(), _u64(), _u64()
+        _check(load_library().fhe_ntt_plan_info(self.handle, q, n, psi, ninv))
+        return dict(q=q.value, n=n.value, psi=psi.value, n_inv=ninv.value)
+
+    def tables(self):
+        r = np.empty(self.n, dtype=np.uint64)
+        ri = np.empty(self.n, dtype=np.uint64)
+        _check(load_library().fhe_ntt_plan_tables(self.handle, r.ctypes.data_as(_p64),
+                                                  ri.ctypes.data_as(_p64)))
+        return r, ri
+
+    # -- host buffers ---------------------------------------------------------
+    def _batch(self, a):
+        if a.size % self.n:
+            raise ValueError(f"array of {a.size} values is not a whole number of n={self.n} polynomials")
+        return a.size // self.n
+
+    def forward(self, a):
+        a, pa = _host(a)
+        out = np.empty_like(a)
+        _check(load_library().fhe_ntt_forward(self.handle, pa, out.ctypes.data_as(_vp), self._batch(a)))
+        return out
+
+    def inverse(self, a):
+        a, pa = _host(a)
+        out = np.empty_like(a)
+        _check(load_library().fhe_ntt_inverse(self.handle, pa, out.ctypes.data_as(_vp), self._batch(a)))
+        return out
+
+    def rq_mul(self, a, b, a_is_evals=False, b_is_evals=False, want_evals=True):
+        """→ (c, c_evals, a_evals, b_evals); the last three are None unless want_evals."""
+        a, pa = _host(a)
+        b, pb = _host(b)
+        if a.shape != b.shape:
+            raise ValueError("operand shapes differ")
+        c = np.empty_like(a)
+        ce = np.empty_like(a) if want_evals else None
+        ae = np.empty_like(a) if want_evals else None
+        be = np.empty_like(a) if want_evals else None
+        p = lambda x: x.ctypes.data_as(_vp) if x is not None else None
+        _check(load_library().fhe_rq_mul(self.handle, pa, int(a_is_evals), pb, int(b_is_evals),
+                                         p(c), p(ce), p(ae), p(be), self._batch(a)))
+        return c, ce, ae, be
+
+    def pointwise_mul(self, a, b):
+        a, pa = _host(a)
+        b, pb = _host(b)
+        c = np.empty_like(a)
+        _check(load_library().fhe_rq_pointwise_mul(self.handle, pa, pb, c.ctypes.data_as(_vp),
+                                                   self._batch(a)))
+        return c
+
+    def check_canonical(self, a):
+        a, pa = _host(a)
+        _check(load_library().fhe_rq_check_canonical(self.handle, pa, self._batch(a)))
+
+    # -- device pointers (ints), stream handle (int or None) -----------------------
+    def forward_dev(self, d_in, d_out, batch, stream=None):
+        _check(load_library().fhe_ntt_forward_dev(self.handle, d_in, d_out, batch, stream))
+
+    def inverse_dev(self, d_in, d_out, batch, stream=None):
+        _check(load_library().fhe_ntt_inverse_dev(self.handle, d_in, d_out, batch, stream))
+
+    def rq_mul_dev(self, d_a, d_b, d_c, batch, a_is_evals=False, b_is_evals=False, d_c_evals=None,
+                   d_a_evals=None, d_b_evals=None, d_work=None, stream=None):
+        _check(load_library().fhe_rq_mul_dev(self.handle, d_a, int(a_is_evals), d_b, int(b_is_evals),
+                                             d_c, d_c_evals, d_a_evals, d_b_evals, batch, d_work, stream))
+
+    def pointwise_mul_dev(self, d_a, d_b, d_c, batch, stream=None):
+        _check(load_library().fhe_rq_pointwise_mul_dev(self.handle, d_a, d_b, d_c, batch, stream))
+
+    def workspace_bytes(self, batch):
+        return int(load_library().fhe_rq_mul_workspace_bytes(self.handle, batch))
+
+
+def rq_mul_checked(plan_a, plan_b, a, b):
+    a, pa = _host(a)
+    b, pb = _host(b)
+    c = np.empty_like(a)
+    _check(load_library().fhe_rq_mul_checked(plan_a.handle, plan_b.handle, pa, pb,
+                                             c.ctypes.data_as(_vp), None, a.size // plan_a.n))
+    return c
+
+
+def fill_synthetic_dev(q, seed, first_index, count, d_out, stream=None):
+    _check(load_library().fhe_fill_synthetic_dev(int(q), int(seed), int(first_index), int(count),
+                                                 d_out, stream))
+
+
+def device_count():
+    return int(load_library().fhe_ntt_device_count())
+
+
+def set_batch_tile(polys):
+    _check(load_library().fhe_ntt_set_batch_tile(int(polys)))
+
+
+def kernel_timing_enable(on):
+    _check(load_library().fhe_ntt_kernel_timing_enable(int(bool(on))))
+
+
+def kernel_timing_reset():
+    _check(load_library().fhe_ntt_kernel_timing_reset())
+
+
+def kernel_timing_read(cap=64):
+    """→ {kernel_name: (total_ms, launches)}"""
+    names = ctypes.create_string_buffer(64 * cap)
+    ms = (ctypes.c_double * cap)()
+    cnt = (ctypes.c_uint64 * cap)()
+    k = load_library().fhe_ntt_kernel_timing_read(names, ms, cnt, cap)
+    out = {}
+    for i in range(min(k, cap)):
+        nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+        out[nm] = (float(ms[i]), int(cnt[i]))
+    return out
+
+
+def shutdown():
+    global _lib
+    if _lib is not None:
+        _lib.fhe_ntt_shutdown()

@@ -1,0 +1,648 @@
+// capi.hip — the C ABI of libfhe_ntt.so (include/fhe_ntt.h): plan cache, table
+// generation, buffer plumbing.  No compute happens on the host: every transform
+// goes through the HIP kernels in ntt_kernels.hip, and without a HIP device the
+// compute entry points fail with FHE_E_NO_DEVICE (there is no CPU fallback).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/fhe_ntt.h"
+#include "ntt_kernels.hpp"
+
+using fhe::u64;
+typedef unsigned __int128 u128;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int hip_fail(hipError_t e, const char *what) {
+    return fail(FHE_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                     \
+    do {                                                  \
+        hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// host number theory (one-off, per plan) — follows arith/src/ntt.rs:115-185
+// ---------------------------------------------------------------------------
+static inline u64 mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+
+// ntt.rs:164-179 const_exp_mod
+static u64 exp_mod(u64 q, u64 x, u64 k) {
+    u64 r = 1;
+    x %= q;
+    while (k > 0) {
+        if (k & 1) r = mulmod(r, x, q);
+        x = mulmod(x, x, q);
+        k >>= 1;
+    }
+    return r;
+}
+// ntt.rs:182-185 const_inv_mod (Fermat; q assumed prime as in the reference)
+static u64 inv_mod(u64 q, u64 x) { return exp_mod(q, x, q - 2); }
+
+static inline u64 shoup(u64 w, u64 q) { return (u64)((((u128)w) << 64) / q); }
+
+static inline u64 bitrev(u64 i, unsigned log_n) {
+    u64 r = 0;
+    for (unsigned b = 0; b < log_n; b++) r |= ((i >> b) & 1ull) << (log_n - 1 - b);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------
+static constexpr int kMaxDevices = 16;
+
+struct DeviceTables {
+    fhe::Tw *tw_fwd = nullptr;
+    fhe::Tw *tw_inv = nullptr;
+    bool ready = false;
+};
+
+struct fhe_ntt_plan {
+    u64 q = 0, n = 0, psi = 0, n_inv = 0;
+    unsigned log_n = 0;
+    std::vector<u64> roots, roots_inv;  // as the reference's CACHE value (ntt.rs:18)
+    fhe::Mod mod{};
+    fhe::Tw ninv{}, s_ninv{};
+    mutable std::mutex dev_lock;
+    mutable DeviceTables dev[kMaxDevices];
+};
+
+static std::mutex g_plans_lock;
+static std::map<std::pair<u64, u64>, std::unique_ptr<fhe_ntt_plan>> g_plans;
+
+static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
+    // order of checks mirrors primitive_root_of_unity(q, 2n), ntt.rs:115-131
+    if (n < 2 || (n & (n - 1)) != 0)
+        return fail(FHE_E_BAD_N, "n=%llu: must be a power of two >= 2 (ntt.rs:116,139)",
+                    (unsigned long long)n);
+    unsigned log_n = 0;
+    while ((1ull << log_n) < n) log_n++;
+    if ((int)log_n > fhe::kMaxLog)
+        return fail(FHE_E_BAD_N, "n=%llu: engine supports n <= 2^%d", (unsigned long long)n, fhe::kMaxLog);
+    if (q < 3) return fail(FHE_E_BAD_Q, "q=%llu: modulus too small", (unsigned long long)q);
+    if (q >> 62)
+        return fail(FHE_E_BAD_Q, "q=%llu: engine needs q < 2^62 (lazy-reduction headroom)",
+                    (unsigned long long)q);
+    if ((q - 1) % (2 * n) != 0)
+        return fail(FHE_E_BAD_Q, "q=%llu, n=%llu: (q-1) %% 2n != 0 (ntt.rs:117)",
+                    (unsigned long long)q, (unsigned long long)n);
+    // first k = 1,2,.. with w = k^((q-1)/2n), w^n != 1   (ntt.rs:120-129)
+    u64 psi = 0;
+    for (u64 k = 1; k < q; k++) {
+        u64 w = exp_mod(q, k, (q - 1) / (2 * n));
+        if (exp_mod(q, w, n) != 1) { psi = w; break; }
+    }
+    if (psi == 0) return fail(FHE_E_NO_ROOT, "No primitive root of unity (ntt.rs:130)");
+
+    p->q = q; p->n = n; p->log_n = log_n; p->psi = psi;
+    p->n_inv = inv_mod(q, n);  // ntt.rs:27-30
+    p->roots.resize(n);
+    p->roots_inv.resize(n);
+    // roots[i] = psi^bitrev(i) (ntt.rs:133-147): running powers, then bit-reverse
+    // placement — same values as the reference's n modexps.
+    {
+        u64 pw = 1;
+        for (u64 j = 0; j < n; j++) {
+            p->roots[bitrev(j, log_n)] = pw;
+            pw = mulmod(pw, psi, q);
+        }
+    }
+    // roots_inv[i] = roots[i]^(q-2) (ntt.rs:149-161) — kept as the reference's
+    // Fermat power so that the tables agree even if q is not prime.
+    for (u64 i = 0; i < n; i++) p->roots_inv[i] = inv_mod(q, p->roots[i]);
+
+    p->mod.q = q;
+    p->mod.q2 = 2 * q;
+    p->mod.r64 = (u64)((((u128)1) << 64) % q);
+    p->mod.r64p = shoup(p->mod.r64, q);
+    p->mod.onep = (u64)((((u128)1) << 64) / q);
+    p->ninv.w = p->n_inv;
+    p->ninv.wp = shoup(p->n_inv, q);
+    p->s_ninv.w = mulmod(p->roots_inv[1], p->n_inv, q);
+    p->s_ninv.wp = shoup(p->s_ninv.w, q);
+    return FHE_OK;
+}
+
+extern "C" int fhe_ntt_plan_get(uint64_t q, uint64_t n, const fhe_ntt_plan **out) {
+    if (!out) return fail(FHE_E_NULL, "fhe_ntt_plan_get: out is NULL");
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(g_plans_lock);
+    auto key = std::make_pair((u64)q, (u64)n);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        std::unique_ptr<fhe_ntt_plan> p(new fhe_ntt_plan());
+        int rc = build_plan(q, n, p.get());
+        if (rc != FHE_OK) return rc;
+        it = g_plans.emplace(key, std::move(p)).first;
+    }
+    *out = it->second.get();
+    return FHE_OK;
+}
+
+extern "C" int fhe_ntt_plan_info(const fhe_ntt_plan *plan, uint64_t *q, uint64_t *n, uint64_t *psi,
+                                 uint64_t *n_inv) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (q) *q = plan->q;
+    if (n) *n = plan->n;
+    if (psi) *psi = plan->psi;
+    if (n_inv) *n_inv = plan->n_inv;
+    return FHE_OK;
+}
+
+extern "C" int fhe_ntt_plan_tables(const fhe_ntt_plan *plan, uint64_t *roots, uint64_t *roots_inv) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (roots) memcpy(roots, plan->roots.data(), plan->n * sizeof(u64));
+    if (roots_inv) memcpy(roots_inv, plan->roots_inv.data(), plan->n * sizeof(u64));
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device state
+// ---------------------------------------------------------------------------
+static int current_device(int *dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(FHE_E_NO_DEVICE, "no HIP device available (%s); libfhe_ntt has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    HIP_TRY(hipGetDevice(dev));
+    if (*dev < 0 || *dev >= kMaxDevices) return fail(FHE_E_HIP, "device ordinal %d out of range", *dev);
+    return FHE_OK;
+}
+
+static int device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
+    int dev = 0;
+    int rc = current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    std::lock_guard<std::mutex> lk(plan->dev_lock);
+    DeviceTables &t = plan->dev[dev];
+    if (!t.ready) {
+        const u64 n = plan->n, q = plan->q;
+        std::vector<fhe::Tw> f(n), i(n);
+        for (u64 k = 0; k < n; k++) {
+            f[k].w = plan->roots[k];
+            f[k].wp = shoup(plan->roots[k], q);
+            i[k].w = plan->roots_inv[k];
+            i[k].wp = shoup(plan->roots_inv[k], q);
+        }
+        HIP_TRY(hipMalloc((void **)&t.tw_fwd, n * sizeof(fhe::Tw)));
+        HIP_TRY(hipMalloc((void **)&t.tw_inv, n * sizeof(fhe::Tw)));
+        HIP_TRY(hipMemcpy(t.tw_fwd, f.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t.tw_inv, i.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice));
+        t.ready = true;
+    }
+    dp->tw_fwd = t.tw_fwd;
+    dp->tw_inv = t.tw_inv;
+    dp->mod = plan->mod;
+    dp->ninv = plan->ninv;
+    dp->s_ninv = plan->s_ninv;
+    dp->log_n = plan->log_n;
+    return FHE_OK;
+}
+
+// polynomials per launch for two-pass sizes
+static std::mutex g_cfg_lock;
+static size_t g_batch_tile_override = 0;
+static constexpr size_t kDefaultTileBytes = 64ull << 20;
+
+static u64 batch_tile_for(const fhe_ntt_plan *plan) {
+    size_t ov;
+    {
+        std::lock_guard<std::mutex> lk(g_cfg_lock);
+        ov = g_batch_tile_override;
+    }
+    if (ov == 0) {
+        static const size_t env = [] {
+            const char *s = getenv("FHE_NTT_BATCH_TILE");
+            return s ? (size_t)strtoull(s, nullptr, 10) : (size_t)0;
+        }();
+        ov = env;
+    }
+    if (ov) return ov;
+    u64 t = kDefaultTileBytes / (plan->n * 8);
+    return t < 16 ? 16 : t;
+}
+
+extern "C" int fhe_ntt_set_batch_tile(size_t polys) {
+    std::lock_guard<std::mutex> lk(g_cfg_lock);
+    g_batch_tile_override = polys;
+    return FHE_OK;
+}
+
+// grow-only per-device workspace for fhe_rq_mul_dev(d_work = NULL)
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+static std::mutex g_ws_lock;
+static Workspace g_ws[kMaxDevices];
+
+static int workspace_get(size_t bytes, void **out) {
+    int dev = 0;
+    int rc = current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_ws_lock);
+    Workspace &w = g_ws[dev];
+    if (w.bytes < bytes) {
+        if (w.ptr) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(w.ptr));
+            w.ptr = nullptr;
+            w.bytes = 0;
+        }
+        HIP_TRY(hipMalloc(&w.ptr, bytes));
+        w.bytes = bytes;
+    }
+    *out = w.ptr;
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel timing (bench.py's roofline leg)
+// ---------------------------------------------------------------------------
+struct TimingSlot {
+    std::string name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+static std::mutex g_timing_lock;
+static bool g_timing_on = false;
+static std::map<std::string, TimingSlot> g_timing;
+
+fhe::KernelTimer::KernelTimer(const char *name, int tag, hipStream_t st) : slot_(nullptr), st_(st) {
+    if (!g_timing_on) return;
+    std::lock_guard<std::mutex> lk(g_timing_lock);
+    char key[64];
+    snprintf(key, sizeof(key), "%s_%d", name, tag);
+    TimingSlot &s = g_timing[key];
+    s.name = key;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(a, st);
+    s.events.emplace_back(a, b);
+    slot_ = &s;
+}
+fhe::KernelTimer::~KernelTimer() {
+    if (!slot_) return;
+    std::lock_guard<std::mutex> lk(g_timing_lock);
+    TimingSlot *s = static_cast<TimingSlot *>(slot_);
+    (void)hipEventRecord(s->events.back().second, st_);
+}
+
+static void timing_drain_locked() {
+    for (auto &kv : g_timing) {
+        TimingSlot &s = kv.second;
+        for (auto &ev : s.events) {
+            float ms = 0;
+            if (hipEventSynchronize(ev.second) == hipSuccess &&
+                hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                s.total_ms += ms;
+                s.launches++;
+            }
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        s.events.clear();
+    }
+}
+
+extern "C" int fhe_ntt_kernel_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_timing_lock);
+    g_timing_on = on != 0;
+    return FHE_OK;
+}
+extern "C" int fhe_ntt_kernel_timing_reset(void) {
+    std::lock_guard<std::mutex> lk(g_timing_lock);
+    timing_drain_locked();
+    g_timing.clear();
+    return FHE_OK;
+}
+extern "C" int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_t *launches, int cap) {
+    std::lock_guard<std::mutex> lk(g_timing_lock);
+    timing_drain_locked();
+    int i = 0;
+    for (auto &kv : g_timing) {
+        if (i < cap) {
+            if (names) {
+                strncpy(names + (size_t)i * 64, kv.second.name.c_str(), 63);
+                names[(size_t)i * 64 + 63] = 0;
+            }
+            if (total_ms) total_ms[i] = kv.second.total_ms;
+            if (launches) launches[i] = kv.second.launches;
+        }
+        i++;
+    }
+    return i;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident entry points
+// ---------------------------------------------------------------------------
+extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, void *d_out,
+                                   size_t batch, void *hip_stream) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!d_in || !d_out) return fail(FHE_E_NULL, "fhe_ntt_forward_dev: NULL buffer");
+    fhe::DevicePlan dp;
+    int rc = device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_in, (u64 *)d_out, batch,
+                                           batch_tile_for(plan), (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward");
+    return FHE_OK;
+}
+
+extern "C" int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, void *d_out,
+                                   size_t batch, void *hip_stream) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!d_in || !d_out) return fail(FHE_E_NULL, "fhe_ntt_inverse_dev: NULL buffer");
+    fhe::DevicePlan dp;
+    int rc = device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    hipError_t e = fhe::launch_ntt_inverse(dp, (const u64 *)d_in, nullptr, nullptr, (u64 *)d_out,
+                                           batch, batch_tile_for(plan), (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt_inverse");
+    return FHE_OK;
+}
+
+extern "C" size_t fhe_rq_mul_workspace_bytes(const fhe_ntt_plan *plan, size_t batch) {
+    if (!plan) return 0;
+    return 2 * batch * plan->n * sizeof(u64);
+}
+
+extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_is_evals,
+                              const void *d_b, int b_is_evals, void *d_c, void *d_c_evals,
+                              void *d_a_evals_out, void *d_b_evals_out, size_t batch, void *d_work,
+                              void *hip_stream) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!d_a || !d_b || !d_c) return fail(FHE_E_NULL, "fhe_rq_mul_dev: NULL operand");
+    fhe::DevicePlan dp;
+    int rc = device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t elems = batch * plan->n, bytes = elems * sizeof(u64);
+    const u64 tile = batch_tile_for(plan);
+
+    const bool need_wa = !a_is_evals && !d_a_evals_out;
+    const bool need_wb = !b_is_evals && !d_b_evals_out;
+    u64 *work = (u64 *)d_work;
+    if ((need_wa || need_wb) && !work) {
+        void *w = nullptr;
+        rc = workspace_get(2 * bytes, &w);
+        if (rc != FHE_OK) return rc;
+        work = (u64 *)w;
+    }
+    // A = NTT(a): the operand's cached evals if it has them (ring_nq.rs:590-594)
+    const u64 *A = (const u64 *)d_a;
+    if (!a_is_evals) {
+        u64 *dst = d_a_evals_out ? (u64 *)d_a_evals_out : work;
+        hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_a, dst, batch, tile, st);
+        if (e != hipSuccess) return hip_fail(e, "forward(a)");
+        A = dst;
+    } else if (d_a_evals_out && d_a_evals_out != d_a) {
+        HIP_TRY(hipMemcpyAsync(d_a_evals_out, d_a, bytes, hipMemcpyDeviceToDevice, st));
+    }
+    const u64 *B = (const u64 *)d_b;
+    if (!b_is_evals) {
+        u64 *dst = d_b_evals_out ? (u64 *)d_b_evals_out : work + elems;
+        hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_b, dst, batch, tile, st);
+        if (e != hipSuccess) return hip_fail(e, "forward(b)");
+        B = dst;
+    } else if (d_b_evals_out && d_b_evals_out != d_b) {
+        HIP_TRY(hipMemcpyAsync(d_b_evals_out, d_b, bytes, hipMemcpyDeviceToDevice, st));
+    }
+    // c = intt(A .* B), C = A .* B optionally kept (ring_nq.rs:601-606)
+    hipError_t e = fhe::launch_ntt_inverse(dp, A, B, (u64 *)d_c_evals, (u64 *)d_c, batch, tile, st);
+    if (e != hipSuccess) return hip_fail(e, "inverse(A.*B)");
+    return FHE_OK;
+}
+
+extern "C" int fhe_rq_pointwise_mul_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b,
+                                        void *d_c, size_t batch, void *hip_stream) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!d_a || !d_b || !d_c) return fail(FHE_E_NULL, "fhe_rq_pointwise_mul_dev: NULL buffer");
+    fhe::DevicePlan dp;
+    int rc = device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    hipError_t e = fhe::launch_pointwise_mul(dp, (const u64 *)d_a, (const u64 *)d_b, (u64 *)d_c,
+                                             batch * plan->n, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "launch_pointwise_mul");
+    return FHE_OK;
+}
+
+extern "C" int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_index, size_t count,
+                                      void *d_out, void *hip_stream) {
+    if (count == 0) return FHE_OK;
+    if (!d_out) return fail(FHE_E_NULL, "fhe_fill_synthetic_dev: NULL buffer");
+    if (q == 0) return fail(FHE_E_BAD_Q, "q is 0");
+    int dev;
+    int rc = current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipError_t e = fhe::launch_fill_synthetic((u64 *)d_out, count, q, seed, first_index,
+                                              (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "launch_fill_synthetic");
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer entry points: stage through device memory around the same kernels
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        return FHE_OK;
+    }
+};
+
+static int host_transform(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t *out, size_t batch,
+                          bool inverse) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!in || !out) return fail(FHE_E_NULL, "NULL buffer");
+    int dev;
+    int rc = current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t bytes = batch * plan->n * sizeof(u64);
+    DevBuf d;
+    if ((rc = d.alloc(bytes)) != FHE_OK) return rc;
+    hipStream_t st = hipStreamPerThread;
+    HIP_TRY(hipMemcpyAsync(d.p, in, bytes, hipMemcpyHostToDevice, st));
+    rc = inverse ? fhe_ntt_inverse_dev(plan, d.p, d.p, batch, st)
+                 : fhe_ntt_forward_dev(plan, d.p, d.p, batch, st);
+    if (rc != FHE_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d.p, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FHE_OK;
+}
+
+extern "C" int fhe_ntt_forward(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t *out,
+                               size_t batch) {
+    return host_transform(plan, in, out, batch, false);
+}
+extern "C" int fhe_ntt_inverse(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t *out,
+                               size_t batch) {
+    return host_transform(plan, in, out, batch, true);
+}
+
+extern "C" int fhe_rq_mul(const fhe_ntt_plan *plan, const uint64_t *a, int a_is_evals,
+                          const uint64_t *b, int b_is_evals, uint64_t *c, uint64_t *c_evals,
+                          uint64_t *a_evals_out, uint64_t *b_evals_out, size_t batch) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!a || !b || !c) return fail(FHE_E_NULL, "fhe_rq_mul: NULL operand");
+    int dev;
+    int rc = current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t bytes = batch * plan->n * sizeof(u64);
+    DevBuf da, db, dc, dce;
+    if ((rc = da.alloc(bytes)) != FHE_OK) return rc;
+    if ((rc = db.alloc(bytes)) != FHE_OK) return rc;
+    if ((rc = dc.alloc(bytes)) != FHE_OK) return rc;
+    if (c_evals && (rc = dce.alloc(bytes)) != FHE_OK) return rc;
+    hipStream_t st = hipStreamPerThread;
+    HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, st));
+    // forward transforms run in place on the staged copies, which then ARE the evals
+    rc = fhe_rq_mul_dev(plan, da.p, a_is_evals, db.p, b_is_evals, dc.p, dce.p,
+                        a_is_evals ? nullptr : da.p, b_is_evals ? nullptr : db.p, batch, nullptr, st);
+    if (rc != FHE_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c, dc.p, bytes, hipMemcpyDeviceToHost, st));
+    if (c_evals) HIP_TRY(hipMemcpyAsync(c_evals, dce.p, bytes, hipMemcpyDeviceToHost, st));
+    if (a_evals_out) HIP_TRY(hipMemcpyAsync(a_evals_out, da.p, bytes, hipMemcpyDeviceToHost, st));
+    if (b_evals_out) HIP_TRY(hipMemcpyAsync(b_evals_out, db.p, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FHE_OK;
+}
+
+extern "C" int fhe_rq_mul_checked(const fhe_ntt_plan *plan_a, const fhe_ntt_plan *plan_b,
+                                  const uint64_t *a, const uint64_t *b, uint64_t *c,
+                                  uint64_t *c_evals, size_t batch) {
+    if (!plan_a || !plan_b) return fail(FHE_E_NULL, "plan is NULL");
+    if (plan_a->q != plan_b->q || plan_a->n != plan_b->n)
+        return fail(FHE_E_PARAM_MISMATCH,
+                    "operands have different RingParam: (q=%llu,n=%llu) vs (q=%llu,n=%llu) "
+                    "(assert_eq!(lhs.param, rhs.param), ring_nq.rs:565,587)",
+                    (unsigned long long)plan_a->q, (unsigned long long)plan_a->n,
+                    (unsigned long long)plan_b->q, (unsigned long long)plan_b->n);
+    return fhe_rq_mul(plan_a, a, 0, b, 0, c, c_evals, nullptr, nullptr, batch);
+}
+
+extern "C" int fhe_rq_pointwise_mul(const fhe_ntt_plan *plan, const uint64_t *a, const uint64_t *b,
+                                    uint64_t *c, size_t batch) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!a || !b || !c) return fail(FHE_E_NULL, "fhe_rq_pointwise_mul: NULL buffer");
+    int dev;
+    int rc = current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t bytes = batch * plan->n * sizeof(u64);
+    DevBuf da, db;
+    if ((rc = da.alloc(bytes)) != FHE_OK) return rc;
+    if ((rc = db.alloc(bytes)) != FHE_OK) return rc;
+    hipStream_t st = hipStreamPerThread;
+    HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, st));
+    rc = fhe_rq_pointwise_mul_dev(plan, da.p, db.p, da.p, batch, st);
+    if (rc != FHE_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c, da.p, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FHE_OK;
+}
+
+extern "C" int fhe_rq_check_canonical(const fhe_ntt_plan *plan, const uint64_t *x, size_t batch) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (!x) return fail(FHE_E_NULL, "fhe_rq_check_canonical: NULL buffer");
+    int dev;
+    int rc = current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t count = batch * plan->n, bytes = count * sizeof(u64);
+    DevBuf dx, df;
+    if ((rc = dx.alloc(bytes)) != FHE_OK) return rc;
+    if ((rc = df.alloc(sizeof(int))) != FHE_OK) return rc;
+    hipStream_t st = hipStreamPerThread;
+    HIP_TRY(hipMemcpyAsync(dx.p, x, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(df.p, 0, sizeof(int), st));
+    hipError_t e = fhe::launch_check_canonical((const u64 *)dx.p, count, plan->q, (int *)df.p, st);
+    if (e != hipSuccess) return hip_fail(e, "launch_check_canonical");
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, df.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flag) return fail(FHE_E_NOT_CANONICAL, "a coefficient >= q=%llu was found", (unsigned long long)plan->q);
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------
+extern "C" int fhe_ntt_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+extern "C" const char *fhe_last_error(void) { return g_err; }
+extern "C" const char *fhe_ntt_version(void) { return "fhe_ntt 0.1 (gfx950)"; }
+
+extern "C" int fhe_ntt_shutdown(void) {
+    {
+        std::lock_guard<std::mutex> lk(g_timing_lock);
+        timing_drain_locked();
+        g_timing.clear();
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_ws_lock);
+        for (auto &w : g_ws) {
+            if (w.ptr) (void)hipFree(w.ptr);
+            w.ptr = nullptr;
+            w.bytes = 0;
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_plans_lock);
+    for (auto &kv : g_plans) {
+        fhe_ntt_plan *p = kv.second.get();
+        std::lock_guard<std::mutex> lk2(p->dev_lock);
+        for (auto &t : p->dev) {
+            if (t.tw_fwd) (void)hipFree(t.tw_fwd);
+            if (t.tw_inv) (void)hipFree(t.tw_inv);
+            t = DeviceTables();
+        }
+    }
+    g_plans.clear();
+    return FHE_OK;
+}

@@ -1,0 +1,630 @@
+// ntt_kernels.hip — batched negacyclic NTT / iNTT / pointwise kernels for gfx950.
+//
+// What is computed (bit-exact with the reference):
+//   forward  NTT::ntt   arith/src/ntt.rs:44-73   CT, natural in -> bit-reversed out
+//   inverse  NTT::intt  arith/src/ntt.rs:78-110  GS, bit-reversed in -> natural out, * n^-1
+//   pointwise           arith/src/ring_nq.rs:601-604
+// The reference walks one stage at a time over the whole polynomial, one u128 %
+// per butterfly.  Here the log2(n) stages are grouped into ROUNDS of up to four
+// stages that run entirely in registers (16 coefficients per thread); between
+// rounds the workgroup transposes through LDS; a polynomial that does not fit
+// one workgroup's LDS tile (n >= 2^14) is split into a STRIDED pass (the stages
+// with t >= 2^LB, columns of the n/2^LB x 2^LB view) and a CONTIGUOUS pass (the
+// last LB stages on 2^LB-coefficient blocks).  Every global access is a
+// coalesced slab: >=128 B runs per 16 lanes.
+//
+// Index algebra shared by all kernels (L = log2 n, stage s = 0..L-1 acts on bit
+// L-1-s of the coefficient index j, twiddle = roots[2^s + (j >> (L-s))], exactly
+// ntt.rs:54 `roots_of_unity[m + i]` with m = 2^s, i = j / 2t):
+//   a pass covers LP consecutive stages, i.e. an LP-bit FIELD f of j; the bits of
+//   j above the field are `blk`, with s0 of them; local stage ls = s - s0;
+//   twiddle index = (1 << (s0+ls)) + (blk << ls) + (f >> (LP-ls)).
+//   A round holds field bits [a, a+4) in registers (k = those 4 bits) and runs
+//   the stages for bits a+3, a+2, ... ; with H = f >> (a+4) the index of stage i
+//   of the round is (T0 << i) + (k >> (4-i)),  T0 = (1<<(s0+ls0)) + (blk<<ls0) + H.
+#include "ntt_kernels.hpp"
+#include "zq_device.hpp"
+
+namespace fhe {
+
+// ---------------------------------------------------------------------------
+// one round: R stages on the 16 register-resident coefficients
+// ---------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, u64 q,
+                                          u64 q2) {
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            const Tw t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l;
+                ct_bfly(v[k], v[k + span], t.w, t.wp, q, q2);
+            }
+        }
+    }
+}
+
+// FOLD: this round contains the transform's last GS stage (m = 1, ntt.rs:85 loop
+// exit) and the n^-1 scaling of ntt.rs:100-102 is folded into it:
+//   r[j] = (U+V)*n_inv,  r[j+t] = (U-V)*(roots_inv[1]*n_inv).
+template <int R, bool FOLD>
+__device__ __forceinline__ void round_inv(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, u64 q,
+                                          u64 q2, const Tw ninv, const Tw s_ninv) {
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            if (FOLD && i == 0) {
+#pragma unroll
+                for (int l = 0; l < span; l++) {
+                    const int k = g * 2 * span + l;
+                    const u64 s = v[k] + v[k + span];       // < 4q, any value is fine for Shoup
+                    const u64 d = v[k] - v[k + span] + q2;  // in (0,4q)
+                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, q);
+                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, q);
+                }
+            } else {
+                const Tw t = tw[(T0 << i) + g];
+#pragma unroll
+                for (int l = 0; l < span; l++) {
+                    const int k = g * 2 * span + l;
+                    gs_bfly(v[k], v[k + span], t.w, t.wp, q, q2);
+                }
+            }
+        }
+    }
+}
+
+// field value of register k for a thread whose non-register field bits are tf,
+// register window = field bits [A, A+4)
+template <int A>
+__device__ __forceinline__ u32 field_of(u32 tf, int k) {
+    const u32 lo = tf & ((1u << A) - 1u);
+    const u32 hi = tf >> A;
+    return (hi << (A + 4)) | ((u32)k << A) | lo;
+}
+
+// LDS slot of tile element e in the contiguous kernels: one 8-byte pad every 16
+// elements so that the a=0 window (lane stride 16 elements) is conflict-free.
+__device__ __forceinline__ u32 pad16(u32 e) { return e + (e >> 4); }
+
+// ---------------------------------------------------------------------------
+// CONTIGUOUS pass: blocks of M = 2^LP consecutive coefficients.
+// Workgroup = W units (unit = one M-block of one polynomial, all W units share
+// `blk`, hence the twiddles), TPB = M/16 threads per unit.
+// ---------------------------------------------------------------------------
+template <int LP>
+struct ContigCfg {
+    static constexpr int M = 1 << LP;
+    static constexpr int TPB = M / 16;
+    static constexpr int TH = (LP <= 12) ? 256 : 512;
+    static constexpr int W = TH / TPB;
+    static constexpr int TILE = W * M;  // = 16 * TH
+    static constexpr int NR = (LP + 3) / 4;
+    static constexpr int R0 = LP - 4 * (NR - 1);
+    static constexpr int A0 = LP - 4;  // register window of round 0 = top 4 field bits
+    static constexpr size_t LDS_BYTES = (size_t)(TILE + TILE / 16) * 8;
+    // window base of round j >= 1
+    static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
+    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
+};
+
+template <int LP, int AF, int AT>
+__device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u32 tf) {
+    constexpr int M = 1 << LP;
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16(w * M + field_of<AF>(tf, k))] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
+    __syncthreads();
+}
+
+template <int LP, bool FINAL>
+__global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u32 s0 = a.log_n - LP;
+    const u32 blk = blockIdx.x & ((1u << s0) - 1u);
+    const u64 pg = (u64)(blockIdx.x >> s0);
+    const u64 n = 1ull << a.log_n;
+    const u64 poly = pg * C::W + w;
+    const bool active = poly < a.batch;
+    const u64 base = poly * n + (u64)blk * C::M;
+    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Tw *__restrict__ tw = a.tw;
+
+    u64 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = active ? a.in[base + field_of<C::A0>(tf, k)] : 0ull;
+
+    round_fwd<C::R0>(v, tw, (1u << s0) + blk, q, q2);
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        exchange_contig<LP, C::A0, A>(v, lds, w, tf);
+        round_fwd<4>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        exchange_contig<LP, C::a_of(1), A>(v, lds, w, tf);
+        round_fwd<4>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2);
+    }
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        exchange_contig<LP, C::a_of(2), A>(v, lds, w, tf);
+        round_fwd<4>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2);
+    }
+    // transpose through LDS so the store is one contiguous slab per wave
+    constexpr int ALAST = C::a_of(C::NR - 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u64 x = FINAL ? canon4(v[k], q, q2) : v[k];
+        lds[pad16(w * C::M + field_of<ALAST>(tf, k))] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u32 e = i * C::TH + tid;
+        const u32 wu = e >> LP, f = e & (C::M - 1);
+        const u64 p = pg * C::W + wu;
+        if (p < a.batch) a.out[p * n + (u64)blk * C::M + f] = lds[pad16(e)];
+    }
+}
+
+// MUL_IN: the input is the pointwise product in .* in2 (fused
+// zip_eq(l,r).map(l*r), ring_nq.rs:601-604); if a.out2 != nullptr the product
+// (the `evals` of the result, ring_nq.rs:606) is also written there.
+template <int LP, bool FINAL, bool MUL_IN>
+__global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u32 s0 = a.log_n - LP;
+    const u32 blk = blockIdx.x & ((1u << s0) - 1u);
+    const u64 pg = (u64)(blockIdx.x >> s0);
+    const u64 n = 1ull << a.log_n;
+    const u64 poly = pg * C::W + w;
+    const bool active = poly < a.batch;
+    const u64 base = poly * n + (u64)blk * C::M;
+    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Tw *__restrict__ tw = a.tw;
+
+    // coalesced load -> LDS
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u32 e = i * C::TH + tid;
+        const u32 wu = e >> LP, f = e & (C::M - 1);
+        const u64 p = pg * C::W + wu;
+        u64 x = 0;
+        if (p < a.batch) {
+            const u64 g = p * n + (u64)blk * C::M + f;
+            x = a.in[g];
+            if (MUL_IN) {
+                x = mul_mod_var(x, a.in2[g], a.mod);
+                if (a.out2) a.out2[g] = x;
+            }
+        }
+        lds[pad16(e)] = x;
+    }
+    __syncthreads();
+    constexpr int ALAST = C::a_of(C::NR - 1);
+    u64 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * C::M + field_of<ALAST>(tf, k))];
+    __syncthreads();
+
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        exchange_contig<LP, A, C::a_of(2)>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        exchange_contig<LP, A, C::a_of(1)>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        exchange_contig<LP, A, C::A0>(v, lds, w, tf);
+    }
+    // FINAL implies s0 == 0 (this pass holds the m = 1 stage)
+    round_inv<C::R0, FINAL>(v, tw, (1u << s0) + blk, q, q2, a.ninv, a.s_ninv);
+
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            a.out[base + field_of<C::A0>(tf, k)] = FINAL ? canon2(v[k], q) : v[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// STRIDED pass: the first LA stages of a forward transform (last LA of an
+// inverse), on the (2^LA rows) x (2^LB columns) view of one polynomial.
+// Workgroup tile = all 2^LA rows x CW adjacent columns; lanes run along columns,
+// so every global access is a CW*8-byte contiguous run and LDS needs no padding.
+// ---------------------------------------------------------------------------
+template <int LA, int CW>
+struct StridedCfg {
+    static constexpr int F = 1 << LA;
+    static constexpr int TPF = F / 16;
+    static constexpr int TH = TPF * CW;
+    static constexpr int NR = (LA + 3) / 4;
+    static constexpr int R0 = LA - 4 * (NR - 1);
+    static constexpr int A0 = LA - 4;
+    static constexpr size_t LDS_BYTES = (size_t)F * CW * 8;
+    static constexpr int a_of(int j) { return j == 0 ? A0 : LA - R0 - 4 * j; }
+    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
+};
+
+template <int CW, int AF, int AT>
+__device__ __forceinline__ void exchange_strided(u64 (&v)[16], u64 *lds, u32 c, u32 tf) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[field_of<AF>(tf, k) * CW + c] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = lds[field_of<AT>(tf, k) * CW + c];
+    __syncthreads();
+}
+
+template <int LA, int CW>
+__global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kernel(PassArgs a) {
+    using C = StridedCfg<LA, CW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const u32 tid = threadIdx.x, c = tid % CW, tf = tid / CW;
+    const u32 lb = a.log_n - LA;               // log2 of the row length
+    const u32 lcg = lb - __builtin_ctz(CW);    // log2(column groups per polynomial)
+    const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
+    const u64 poly = (u64)(blockIdx.x >> lcg);
+    const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
+    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Tw *__restrict__ tw = a.tw;
+
+    u64 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = a.in[base + ((u64)field_of<C::A0>(tf, k) << lb)];
+
+    round_fwd<C::R0>(v, tw, 1u, q, q2);
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        exchange_strided<CW, C::A0, A>(v, lds, c, tf);
+        round_fwd<4>(v, tw, (1u << LS) + (tf >> A), q, q2);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        exchange_strided<CW, C::a_of(1), A>(v, lds, c, tf);
+        round_fwd<4>(v, tw, (1u << LS) + (tf >> A), q, q2);
+    }
+    constexpr int ALAST = C::a_of(C::NR - 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) a.out[base + ((u64)field_of<ALAST>(tf, k) << lb)] = v[k];  // lazy, < 4q
+}
+
+template <int LA, int CW>
+__global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kernel(PassArgs a) {
+    using C = StridedCfg<LA, CW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const u32 tid = threadIdx.x, c = tid % CW, tf = tid / CW;
+    const u32 lb = a.log_n - LA;
+    const u32 lcg = lb - __builtin_ctz(CW);
+    const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
+    const u64 poly = (u64)(blockIdx.x >> lcg);
+    const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
+    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Tw *__restrict__ tw = a.tw;
+
+    constexpr int ALAST = C::a_of(C::NR - 1);
+    u64 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = a.in[base + ((u64)field_of<ALAST>(tf, k) << lb)];  // < 2q
+
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        exchange_strided<CW, A, C::a_of(1)>(v, lds, c, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        exchange_strided<CW, A, C::A0>(v, lds, c, tf);
+    }
+    round_inv<C::R0, true>(v, tw, 1u, q, q2, a.ninv, a.s_ninv);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        a.out[base + ((u64)field_of<C::A0>(tf, k) << lb)] = canon2(v[k], q);
+}
+
+// ---------------------------------------------------------------------------
+// n in {2,4,8}: one thread per polynomial, stage loops as in the reference.
+// ---------------------------------------------------------------------------
+template <bool INV>
+__global__ __launch_bounds__(256) void ntt_tiny_kernel(PassArgs a) {
+    const u64 poly = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (poly >= a.batch) return;
+    const u32 n = 1u << a.log_n;
+    const u64 q = a.mod.q, q2 = a.mod.q2;
+    u64 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (u32)i < n ? a.in[poly * n + i] : 0ull;
+    if (!INV) {
+        for (u32 s = 0; s < a.log_n; s++) {
+            const u32 t = n >> (s + 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if ((u32)j < n && !((u32)j & t)) {
+                    const Tw w = a.tw[(1u << s) + ((u32)j >> (a.log_n - s))];
+                    // static register indexing: j + t is one of j+1, j+2, j+4
+                    u64 x = v[j], y = (t == 1) ? v[(j + 1) & 7] : (t == 2) ? v[(j + 2) & 7] : v[(j + 4) & 7];
+                    ct_bfly(x, y, w.w, w.wp, q, q2);
+                    v[j] = x;
+                    if (t == 1) v[(j + 1) & 7] = y; else if (t == 2) v[(j + 2) & 7] = y; else v[(j + 4) & 7] = y;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((u32)i < n) a.out[poly * n + i] = canon4(v[i], q, q2);
+    } else {
+        for (int s = (int)a.log_n - 1; s >= 0; s--) {
+            const u32 t = n >> (s + 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if ((u32)j < n && !((u32)j & t)) {
+                    const Tw w = a.tw[(1u << s) + ((u32)j >> (a.log_n - s))];
+                    u64 x = v[j], y = (t == 1) ? v[(j + 1) & 7] : (t == 2) ? v[(j + 2) & 7] : v[(j + 4) & 7];
+                    gs_bfly(x, y, w.w, w.wp, q, q2);
+                    v[j] = x;
+                    if (t == 1) v[(j + 1) & 7] = y; else if (t == 2) v[(j + 2) & 7] = y; else v[(j + 4) & 7] = y;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((u32)i < n)
+                a.out[poly * n + i] = canon2(mul_shoup_lazy(v[i], a.ninv.w, a.ninv.wp, q), q);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// element-wise kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pointwise_mul_kernel(const u64 *__restrict__ x,
+                                                            const u64 *__restrict__ y,
+                                                            u64 *__restrict__ z, u64 count, Mod m) {
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+        z[i] = mul_mod_var(x[i], y[i], m);
+}
+
+__global__ __launch_bounds__(256) void fill_synthetic_kernel(u64 *__restrict__ out, u64 count,
+                                                             u64 q, u64 seed, u64 first) {
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+        out[i] = __umul64hi(splitmix64(seed ^ (first + i)), q);
+}
+
+// any value >= q sets *flag (fhe_rq_check_canonical)
+__global__ __launch_bounds__(256) void check_canonical_kernel(const u64 *__restrict__ x, u64 count,
+                                                              u64 q, int *flag) {
+    const u64 stride = (u64)gridDim.x * 256;
+    int bad = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) bad |= (x[i] >= q);
+    if (bad) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline hipError_t post_launch() { return hipGetLastError(); }
+
+// dynamic LDS above 64 KiB must be opted into per kernel
+static inline hipError_t allow_big_lds(const void *fn, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int LP, bool FINAL>
+static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    const u64 nb = 1ull << (a.log_n - LP);
+    const u64 groups = (a.batch + C::W - 1) / C::W;
+    const u64 grid = nb * groups;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL>, C::LDS_BYTES)) return e;
+    KernelTimer kt(FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig", LP, st);
+    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL>), dim3((unsigned)grid), dim3(C::TH),
+                       C::LDS_BYTES, st, a);
+    return post_launch();
+}
+
+template <int LP, bool FINAL, bool MUL_IN>
+static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    const u64 nb = 1ull << (a.log_n - LP);
+    const u64 groups = (a.batch + C::W - 1) / C::W;
+    const u64 grid = nb * groups;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)ntt_inv_contig_kernel<LP, FINAL, MUL_IN>, C::LDS_BYTES)) return e;
+    KernelTimer kt(MUL_IN ? "ntt_inv_contig_mul" : (FINAL ? "ntt_inv_contig_final" : "ntt_inv_contig"), LP, st);
+    hipLaunchKernelGGL((ntt_inv_contig_kernel<LP, FINAL, MUL_IN>), dim3((unsigned)grid),
+                       dim3(C::TH), C::LDS_BYTES, st, a);
+    return post_launch();
+}
+
+template <int LA, int CW, bool INV>
+static hipError_t launch_strided(const PassArgs &a, hipStream_t st) {
+    using C = StridedCfg<LA, CW>;
+    const u64 ncg = (1ull << (a.log_n - LA)) / CW;
+    const u64 grid = ncg * a.batch;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    KernelTimer kt(INV ? "ntt_inv_strided" : "ntt_fwd_strided", LA, st);
+    if (INV)
+        hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW>), dim3((unsigned)grid), dim3(C::TH),
+                           C::LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW>), dim3((unsigned)grid), dim3(C::TH),
+                           C::LDS_BYTES, st, a);
+    return post_launch();
+}
+
+#define CONTIG_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+
+static hipError_t fwd_contig_dispatch(int lp, bool final, const PassArgs &a, hipStream_t st) {
+    switch (lp) {
+#define X(LP_) case LP_: return final ? launch_fwd_contig<LP_, true>(a, st) : launch_fwd_contig<LP_, false>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t inv_contig_dispatch(int lp, bool final, bool mul_in, const PassArgs &a,
+                                      hipStream_t st) {
+    switch (lp) {
+#define X(LP_)                                                                             \
+    case LP_:                                                                              \
+        if (final) return mul_in ? launch_inv_contig<LP_, true, true>(a, st)               \
+                                 : launch_inv_contig<LP_, true, false>(a, st);             \
+        return mul_in ? launch_inv_contig<LP_, false, true>(a, st)                         \
+                      : launch_inv_contig<LP_, false, false>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
+template <bool INV>
+static hipError_t strided_dispatch(int la, const PassArgs &a, hipStream_t st) {
+    switch (la) {
+        case 6: return launch_strided<6, 128, INV>(a, st);
+        case 7: return launch_strided<7, 64, INV>(a, st);
+        case 8: return launch_strided<8, 32, INV>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// pass split for n >= 2^14: LB = max(8, L-8) contiguous stages, LA = L-LB in 6..8
+static inline int contig_bits(int L) { return L <= kMaxSinglePassLog ? L : (L - 8 > 8 ? L - 8 : 8); }
+
+hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
+                              u64 batch_tile, hipStream_t st) {
+    PassArgs a{};
+    a.tw = p.tw_fwd;
+    a.mod = p.mod;
+    a.ninv = p.ninv;
+    a.s_ninv = p.s_ninv;
+    a.log_n = p.log_n;
+    const int L = p.log_n;
+    if (batch == 0) return hipSuccess;
+    if (L < 4) {
+        a.in = in; a.out = out; a.batch = batch;
+        KernelTimer kt("ntt_tiny_fwd", L, st);
+        hipLaunchKernelGGL(ntt_tiny_kernel<false>, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, a);
+        return post_launch();
+    }
+    if (L <= kMaxSinglePassLog) {
+        a.in = in; a.out = out; a.batch = batch;
+        return fwd_contig_dispatch(L, true, a, st);
+    }
+    const int LB = contig_bits(L), LA = L - LB;
+    const u64 n = 1ull << L;
+    if (batch_tile == 0) batch_tile = batch;
+    for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
+        const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile;
+        a.in = in + b0 * n; a.out = out + b0 * n; a.batch = nb;
+        hipError_t e = strided_dispatch<false>(LA, a, st);
+        if (e != hipSuccess) return e;
+        a.in = out + b0 * n;
+        e = fwd_contig_dispatch(LB, true, a, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// in2 != nullptr: transform the pointwise product in .* in2 (and write it to
+// evals_out when that is non-null).
+hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
+                              u64 *out, u64 batch, u64 batch_tile, hipStream_t st) {
+    PassArgs a{};
+    a.tw = p.tw_inv;
+    a.mod = p.mod;
+    a.ninv = p.ninv;
+    a.s_ninv = p.s_ninv;
+    a.log_n = p.log_n;
+    const int L = p.log_n;
+    if (batch == 0) return hipSuccess;
+    if (L < 4) {
+        const u64 *src = in;
+        if (in2) {  // tiny sizes: unfused pointwise into evals_out (or out) first
+            u64 *dst = evals_out ? evals_out : out;
+            hipError_t e = launch_pointwise_mul(p, in, in2, dst, batch << L, st);
+            if (e != hipSuccess) return e;
+            src = dst;
+        }
+        a.in = src; a.out = out; a.batch = batch;
+        KernelTimer kt("ntt_tiny_inv", L, st);
+        hipLaunchKernelGGL(ntt_tiny_kernel<true>, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, a);
+        return post_launch();
+    }
+    if (L <= kMaxSinglePassLog) {
+        a.in = in; a.in2 = in2; a.out2 = evals_out; a.out = out; a.batch = batch;
+        return inv_contig_dispatch(L, true, in2 != nullptr, a, st);
+    }
+    const int LB = contig_bits(L), LA = L - LB;
+    const u64 n = 1ull << L;
+    if (batch_tile == 0) batch_tile = batch;
+    for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
+        const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile;
+        a.in = in + b0 * n; a.in2 = in2 ? in2 + b0 * n : nullptr;
+        a.out2 = evals_out ? evals_out + b0 * n : nullptr;
+        a.out = out + b0 * n; a.batch = nb;
+        hipError_t e = inv_contig_dispatch(LB, false, in2 != nullptr, a, st);
+        if (e != hipSuccess) return e;
+        a.in = out + b0 * n; a.in2 = nullptr; a.out2 = nullptr;
+        e = strided_dispatch<true>(LA, a, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static inline unsigned ew_grid(u64 count) {
+    u64 g = (count + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    return (unsigned)(g ? g : 1);
+}
+
+hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
+                                hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    KernelTimer kt("pointwise_mul", 0, st);
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(ew_grid(count)), dim3(256), 0, st, x, y, z, count, p.mod);
+    return post_launch();
+}
+
+hipError_t launch_fill_synthetic(u64 *out, u64 count, u64 q, u64 seed, u64 first, hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    KernelTimer kt("fill_synthetic", 0, st);
+    hipLaunchKernelGGL(fill_synthetic_kernel, dim3(ew_grid(count)), dim3(256), 0, st, out, count, q, seed, first);
+    return post_launch();
+}
+
+hipError_t launch_check_canonical(const u64 *x, u64 count, u64 q, int *d_flag, hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(check_canonical_kernel, dim3(ew_grid(count)), dim3(256), 0, st, x, count, q, d_flag);
+    return post_launch();
+}
+
+}  // namespace fhe

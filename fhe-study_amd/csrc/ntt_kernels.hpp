@@ -1,0 +1,56 @@
+// ntt_kernels.hpp — internal interface between the C ABI (capi.hip) and the
+// kernels (ntt_kernels.hip).  Not part of the public boundary (include/fhe_ntt.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zq_device.hpp"
+
+namespace fhe {
+
+// n <= 2^13 runs as ONE contiguous pass (the whole polynomial is one LDS tile);
+// larger n is split into a strided and a contiguous pass.
+constexpr int kMaxSinglePassLog = 13;
+constexpr int kMaxLog = 20;
+
+// Per-device, per-(q,n) constants.  Tables are `n` entries of {w, floor(w*2^64/q)},
+// indexed exactly like the reference's `roots_of_unity[m+i]` (ntt.rs:54,88).
+struct DevicePlan {
+    const Tw *tw_fwd = nullptr;
+    const Tw *tw_inv = nullptr;
+    Mod mod{};
+    Tw ninv{};    // n^-1                     (ntt.rs:27-30)
+    Tw s_ninv{};  // roots_inv[1] * n^-1      (last GS stage folded with ntt.rs:100-102)
+    uint32_t log_n = 0;
+};
+
+struct PassArgs {
+    const u64 *in;
+    const u64 *in2;  // second operand of a fused pointwise product, or nullptr
+    u64 *out;
+    u64 *out2;       // where the fused pointwise product is also stored, or nullptr
+    const Tw *tw;
+    Mod mod;
+    Tw ninv, s_ninv;
+    u64 batch;
+    uint32_t log_n;
+};
+
+// Brackets one launch with HIP events when fhe_ntt_kernel_timing_enable(1).
+struct KernelTimer {
+    KernelTimer(const char *name, int tag, hipStream_t st);
+    ~KernelTimer();
+    void *slot_;
+    hipStream_t st_;
+};
+
+hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
+                              u64 batch_tile, hipStream_t st);
+hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
+                              u64 *out, u64 batch, u64 batch_tile, hipStream_t st);
+hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
+                                hipStream_t st);
+hipError_t launch_fill_synthetic(u64 *out, u64 count, u64 q, u64 seed, u64 first, hipStream_t st);
+hipError_t launch_check_canonical(const u64 *x, u64 count, u64 q, int *d_flag, hipStream_t st);
+
+}  // namespace fhe

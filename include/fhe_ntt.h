@@ -1,0 +1,147 @@
+/*
+ * fhe_ntt.h — C ABI of libfhe_ntt.so: the MI355X (gfx950) negacyclic-NTT engine
+ * for R_q = Z_q[X]/(X^N+1).
+ *
+ * This is the drop-in boundary for the hot path of arnaucube/fhe-study's
+ * `arith` crate.  The reference has no FFI of its own (it is 100 % safe Rust);
+ * the seam is the Rust API `arith::NTT::{ntt,intt}` and `ring_nq::{mul,mul_mut}`.
+ * Each entry point below names the reference item it replaces (paths relative
+ * to the reference root).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - Polynomials are `batch × n` row-major arrays of uint64_t coefficient
+ *     VALUES (the `v` of `Zq{q,v}`, arith/src/zq.rs:6-10), canonical: v < q.
+ *   - The caller owns every buffer; `out` may alias `in` (in-place).
+ *   - No function unwinds or aborts: every failure is a negative FHE_E_* code
+ *     and a message retrievable with fhe_last_error() (thread-local).  The
+ *     reference panics in the same situations; the Rust shim turns a non-zero
+ *     return into `panic!`.
+ *   - All functions are thread-safe.  Plans are immutable and owned by the
+ *     library until fhe_ntt_shutdown().
+ *   - `*_dev` variants take DEVICE pointers of the current HIP device and a
+ *     `hipStream_t` passed as `void*` (NULL = the default stream); they only
+ *     enqueue work and never synchronise.  Host-pointer variants copy
+ *     host→device→host around the same kernels and return when `out` is valid.
+ *   - There is no CPU fallback: without a HIP device every compute entry point
+ *     returns FHE_E_NO_DEVICE.
+ */
+#ifndef FHE_NTT_H
+#define FHE_NTT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes -------------------------------------------------------- */
+#define FHE_OK 0
+/* n is not a power of two (assert, arith/src/ntt.rs:116), n < 2 (degenerate
+ * in the reference, ntt.rs:139) or n > 2^20 (engine limit). */
+#define FHE_E_BAD_N (-1)
+/* (q-1) % 2n != 0 (assert, ntt.rs:117), q < 3, or q >= 2^62 (engine headroom
+ * for lazy reduction; the reference itself needs q < 2^63, zq.rs:225). */
+#define FHE_E_BAD_Q (-2)
+/* the k = 1,2,... search found no primitive 2n-th root (panic, ntt.rs:130). */
+#define FHE_E_NO_ROOT (-3)
+/* a NULL pointer where a buffer / plan is required. */
+#define FHE_E_NULL (-4)
+/* a HIP runtime call or kernel launch failed (message has the HIP error). */
+#define FHE_E_HIP (-5)
+/* no usable HIP device in this process. */
+#define FHE_E_NO_DEVICE (-6)
+/* operands of a ring multiply have different (q,n)
+ * (assert_eq!(lhs.param, rhs.param), arith/src/ring_nq.rs:565,587). */
+#define FHE_E_PARAM_MISMATCH (-7)
+/* a coefficient >= q was found by fhe_rq_check_canonical(). */
+#define FHE_E_NOT_CANONICAL (-8)
+/* invalid argument other than the above (e.g. bad flag, count overflow). */
+#define FHE_E_INVALID (-9)
+
+typedef struct fhe_ntt_plan fhe_ntt_plan; /* opaque */
+
+/* ---- plan cache: replaces `roots(q,n)` + CACHE, arith/src/ntt.rs:18-38 ---
+ * Memoised per (q,n).  Derives psi by the reference's k=1,2,.. search
+ * (ntt.rs:115-131), roots[i] = psi^bitrev(i) (ntt.rs:133-147), roots_inv[i] =
+ * roots[i]^-1 (ntt.rs:149-161; computed with one inversion + products, the
+ * values are identical) and n_inv (ntt.rs:27-30).  Host-only: needs no GPU. */
+int fhe_ntt_plan_get(uint64_t q, uint64_t n, const fhe_ntt_plan **out);
+int fhe_ntt_plan_info(const fhe_ntt_plan *plan, uint64_t *q, uint64_t *n, uint64_t *psi,
+                      uint64_t *n_inv);
+/* copies the n-entry tables (either pointer may be NULL). */
+int fhe_ntt_plan_tables(const fhe_ntt_plan *plan, uint64_t *roots, uint64_t *roots_inv);
+
+/* ---- transforms: host buffers ------------------------------------------- */
+/* NTT::ntt(&Rq)->Rq, arith/src/ntt.rs:44-73: natural order in, bit-reversed
+ * order out, canonical. */
+int fhe_ntt_forward(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t *out, size_t batch);
+/* NTT::intt(&Rq)->Rq, arith/src/ntt.rs:78-110 (includes the n_inv scaling). */
+int fhe_ntt_inverse(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t *out, size_t batch);
+
+/* Rq x Rq, arith/src/ring_nq.rs:564-607 (`mul`, `mul_mut`, the `Mul` impls
+ * :490-503 and Rq::mul :294-296).
+ *   a, b           operands, batch × n each.
+ *   a_is_evals /   non-zero: that operand pointer already holds NTT-domain
+ *   b_is_evals     values (the reference's cached `evals`, ring_nq.rs:590-599).
+ *   c              product coefficients (required).
+ *   c_evals        nullable: pointwise product in the NTT domain — the `evals`
+ *                  the reference attaches to the product (ring_nq.rs:606).
+ *   a_evals_out /  nullable: NTT(a), NTT(b) — what `mul_mut` stores back into
+ *   b_evals_out    its operands (ring_nq.rs:568-573). */
+int fhe_rq_mul(const fhe_ntt_plan *plan, const uint64_t *a, int a_is_evals, const uint64_t *b,
+               int b_is_evals, uint64_t *c, uint64_t *c_evals, uint64_t *a_evals_out,
+               uint64_t *b_evals_out, size_t batch);
+/* same with two plans, as the reference compares `param` of both operands;
+ * returns FHE_E_PARAM_MISMATCH unless they are the same (q,n). */
+int fhe_rq_mul_checked(const fhe_ntt_plan *plan_a, const fhe_ntt_plan *plan_b, const uint64_t *a,
+                       const uint64_t *b, uint64_t *c, uint64_t *c_evals, size_t batch);
+/* zip_eq(l,r).map(l*r), arith/src/ring_nq.rs:601-604: c[i] = a[i]*b[i] mod q */
+int fhe_rq_pointwise_mul(const fhe_ntt_plan *plan, const uint64_t *a, const uint64_t *b,
+                         uint64_t *c, size_t batch);
+/* FHE_OK, or FHE_E_NOT_CANONICAL if any of the batch*n values is >= q. */
+int fhe_rq_check_canonical(const fhe_ntt_plan *plan, const uint64_t *x, size_t batch);
+
+/* ---- transforms: device-resident buffers -------------------------------- */
+int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, void *d_out, size_t batch,
+                        void *hip_stream);
+int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, void *d_out, size_t batch,
+                        void *hip_stream);
+/* d_work: device scratch of fhe_rq_mul_workspace_bytes(plan,batch) bytes, or
+ * NULL to use a library-owned grow-only workspace (not graph-capturable while
+ * it grows). */
+int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_is_evals, const void *d_b,
+                   int b_is_evals, void *d_c, void *d_c_evals, void *d_a_evals_out,
+                   void *d_b_evals_out, size_t batch, void *d_work, void *hip_stream);
+size_t fhe_rq_mul_workspace_bytes(const fhe_ntt_plan *plan, size_t batch);
+int fhe_rq_pointwise_mul_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c,
+                             size_t batch, void *hip_stream);
+/* Synthetic coefficients: x[i] = mulhi64(splitmix64(seed ^
+ * (first_index+i)), q), generated on the device. */
+int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_index, size_t count,
+                           void *d_out, void *hip_stream);
+
+/* ---- tuning / measurement ----------------------------------------------- */
+/* Polynomials per launch for two-pass sizes (n >= 2^14): the batch is walked
+ * in tiles so the intermediate of pass A is still in the 256 MiB Infinity
+ * Cache when pass B reads it.  0 restores the default. */
+int fhe_ntt_set_batch_tile(size_t polys);
+/* When enabled, every kernel launch is bracketed by HIP events on its stream;
+ * fhe_ntt_kernel_timing_read() synchronises, and returns per-kernel totals
+ * since the last reset.  `names` receives up to `cap` NUL-terminated names of
+ * at most 63 chars (64-byte slots), `total_ms`/`launches` the matching sums.
+ * Returns the number of distinct kernels recorded (may exceed cap). */
+int fhe_ntt_kernel_timing_enable(int on);
+int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_t *launches, int cap);
+int fhe_ntt_kernel_timing_reset(void);
+
+/* ---- misc ---------------------------------------------------------------- */
+int fhe_ntt_device_count(void);            /* HIP devices visible (0 if none) */
+const char *fhe_last_error(void);          /* thread-local, never NULL */
+const char *fhe_ntt_version(void);
+int fhe_ntt_shutdown(void);                /* frees plans, tables, workspaces */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHE_NTT_H */

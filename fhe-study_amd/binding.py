@@ -79,6 +79,25 @@ _int = ctypes.c_int
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).
+    Two HIP runtimes in one process cannot both own the GPU, so if torch is installed its
+    copy is loaded first and libfhe_ntt.so binds to it — whichever of the two the process
+    imports first.  torch itself is NOT imported here."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass  # fall back to the loader's default search (RUNPATH /opt/rocm/lib)
+
+
 def load_library():
     """dlopen the in-tree library; raises if it has not been built."""
     global _lib
@@ -88,6 +107,7 @@ def load_library():
         raise FileNotFoundError(
             f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no fallback path")
+    _preload_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     L.fhe_ntt_plan_get.argtypes = [_u64, _u64, ctypes.POINTER(_vp)]
     L.fhe_ntt_plan_info.argtypes = [_vp, _p64, _p64, _p64, _p64]

@@ -137,9 +137,9 @@ def test_other_moduli_and_extreme_values(pkg, oracle, q):
         a = np.stack(rows)
         b = a[::-1].copy()
         plan = pkg.Plan(q, n)
-        assert np.array_equal(plan.forward(a), oracle.ntt(q, n, a).reshape(-1))
-        assert np.array_equal(plan.inverse(a), oracle.intt(q, n, a).reshape(-1))
-        assert np.array_equal(plan.rq_mul(a, b)[0], oracle.rq_mul(q, n, a, b)[0].reshape(-1))
+        assert np.array_equal(plan.forward(a).reshape(-1), oracle.ntt(q, n, a).reshape(-1))
+        assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1))
+        assert np.array_equal(plan.rq_mul(a, b)[0].reshape(-1), oracle.rq_mul(q, n, a, b)[0].reshape(-1))
         assert (plan.forward(a) < q).all() and (plan.inverse(a) < q).all()
 
 

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfhe_ntt.so")
+LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")  # env: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["capi.hip", "ntt_kernels.hip"]
 HEADERS = ["ntt_kernels.hpp", "zq_device.hpp", os.path.join("..", "..", "include", "fhe_ntt.h")]

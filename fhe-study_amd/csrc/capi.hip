@@ -136,6 +136,10 @@ static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
 
     p->mod.q = q;
     p->mod.q2 = 2 * q;
+    p->mod.nq = (u64)0 - q;
+    p->mod.neg2q = (u64)0 - 2 * q;
+    p->mod.neg4q = (u64)0 - 4 * q;  // only used when q < 2^61
+    p->mod.q2p1 = 2 * q + 1;
     p->mod.r64 = (u64)((((u128)1) << 64) % q);
     p->mod.r64p = shoup(p->mod.r64, q);
     p->mod.onep = (u64)((((u128)1) << 64) / q);
@@ -222,6 +226,7 @@ static int device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     dp->ninv = plan->ninv;
     dp->s_ninv = plan->s_ninv;
     dp->log_n = plan->log_n;
+    dp->wide = (plan->q >> 61) == 0;
     return FHE_OK;
 }
 
@@ -364,11 +369,21 @@ extern "C" int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_
 // ---------------------------------------------------------------------------
 // device-resident entry points
 // ---------------------------------------------------------------------------
+// the kernels move 16 bytes per lane where a thread owns consecutive coefficients
+static inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+#define REQUIRE_ALIGNED(p)                                                                   \
+    do {                                                                                     \
+        if ((p) && misaligned(p))                                                            \
+            return fail(FHE_E_INVALID, #p " must be 16-byte aligned (got %p)", (const void *)(p)); \
+    } while (0)
+
 extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, void *d_out,
                                    size_t batch, void *hip_stream) {
     if (!plan) return fail(FHE_E_NULL, "plan is NULL");
     if (batch == 0) return FHE_OK;
     if (!d_in || !d_out) return fail(FHE_E_NULL, "fhe_ntt_forward_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_in);
+    REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     int rc = device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
@@ -383,6 +398,8 @@ extern "C" int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, v
     if (!plan) return fail(FHE_E_NULL, "plan is NULL");
     if (batch == 0) return FHE_OK;
     if (!d_in || !d_out) return fail(FHE_E_NULL, "fhe_ntt_inverse_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_in);
+    REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     int rc = device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
@@ -404,6 +421,13 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
     if (!plan) return fail(FHE_E_NULL, "plan is NULL");
     if (batch == 0) return FHE_OK;
     if (!d_a || !d_b || !d_c) return fail(FHE_E_NULL, "fhe_rq_mul_dev: NULL operand");
+    REQUIRE_ALIGNED(d_a);
+    REQUIRE_ALIGNED(d_b);
+    REQUIRE_ALIGNED(d_c);
+    REQUIRE_ALIGNED(d_c_evals);
+    REQUIRE_ALIGNED(d_a_evals_out);
+    REQUIRE_ALIGNED(d_b_evals_out);
+    REQUIRE_ALIGNED(d_work);
     fhe::DevicePlan dp;
     int rc = device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;

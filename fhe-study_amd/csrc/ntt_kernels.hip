@@ -25,24 +25,39 @@
 #include "ntt_kernels.hpp"
 #include "zq_device.hpp"
 
+#include <cstdlib>
+
 namespace fhe {
 
 // ---------------------------------------------------------------------------
 // one round: R stages on the 16 register-resident coefficients
 // ---------------------------------------------------------------------------
-template <int R>
-__device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, u64 q,
-                                          u64 q2) {
+// Lazy ranges of the forward rounds:
+//   WIDE (q < 2^61, 8q < 2^64): a stage without correction takes x < 6q to x,y < 8q, a
+//   stage that first subtracts 4q from x >= 4q takes x < 8q to x,y < 6q; corrections sit
+//   on stages R-1, R-3, .. of a round, so every round ends below 6q: one conditional
+//   subtraction per TWO butterflies.
+//   otherwise (q < 2^62): Harvey's [0,4q) with a 2q correction in every butterfly.
+template <int R, bool WIDE>
+__device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
+                                          const Mod &m) {
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int span = 8 >> i;
+        constexpr int kNone = 0;
+        const bool corr = ((R - 1 - i) & 1) == 0;
+#ifdef FHE_ABLATE_NO_BUTTERFLIES   // timing-only build: memory pattern without the arithmetic
+        if (i >= 0) continue;
+#endif
 #pragma unroll
         for (int g = 0; g < (1 << i); g++) {
             const Tw t = tw[(T0 << i) + g];
 #pragma unroll
             for (int l = 0; l < span; l++) {
                 const int k = g * 2 * span + l;
-                ct_bfly(v[k], v[k + span], t.w, t.wp, q, q2);
+                if (!WIDE) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
+                else if (corr) ct_bfly<4>(v[k], v[k + span], t.w, t.wp, m);
+                else ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
             }
         }
     }
@@ -52,8 +67,8 @@ __device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ t
 // exit) and the n^-1 scaling of ntt.rs:100-102 is folded into it:
 //   r[j] = (U+V)*n_inv,  r[j+t] = (U-V)*(roots_inv[1]*n_inv).
 template <int R, bool FOLD>
-__device__ __forceinline__ void round_inv(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, u64 q,
-                                          u64 q2, const Tw ninv, const Tw s_ninv) {
+__device__ __forceinline__ void round_inv(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
+                                          const Mod &m, const Tw ninv, const Tw s_ninv) {
 #pragma unroll
     for (int i = R - 1; i >= 0; i--) {
         const int span = 8 >> i;
@@ -63,17 +78,17 @@ __device__ __forceinline__ void round_inv(u64 (&v)[16], const Tw *__restrict__ t
 #pragma unroll
                 for (int l = 0; l < span; l++) {
                     const int k = g * 2 * span + l;
-                    const u64 s = v[k] + v[k + span];       // < 4q, any value is fine for Shoup
-                    const u64 d = v[k] - v[k + span] + q2;  // in (0,4q)
-                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, q);
-                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, q);
+                    const u64 s = add64(v[k], v[k + span]);                    // < 4q, fine for Shoup
+                    const u64 d = add64(add64(v[k], m.q2p1), ~v[k + span]);    // x - y + 2q
+                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, m);
+                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, m);
                 }
             } else {
                 const Tw t = tw[(T0 << i) + g];
 #pragma unroll
                 for (int l = 0; l < span; l++) {
                     const int k = g * 2 * span + l;
-                    gs_bfly(v[k], v[k + span], t.w, t.wp, q, q2);
+                    gs_bfly(v[k], v[k + span], t.w, t.wp, m);
                 }
             }
         }
@@ -125,7 +140,7 @@ __device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u
     __syncthreads();
 }
 
-template <int LP, bool FINAL>
+template <int LP, bool FINAL, bool WIDE>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -138,34 +153,37 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     const u64 poly = pg * C::W + w;
     const bool active = poly < a.batch;
     const u64 base = poly * n + (u64)blk * C::M;
-    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Mod &m = a.mod;
     const Tw *__restrict__ tw = a.tw;
 
     u64 v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = active ? a.in[base + field_of<C::A0>(tf, k)] : 0ull;
 
-    round_fwd<C::R0>(v, tw, (1u << s0) + blk, q, q2);
+    round_fwd<C::R0, WIDE>(v, tw, (1u << s0) + blk, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         exchange_contig<LP, C::A0, A>(v, lds, w, tf);
-        round_fwd<4>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2);
+        round_fwd<4, WIDE>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         exchange_contig<LP, C::a_of(1), A>(v, lds, w, tf);
-        round_fwd<4>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2);
+        round_fwd<4, WIDE>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
         exchange_contig<LP, C::a_of(2), A>(v, lds, w, tf);
-        round_fwd<4>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2);
+        round_fwd<4, WIDE>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m);
     }
-    // transpose through LDS so the store is one contiguous slab per wave
+    // transpose through LDS so the store is one contiguous slab per wave.  (Storing the 128
+    // contiguous bytes a thread owns after the last round as 8 x 16 B straight from registers
+    // was measured slower for the forward kernel: 4.91 ms vs 4.40 ms per 16384 polynomials;
+    // the mirrored direct 16-byte LOADS of the inverse kernel are faster: 4.69 vs 5.79 ms.)
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u64 x = FINAL ? canon4(v[k], q, q2) : v[k];
+        const u64 x = FINAL ? (WIDE ? canon8(v[k], m) : canon4(v[k], m)) : v[k];
         lds[pad16(w * C::M + field_of<ALAST>(tf, k))] = x;
     }
     __syncthreads();
@@ -194,55 +212,63 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     const u64 poly = pg * C::W + w;
     const bool active = poly < a.batch;
     const u64 base = poly * n + (u64)blk * C::M;
-    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Mod &m = a.mod;
     const Tw *__restrict__ tw = a.tw;
 
-    // coalesced load -> LDS
+    // first window = field bits [0,4): a thread's 16 coefficients are 128 contiguous bytes,
+    // fetched as 8 x 16 B straight into registers (no staging through LDS)
+    constexpr int ALAST = C::a_of(C::NR - 1);
+    static_assert(ALAST == 0, "first inverse window is the low 4 bits");
+    u64 v[16];
+    {
+        const u64 g0 = base + (u64)tf * 16;
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.in + g0);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const u32 e = i * C::TH + tid;
-        const u32 wu = e >> LP, f = e & (C::M - 1);
-        const u64 p = pg * C::W + wu;
-        u64 x = 0;
-        if (p < a.batch) {
-            const u64 g = p * n + (u64)blk * C::M + f;
-            x = a.in[g];
-            if (MUL_IN) {
-                x = mul_mod_var(x, a.in2[g], a.mod);
-                if (a.out2) a.out2[g] = x;
+        for (int j = 0; j < 8; j++) {
+            ulonglong2 x{0, 0};
+            if (active) x = src[j];
+            v[2 * j] = x.x;
+            v[2 * j + 1] = x.y;
+        }
+        if constexpr (MUL_IN) {
+            const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(a.in2 + g0);
+            ulonglong2 *dst2 = reinterpret_cast<ulonglong2 *>(a.out2 + g0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                ulonglong2 y{0, 0};
+                if (active) y = src2[j];
+                ulonglong2 p;
+                p.x = mul_mod_var(v[2 * j], y.x, a.mod);
+                p.y = mul_mod_var(v[2 * j + 1], y.y, a.mod);
+                v[2 * j] = p.x;
+                v[2 * j + 1] = p.y;
+                if (a.out2 && active) dst2[j] = p;
             }
         }
-        lds[pad16(e)] = x;
     }
-    __syncthreads();
-    constexpr int ALAST = C::a_of(C::NR - 1);
-    u64 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * C::M + field_of<ALAST>(tf, k))];
-    __syncthreads();
 
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
-        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::a_of(2)>(v, lds, w, tf);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::a_of(1)>(v, lds, w, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::A0>(v, lds, w, tf);
     }
     // FINAL implies s0 == 0 (this pass holds the m = 1 stage)
-    round_inv<C::R0, FINAL>(v, tw, (1u << s0) + blk, q, q2, a.ninv, a.s_ninv);
+    round_inv<C::R0, FINAL>(v, tw, (1u << s0) + blk, m, a.ninv, a.s_ninv);
 
     if (active) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            a.out[base + field_of<C::A0>(tf, k)] = FINAL ? canon2(v[k], q) : v[k];
+            a.out[base + field_of<C::A0>(tf, k)] = FINAL ? canon2(v[k], m) : v[k];
     }
 }
 
@@ -275,7 +301,7 @@ __device__ __forceinline__ void exchange_strided(u64 (&v)[16], u64 *lds, u32 c, 
     __syncthreads();
 }
 
-template <int LA, int CW>
+template <int LA, int CW, bool WIDE>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kernel(PassArgs a) {
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -286,27 +312,27 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
     const u64 poly = (u64)(blockIdx.x >> lcg);
     const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
-    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Mod &m = a.mod;
     const Tw *__restrict__ tw = a.tw;
 
     u64 v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = a.in[base + ((u64)field_of<C::A0>(tf, k) << lb)];
 
-    round_fwd<C::R0>(v, tw, 1u, q, q2);
+    round_fwd<C::R0, WIDE>(v, tw, 1u, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         exchange_strided<CW, C::A0, A>(v, lds, c, tf);
-        round_fwd<4>(v, tw, (1u << LS) + (tf >> A), q, q2);
+        round_fwd<4, WIDE>(v, tw, (1u << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         exchange_strided<CW, C::a_of(1), A>(v, lds, c, tf);
-        round_fwd<4>(v, tw, (1u << LS) + (tf >> A), q, q2);
+        round_fwd<4, WIDE>(v, tw, (1u << LS) + (tf >> A), m);
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
-    for (int k = 0; k < 16; k++) a.out[base + ((u64)field_of<ALAST>(tf, k) << lb)] = v[k];  // lazy, < 4q
+    for (int k = 0; k < 16; k++) a.out[base + ((u64)field_of<ALAST>(tf, k) << lb)] = v[k];  // lazy: < 4q, or < 6q (WIDE)
 }
 
 template <int LA, int CW>
@@ -320,7 +346,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
     const u64 poly = (u64)(blockIdx.x >> lcg);
     const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
-    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Mod &m = a.mod;
     const Tw *__restrict__ tw = a.tw;
 
     constexpr int ALAST = C::a_of(C::NR - 1);
@@ -330,18 +356,261 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
 
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::a_of(1)>(v, lds, c, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), q, q2, a.ninv, a.s_ninv);
+        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::A0>(v, lds, c, tf);
     }
-    round_inv<C::R0, true>(v, tw, 1u, q, q2, a.ninv, a.s_ninv);
+    round_inv<C::R0, true>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        a.out[base + ((u64)field_of<C::A0>(tf, k) << lb)] = canon2(v[k], q);
+        a.out[base + ((u64)field_of<C::A0>(tf, k) << lb)] = canon2(v[k], m);
+}
+
+// ---------------------------------------------------------------------------
+// PERSISTENT, LDS-DMA fed variants of the two passes (the n = 2^16 path).
+//
+// Why: a pass is fabric-bound (measured copy rate 5.4 TB/s read+write, tools/
+// ubench_mem.hip), and a workgroup that loads, computes and stores in sequence
+// leaves HBM idle while it computes — LDS caps a CU at ~18 waves of this shape, too
+// few to cover that by occupancy alone (PMC: 34 % of wave time parked in waits).
+// Here a workgroup lives for many work items and the NEXT item's tile is fetched by
+// `global_load_lds_dwordx4` (16 B per lane, no VGPRs, no VALU) into the second of two
+// LDS buffers while the current item is in its butterflies; the results of item i-1
+// drain to HBM at the same time.  Per item the wave executes one `s_waitcnt vmcnt(0)`
+// at a point where everything outstanding was issued a full item ago.
+//
+//   iteration i (buffer `cur` holds item i, complete and visible):
+//     issue DMA(item i+1) -> buf[1-cur]      (last read one iteration ago, before E)
+//     registers <- buf[cur] (round-0 window);  barrier
+//     round 0;  scatter -> buf[cur];  barrier;  gather (next window);  round 1 ...
+//     s_waitcnt vmcnt(0)   (DMA(i+1) and the stores of item i-1: both old)
+//     global stores of item i;  barrier (E);  cur ^= 1
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+// stage a pass-local twiddle table into LDS: local index li in [1, M): ls = floor(log2 li),
+// global index (1 << (s0+ls)) + (blk << ls) + (li - 2^ls); the rounds then index it with
+// T0 = (1 << ls0) + H, i.e. as if the pass were a transform of its own.
+template <int M, int TH>
+__device__ __forceinline__ void stage_twiddles(Tw *ltw, const Tw *__restrict__ tw, u32 s0, u32 blk,
+                                               u32 tid) {
+    for (u32 li = tid; li < (u32)M; li += TH) {
+        Tw t{0, 0};
+        if (li) {
+            const u32 ls = 31u - (u32)__builtin_clz(li);
+            t = tw[(1u << (s0 + ls)) + (blk << ls) + (li - (1u << ls))];
+        }
+        ltw[li] = t;
+    }
+}
+
+// one LDS-DMA wave-instruction: lane l copies 16 B from gsrc to LDS byte lds_dst + 16*l.
+// m0 is compiler-reserved: saved and restored inside the statement (guide §5.7).
+__device__ __forceinline__ void dma16(const void *gsrc, u32 lds_dst_uniform) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ u32 xrow(u32 f) { return f ^ ((f >> 4) & 1u); }
+
+template <int LA, int CW>
+struct StridedDmaCfg {
+    static constexpr int F = 1 << LA;
+    static constexpr int TPF = F / 16;
+    static constexpr int TH = TPF * CW;            // 256 for LA = 8, CW = 16
+    static constexpr int WAVES = TH / 64;
+    static constexpr int NR = (LA + 3) / 4;
+    static constexpr int R0 = LA - 4 * (NR - 1);
+    static constexpr int A0 = LA - 4;
+    static constexpr int TILE_BYTES = F * CW * 8;
+    static constexpr int CHUNKS = TILE_BYTES / 1024;          // wave-instructions per tile
+    static constexpr int CHUNKS_PER_WAVE = CHUNKS / WAVES;
+    static constexpr int LANES_PER_ROW = CW * 8 / 16;         // 16-byte pieces per row segment
+    static constexpr int ROWS_PER_CHUNK = 64 / LANES_PER_ROW;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)TILE_BYTES + (size_t)F * sizeof(Tw);
+    static constexpr int a_of(int j) { return j == 0 ? A0 : LA - R0 - 4 * j; }
+    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
+    static_assert(NR == 2, "two rounds");
+    static_assert(CHUNKS % WAVES == 0 && 64 % LANES_PER_ROW == 0, "tile must split into whole wave chunks");
+};
+
+template <int LA, int CW, bool WIDE>
+__global__ __launch_bounds__((StridedDmaCfg<LA, CW>::TH)) void ntt_fwd_strided_dma_kernel(PassArgs a) {
+    using C = StridedDmaCfg<LA, CW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + 2 * C::TILE_BYTES);
+    const u32 lds_base = (u32)(uintptr_t)(lds_byte *)smem_raw;
+    const u32 tid = threadIdx.x, c = tid % CW, tf = tid / CW;
+    const u32 lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 lb = a.log_n - LA;               // log2 of the row length
+    const u32 lcg = lb - __builtin_ctz(CW);    // log2(column groups per polynomial)
+    const u64 items = a.batch << lcg;
+    const Mod &m = a.mod;
+    for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
+    const Tw *tw = ltw;
+
+    auto base_of = [&](u64 item) -> u64 {       // element index of (row 0, column 0 of the group)
+        const u64 cg = item & ((1ull << lcg) - 1ull), poly = item >> lcg;
+        return (poly << a.log_n) + cg * CW;
+    };
+    // lane's share of a tile fetch: row (lane / LANES_PER_ROW) of each chunk, 16-byte piece lane % LANES_PER_ROW
+    const u32 lrow = lane / C::LANES_PER_ROW, lpiece = lane % C::LANES_PER_ROW;
+    auto fetch = [&](u64 item, u32 buf) {
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.in + base_of(item)) + lpiece * 16;
+#pragma unroll
+        for (int i = 0; i < C::CHUNKS_PER_WAVE; i++) {
+            const u32 chunk = wave * C::CHUNKS_PER_WAVE + i;
+            const u64 row = (u64)chunk * C::ROWS_PER_CHUNK + lrow;
+            dma16(src + ((row << lb) << 3), lds_base + buf * C::TILE_BYTES + chunk * 1024);
+        }
+    };
+
+    u64 item = blockIdx.x;
+    u32 cur = 0;
+    if (item < items) fetch(item, 0);
+    wait_vmem_all();
+    __syncthreads();   // tile 0 and the twiddles are in LDS
+    for (; item < items; item += gridDim.x) {
+        const u64 nitem = item + gridDim.x;
+        if (nitem < items) fetch(nitem, cur ^ 1u);
+        u64 *lds = reinterpret_cast<u64 *>(smem_raw + cur * C::TILE_BYTES);
+        u64 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[field_of<C::A0>(tf, k) * CW + c];
+        __syncthreads();
+        round_fwd<C::R0, WIDE>(v, tw, 1u, m);
+        {
+            constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+            // rows are swizzled (row ^= bit 4 of row) in the exchange so that the gather,
+            // whose two row values per 32-lane group differ by 16, covers all 64 banks
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[xrow(field_of<C::A0>(tf, k)) * CW + c] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[xrow(field_of<A>(tf, k)) * CW + c];
+            round_fwd<4, WIDE>(v, tw, (1u << LS) + (tf >> A), m);
+        }
+        wait_vmem_all();
+        constexpr int ALAST = C::a_of(C::NR - 1);
+        const u64 base = base_of(item) + c;
+#pragma unroll
+        for (int k = 0; k < 16; k++) a.out[base + ((u64)field_of<ALAST>(tf, k) << lb)] = v[k];  // lazy
+        __syncthreads();
+        cur ^= 1u;
+    }
+}
+
+// contiguous pass, LP = 8: work item = 16 polynomials x one 256-coefficient block `blk`
+// (fixed for the life of the workgroup, so its 255 twiddles sit in LDS).
+// DMA layout: unit w (2 KiB) lands at byte w*2048 with its 16-byte pieces rotated by 8*w
+// (piece p of the unit at slot (p + 8*w) mod 128), so that the round-0 gather — 16 lanes
+// per unit, 4 units per wave — spreads over all 64 banks.
+template <int LP>
+struct ContigDmaCfg {
+    static constexpr int M = 1 << LP;              // 256
+    static constexpr int TPB = M / 16;             // 16 threads per unit
+    static constexpr int TH = 256;
+    static constexpr int W = TH / TPB;             // 16 units per item
+    static constexpr int WAVES = TH / 64;
+    static constexpr int UNIT_BYTES = M * 8;       // 2048
+    static constexpr int TILE = W * M;
+    static constexpr int BUF_BYTES = (TILE + TILE / 16) * 8;   // padded layout must fit too
+    static constexpr int PIECES = UNIT_BYTES / 16; // 128 pieces per unit
+    static constexpr int CHUNKS = W * UNIT_BYTES / 1024;       // 32 wave-instructions per item
+    static constexpr int CHUNKS_PER_WAVE = CHUNKS / WAVES;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + (size_t)M * sizeof(Tw);
+    static_assert(LP == 8, "two radix-16 rounds");
+};
+
+template <int LP, bool FINAL, bool WIDE>
+__global__ __launch_bounds__(ContigDmaCfg<LP>::TH) void ntt_fwd_contig_dma_kernel(PassArgs a) {
+    using C = ContigDmaCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + 2 * C::BUF_BYTES);
+    const u32 lds_base = (u32)(uintptr_t)(lds_byte *)smem_raw;
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u32 lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 s0 = a.log_n - LP;
+    const u32 blk = blockIdx.x & ((1u << s0) - 1u);
+    const u32 chunk0 = blockIdx.x >> s0, nchunks = gridDim.x >> s0;
+    const u64 n = 1ull << a.log_n;
+    const u64 groups = (a.batch + C::W - 1) / C::W;
+    const Mod &m = a.mod;
+    stage_twiddles<C::M, C::TH>(ltw, a.tw, s0, blk, tid);
+    const Tw *tw = ltw;
+
+    // chunk = 1 KiB = half a unit: unit u = chunk/2, half h = chunk%2; LDS slot s = h*64 + lane
+    // holds piece (s - 8*u) mod 128 of the unit
+    auto fetch = [&](u64 pg, u32 buf) {
+#pragma unroll
+        for (int i = 0; i < C::CHUNKS_PER_WAVE; i++) {
+            const u32 chunk = wave * C::CHUNKS_PER_WAVE + i;
+            const u32 u = chunk >> 1, h = chunk & 1u;
+            u64 poly = pg * C::W + u;
+            if (poly >= a.batch) poly = a.batch - 1;   // ragged group: fetch something valid, never stored
+            const u32 piece = (h * 64 + lane - 8 * u) & (C::PIECES - 1);
+            const unsigned char *src =
+                reinterpret_cast<const unsigned char *>(a.in + poly * n + (u64)blk * C::M) + piece * 16;
+            dma16(src, lds_base + buf * C::BUF_BYTES + chunk * 1024);
+        }
+    };
+    // element f of unit u in the DMA layout (u64 index inside the buffer)
+    auto dma_slot = [&](u32 u, u32 f) -> u32 {
+        const u32 piece = f >> 1;
+        return u * C::M + (((piece + 8 * u) & (C::PIECES - 1)) << 1) + (f & 1u);
+    };
+
+    u64 pg = chunk0;
+    u32 cur = 0;
+    if (pg < groups) fetch(pg, 0);
+    wait_vmem_all();
+    __syncthreads();
+    for (; pg < groups; pg += nchunks) {
+        const u64 npg = pg + nchunks;
+        if (npg < groups) fetch(npg, cur ^ 1u);
+        u64 *lds = reinterpret_cast<u64 *>(smem_raw + cur * C::BUF_BYTES);
+        u64 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[dma_slot(w, field_of<LP - 4>(tf, k))];
+        __syncthreads();
+        round_fwd<4, WIDE>(v, tw, 1u, m);                       // local stages 0..3: H = 0
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[pad16(w * C::M + field_of<LP - 4>(tf, k))] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * C::M + field_of<0>(tf, k))];
+        round_fwd<4, WIDE>(v, tw, (1u << 4) + tf, m);           // local stages 4..7: H = tf
+        // each thread rewrites exactly the slots it has just read: no barrier needed before
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u64 x = FINAL ? (WIDE ? canon8(v[k], m) : canon4(v[k], m)) : v[k];
+            lds[pad16(w * C::M + field_of<0>(tf, k))] = x;
+        }
+        __syncthreads();
+        wait_vmem_all();
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32 e = i * C::TH + tid;
+            const u32 wu = e >> LP, f = e & (C::M - 1);
+            const u64 p = pg * C::W + wu;
+            if (p < a.batch) a.out[p * n + (u64)blk * C::M + f] = lds[pad16(e)];
+        }
+        __syncthreads();
+        cur ^= 1u;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -352,7 +621,7 @@ __global__ __launch_bounds__(256) void ntt_tiny_kernel(PassArgs a) {
     const u64 poly = (u64)blockIdx.x * 256 + threadIdx.x;
     if (poly >= a.batch) return;
     const u32 n = 1u << a.log_n;
-    const u64 q = a.mod.q, q2 = a.mod.q2;
+    const Mod &m = a.mod;
     u64 v[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = (u32)i < n ? a.in[poly * n + i] : 0ull;
@@ -365,7 +634,7 @@ __global__ __launch_bounds__(256) void ntt_tiny_kernel(PassArgs a) {
                     const Tw w = a.tw[(1u << s) + ((u32)j >> (a.log_n - s))];
                     // static register indexing: j + t is one of j+1, j+2, j+4
                     u64 x = v[j], y = (t == 1) ? v[(j + 1) & 7] : (t == 2) ? v[(j + 2) & 7] : v[(j + 4) & 7];
-                    ct_bfly(x, y, w.w, w.wp, q, q2);
+                    ct_bfly<2>(x, y, w.w, w.wp, m);
                     v[j] = x;
                     if (t == 1) v[(j + 1) & 7] = y; else if (t == 2) v[(j + 2) & 7] = y; else v[(j + 4) & 7] = y;
                 }
@@ -373,7 +642,7 @@ __global__ __launch_bounds__(256) void ntt_tiny_kernel(PassArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            if ((u32)i < n) a.out[poly * n + i] = canon4(v[i], q, q2);
+            if ((u32)i < n) a.out[poly * n + i] = canon4(v[i], m);
     } else {
         for (int s = (int)a.log_n - 1; s >= 0; s--) {
             const u32 t = n >> (s + 1);
@@ -382,7 +651,7 @@ __global__ __launch_bounds__(256) void ntt_tiny_kernel(PassArgs a) {
                 if ((u32)j < n && !((u32)j & t)) {
                     const Tw w = a.tw[(1u << s) + ((u32)j >> (a.log_n - s))];
                     u64 x = v[j], y = (t == 1) ? v[(j + 1) & 7] : (t == 2) ? v[(j + 2) & 7] : v[(j + 4) & 7];
-                    gs_bfly(x, y, w.w, w.wp, q, q2);
+                    gs_bfly(x, y, w.w, w.wp, m);
                     v[j] = x;
                     if (t == 1) v[(j + 1) & 7] = y; else if (t == 2) v[(j + 2) & 7] = y; else v[(j + 4) & 7] = y;
                 }
@@ -391,7 +660,7 @@ __global__ __launch_bounds__(256) void ntt_tiny_kernel(PassArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if ((u32)i < n)
-                a.out[poly * n + i] = canon2(mul_shoup_lazy(v[i], a.ninv.w, a.ninv.wp, q), q);
+                a.out[poly * n + i] = canon2(mul_shoup_lazy(v[i], a.ninv.w, a.ninv.wp, m), m);
     }
 }
 
@@ -433,7 +702,7 @@ static inline hipError_t allow_big_lds(const void *fn, size_t bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int LP, bool FINAL>
+template <int LP, bool FINAL, bool WIDE>
 static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 nb = 1ull << (a.log_n - LP);
@@ -441,9 +710,9 @@ static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     const u64 grid = nb * groups;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL>, C::LDS_BYTES)) return e;
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE>, C::LDS_BYTES)) return e;
     KernelTimer kt(FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig", LP, st);
-    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL>), dim3((unsigned)grid), dim3(C::TH),
+    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE>), dim3((unsigned)grid), dim3(C::TH),
                        C::LDS_BYTES, st, a);
     return post_launch();
 }
@@ -463,7 +732,7 @@ static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
     return post_launch();
 }
 
-template <int LA, int CW, bool INV>
+template <int LA, int CW, bool INV, bool WIDE>
 static hipError_t launch_strided(const PassArgs &a, hipStream_t st) {
     using C = StridedCfg<LA, CW>;
     const u64 ncg = (1ull << (a.log_n - LA)) / CW;
@@ -475,16 +744,74 @@ static hipError_t launch_strided(const PassArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW>), dim3((unsigned)grid), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     else
-        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW>), dim3((unsigned)grid), dim3(C::TH),
+        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, WIDE>), dim3((unsigned)grid), dim3(C::TH),
                            C::LDS_BYTES, st, a);
+    return post_launch();
+}
+
+// FHE_NTT_DMA=1 selects the persistent LDS-DMA kernels for the n = 2^16 passes.  Measured
+// (r01, 16384 polynomials): 9.16 ms vs 8.36 ms for the occupancy-driven kernels — the
+// double buffer halves the resident waves (LDS), which costs more than the prefetch gains —
+// so they are off by default and kept for A/B runs.
+static bool use_dma_kernels() {
+    static const bool on = [] {
+        const char *e = getenv("FHE_NTT_DMA");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+static int strided_cw8() {   // FHE_NTT_CW=16|32: column-group width of the LA=8 strided pass
+    static const int cw = [] {
+        const char *e = getenv("FHE_NTT_CW");
+        return e ? atoi(e) : 32;
+    }();
+    return cw;
+}
+
+// persistent DMA kernels: exactly the workgroups a CU can hold (2 per CU by LDS), each
+// walking a strided share of the items
+constexpr u64 kPersistentWorkgroups = 256 * 2;
+
+template <bool WIDE>
+static hipError_t launch_fwd_strided_dma(const PassArgs &a, hipStream_t st) {
+    using C = StridedDmaCfg<8, 16>;
+    const u64 ncg = (1ull << (a.log_n - 8)) / 16;
+    const u64 items = ncg * a.batch;
+    const u64 grid = items < kPersistentWorkgroups ? items : kPersistentWorkgroups;
+    if (grid == 0) return hipSuccess;
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_strided_dma_kernel<8, 16, WIDE>, C::LDS_BYTES)) return e;
+    KernelTimer kt("ntt_fwd_strided_dma", 8, st);
+    hipLaunchKernelGGL((ntt_fwd_strided_dma_kernel<8, 16, WIDE>), dim3((unsigned)grid), dim3(C::TH),
+                       C::LDS_BYTES, st, a);
+    return post_launch();
+}
+
+template <bool FINAL, bool WIDE>
+static hipError_t launch_fwd_contig_dma(const PassArgs &a, hipStream_t st) {
+    using C = ContigDmaCfg<8>;
+    const u64 nb = 1ull << (a.log_n - 8);
+    const u64 groups = (a.batch + C::W - 1) / C::W;
+    u64 nchunks = kPersistentWorkgroups / nb;
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > groups) nchunks = groups;
+    const u64 grid = nb * nchunks;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_dma_kernel<8, FINAL, WIDE>, C::LDS_BYTES)) return e;
+    KernelTimer kt(FINAL ? "ntt_fwd_contig_dma_final" : "ntt_fwd_contig_dma", 8, st);
+    hipLaunchKernelGGL((ntt_fwd_contig_dma_kernel<8, FINAL, WIDE>), dim3((unsigned)grid), dim3(C::TH),
+                       C::LDS_BYTES, st, a);
     return post_launch();
 }
 
 #define CONTIG_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 
-static hipError_t fwd_contig_dispatch(int lp, bool final, const PassArgs &a, hipStream_t st) {
+static hipError_t fwd_contig_dispatch(int lp, bool final, bool wide, const PassArgs &a, hipStream_t st) {
     switch (lp) {
-#define X(LP_) case LP_: return final ? launch_fwd_contig<LP_, true>(a, st) : launch_fwd_contig<LP_, false>(a, st);
+#define X(LP_)                                                                                   \
+    case LP_:                                                                                    \
+        if (wide) return final ? launch_fwd_contig<LP_, true, true>(a, st) : launch_fwd_contig<LP_, false, true>(a, st); \
+        return final ? launch_fwd_contig<LP_, true, false>(a, st) : launch_fwd_contig<LP_, false, false>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
@@ -506,12 +833,15 @@ static hipError_t inv_contig_dispatch(int lp, bool final, bool mul_in, const Pas
     return hipErrorInvalidValue;
 }
 
-template <bool INV>
+template <bool INV, bool WIDE>
 static hipError_t strided_dispatch(int la, const PassArgs &a, hipStream_t st) {
     switch (la) {
-        case 6: return launch_strided<6, 128, INV>(a, st);
-        case 7: return launch_strided<7, 64, INV>(a, st);
-        case 8: return launch_strided<8, 32, INV>(a, st);
+        case 6: return launch_strided<6, 128, INV, WIDE>(a, st);
+        case 7: return launch_strided<7, 64, INV, WIDE>(a, st);
+        case 8:
+            if (strided_cw8() == 16) return launch_strided<8, 16, INV, WIDE>(a, st);
+            if (strided_cw8() == 64) return launch_strided<8, 64, INV, WIDE>(a, st);
+            return launch_strided<8, 32, INV, WIDE>(a, st);
     }
     return hipErrorInvalidValue;
 }
@@ -537,7 +867,7 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
     }
     if (L <= kMaxSinglePassLog) {
         a.in = in; a.out = out; a.batch = batch;
-        return fwd_contig_dispatch(L, true, a, st);
+        return fwd_contig_dispatch(L, true, p.wide, a, st);
     }
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
@@ -545,10 +875,17 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
     for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
         const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile;
         a.in = in + b0 * n; a.out = out + b0 * n; a.batch = nb;
-        hipError_t e = strided_dispatch<false>(LA, a, st);
+        hipError_t e;
+        if (LA == 8 && use_dma_kernels())
+            e = p.wide ? launch_fwd_strided_dma<true>(a, st) : launch_fwd_strided_dma<false>(a, st);
+        else
+            e = p.wide ? strided_dispatch<false, true>(LA, a, st) : strided_dispatch<false, false>(LA, a, st);
         if (e != hipSuccess) return e;
         a.in = out + b0 * n;
-        e = fwd_contig_dispatch(LB, true, a, st);
+        if (LB == 8 && use_dma_kernels())
+            e = p.wide ? launch_fwd_contig_dma<true, true>(a, st) : launch_fwd_contig_dma<true, false>(a, st);
+        else
+            e = fwd_contig_dispatch(LB, true, p.wide, a, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -594,7 +931,7 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
         hipError_t e = inv_contig_dispatch(LB, false, in2 != nullptr, a, st);
         if (e != hipSuccess) return e;
         a.in = out + b0 * n; a.in2 = nullptr; a.out2 = nullptr;
-        e = strided_dispatch<true>(LA, a, st);
+        e = strided_dispatch<true, false>(LA, a, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -22,6 +22,7 @@ struct DevicePlan {
     Tw ninv{};    // n^-1                     (ntt.rs:27-30)
     Tw s_ninv{};  // roots_inv[1] * n^-1      (last GS stage folded with ntt.rs:100-102)
     uint32_t log_n = 0;
+    bool wide = false;  // q < 2^61: forward butterflies correct every other stage
 };
 
 struct PassArgs {

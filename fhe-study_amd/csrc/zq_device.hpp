@@ -11,9 +11,14 @@
 // transform canonicalises to [0,q), so outputs are bit-identical to the
 // reference's canonical `Zq.v`.
 //
-// Measured on MI355X (tools/ubench_valu.hip, profiles/r01_ubench_valu.txt):
-// v_mad_u64_u32 / v_mul_lo_u32 / v_mul_hi_u32 issue at ~4 cycles per wave64,
-// plain 32-bit VOP2 at ~2; a compiled exact-Shoup butterfly costs ~100 cycles.
+// Instruction selection follows measurements on MI355X (tools/ubench_valu.hip,
+// tools/ubench_bfly.hip, profiles/r01_ubench_*.txt): v_mad_u64_u32, v_mul_*_u32,
+// v_lshl_add_u64 and every carry-producing add issue at ~4 cycles per wave64, a
+// plain 32-bit VOP2 at ~2.  So the butterfly is written as v_mad_u64_u32 chains
+// (multiply AND 64-bit accumulate in one issue slot), 64-bit adds are
+// v_lshl_add_u64, subtraction of a value is "+ ~v + 1" with the +1 folded into a
+// constant, and subtraction of a constant is the addition of its negation.
+// Compiler-only code: 105 cycles/butterfly; this form: 81 (q < 2^61) / 89.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,58 +34,103 @@ struct Tw {  // one twiddle: w and its Shoup companion floor(w*2^64/q)
 
 // Modulus constants handed to kernels by value (live in SGPRs).
 struct Mod {
-    u64 q;    // modulus, 3 <= q < 2^62
-    u64 q2;   // 2q
-    u64 r64;  // 2^64 mod q            (for the variable x variable product)
-    u64 r64p; // floor(r64 * 2^64 / q)
-    u64 onep; // floor(2^64 / q)       (Shoup companion of w = 1)
+    u64 q;      // modulus, 3 <= q < 2^62
+    u64 q2;     // 2q
+    u64 nq;     // -q      mod 2^64
+    u64 neg2q;  // -2q     mod 2^64
+    u64 neg4q;  // -4q     mod 2^64
+    u64 q2p1;   // 2q + 1
+    u64 r64;    // 2^64 mod q            (for the variable x variable product)
+    u64 r64p;   // floor(r64 * 2^64 / q)
+    u64 onep;   // floor(2^64 / q)       (Shoup companion of w = 1)
 };
 
-// y * w mod q  in [0, 2q), for ANY 64-bit y and 0 <= w < q (exact quotient estimate).
-__device__ __forceinline__ u64 mul_shoup_lazy(u64 y, u64 w, u64 wp, u64 q) {
-    u64 qh = __umul64hi(y, wp);
-    return y * w - qh * q;
+// ---- single-instruction wrappers (register allocation stays with the compiler) ----
+__device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) {  // a*b + c  (mod 2^64)
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+__device__ __forceinline__ u64 add64(u64 a, u64 b) {  // a + b in one issue slot
+    u64 d;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ u64 dbl_add64(u64 a, u64 b) {  // 2a + b
+    u64 d;
+    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
-__device__ __forceinline__ u64 csub(u64 x, u64 m) {  // x >= m ? x - m : x
-    return x >= m ? x - m : x;
+// x - m if x >= m else x, for x < 2^63 + m, given negm = -m (mod 2^64), m < 2^63:
+// one 64-bit add, then the sign of the difference selects.
+__device__ __forceinline__ u64 csub_neg(u64 x, u64 negm) {
+    const u64 d = add64(x, negm);
+    return ((long long)d < 0) ? x : d;
+}
+__device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
+
+// add + y*w - floor(y*w'/2^64)*q  (mod 2^64)  =  add + (y*w mod q, lazily in [0,2q)),
+// for ANY 64-bit y and 0 <= w < q.  Low halves go through one mad chain that also
+// absorbs `add`; the four cross terms (only their low 32 bits matter) through another.
+__device__ __forceinline__ u64 mul_shoup_acc(u64 add, u64 y, u64 w, u64 wp, u64 nq) {
+    const u64 qh = __umul64hi(y, wp);
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+    const u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    u64 acc = mad64(y0, w0, add);
+    acc = mad64(h0, n0, acc);
+    u64 H = mad64(y0, w1, 0);
+    H = mad64(y1, w0, H);
+    H = mad64(h0, n1, H);
+    H = mad64(h1, n0, H);
+    const u32 hi = (u32)(acc >> 32) + (u32)H;
+    return ((u64)hi << 32) | (u32)acc;
+}
+// y * w mod q  in [0, 2q)
+__device__ __forceinline__ u64 mul_shoup_lazy(u64 y, u64 w, u64 wp, const Mod &m) {
+    return mul_shoup_acc(0, y, w, wp, m.nq);
 }
 
 // Forward (Cooley-Tukey) butterfly, arith/src/ntt.rs:57-62:
 //   U = r[j]; V = r[j+t]*S; r[j] = U+V; r[j+t] = U-V
-// Lazy form: x,y in [0,4q) -> x,y in [0,4q).  Needs 4q < 2^64.
-__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
-    u64 u = csub(x, q2);
-    u64 t = mul_shoup_lazy(y, w, wp, q);
-    x = u + t;
-    y = u - t + q2;
+// CSUB = 0: none (caller guarantees headroom), 2: x -= 2q if x >= 2q, 4: x -= 4q if x >= 4q.
+//   x' = u + t,  y' = u - t + 2q = (2u + 2q + 1) + ~x'
+template <int CSUB>
+__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, u64 wp, const Mod &m) {
+    u64 u = x;
+    if (CSUB == 2) u = csub_neg(x, m.neg2q);
+    if (CSUB == 4) u = csub_neg(x, m.neg4q);
+    const u64 s = mul_shoup_acc(u, y, w, wp, m.nq);
+    y = add64(dbl_add64(u, m.q2p1), ~s);
+    x = s;
 }
 
 // Inverse (Gentleman-Sande) butterfly, arith/src/ntt.rs:91-96:
 //   U = r[j]; V = r[j+t]; r[j] = U+V; r[j+t] = (U-V)*S
 // Lazy form: x,y in [0,2q) -> x,y in [0,2q).
-__device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
-    u64 s = csub(x + y, q2);
-    u64 d = x - y + q2;
-    x = s;
-    y = mul_shoup_lazy(d, w, wp, q);
+__device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, u64 wp, const Mod &m) {
+    const u64 d = add64(add64(x, m.q2p1), ~y);  // x - y + 2q  in (0,4q)
+    x = csub_neg(add64(x, y), m.neg2q);
+    y = mul_shoup_acc(0, d, w, wp, m.nq);
 }
 
-// [0,4q) -> [0,q)
-__device__ __forceinline__ u64 canon4(u64 x, u64 q, u64 q2) { return csub(csub(x, q2), q); }
 // [0,2q) -> [0,q)
-__device__ __forceinline__ u64 canon2(u64 x, u64 q) { return csub(x, q); }
+__device__ __forceinline__ u64 canon2(u64 x, const Mod &m) { return csub_neg(x, m.nq); }
+// [0,4q) -> [0,q)
+__device__ __forceinline__ u64 canon4(u64 x, const Mod &m) { return canon2(csub_neg(x, m.neg2q), m); }
+// [0,8q) -> [0,q)   (q < 2^61)
+__device__ __forceinline__ u64 canon8(u64 x, const Mod &m) { return canon4(csub_neg(x, m.neg4q), m); }
 
 // a * b mod q, canonical, for two VARIABLE canonical operands
 // (zip_eq(l,r).map(l*r), arith/src/ring_nq.rs:601-604).
 // a*b = hi*2^64 + lo  ==  hi*(2^64 mod q) + lo  (mod q); both terms are reduced
 // with the Shoup estimate against the fixed constants r64 and 1.
 __device__ __forceinline__ u64 mul_mod_var(u64 a, u64 b, const Mod &m) {
-    u64 lo = a * b;
-    u64 hi = __umul64hi(a, b);
-    u64 t1 = mul_shoup_lazy(hi, m.r64, m.r64p, m.q);          // [0,2q)
-    u64 t2 = lo - __umul64hi(lo, m.onep) * m.q;               // lo mod q, in [0,2q)
-    return canon4(t1 + t2, m.q, m.q2);
+    const u64 lo = a * b;
+    const u64 hi = __umul64hi(a, b);
+    const u64 t2 = lo - __umul64hi(lo, m.onep) * m.q;          // lo mod q, in [0,2q)
+    const u64 t = mul_shoup_acc(t2, hi, m.r64, m.r64p, m.nq);  // + hi*r64 mod q: [0,4q)
+    return canon4(t, m);
 }
 
 __device__ __forceinline__ u64 splitmix64(u64 x) {

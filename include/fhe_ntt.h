@@ -20,7 +20,8 @@
  *     library until fhe_ntt_shutdown().
  *   - `*_dev` variants take DEVICE pointers of the current HIP device and a
  *     `hipStream_t` passed as `void*` (NULL = the default stream); they only
- *     enqueue work and never synchronise.  Host-pointer variants copy
+ *     enqueue work and never synchronise.  Device buffers must be 16-byte
+ *     aligned (FHE_E_INVALID otherwise; anything hipMalloc returns is).  Host-pointer variants copy
  *     host→device→host around the same kernels and return when `out` is valid.
  *   - There is no CPU fallback: without a HIP device every compute entry point
  *     returns FHE_E_NO_DEVICE.

@@ -1,0 +1,163 @@
+// tools/ubench_bfly.hip — candidate Shoup/Harvey butterfly formulations, measured in
+// registers only (diagnostic; results quoted in DESIGN.md).  Each variant is checked
+// against a u128 reference on the host before it is timed.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned __int128 u128;
+
+__device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) {
+  u64 d; asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc"); return d;
+}
+__device__ __forceinline__ u64 add64(u64 a, u64 b) {
+  u64 d; asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+__device__ __forceinline__ u64 shl1add64(u64 a, u64 b) {  // (a<<1)+b
+  u64 d; asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+
+struct Q { u64 q, q2, nq, neg4q, neg2q, q2p1, q4; };
+
+// variant 0: what the product kernels do today (compiler everything), [0,4q)
+__device__ __forceinline__ void bf_v0(u64& x, u64& y, u64 w, u64 wp, const Q& c) {
+  u64 u = x >= c.q2 ? x - c.q2 : x;
+  u64 qh = __umul64hi(y, wp);
+  u64 t = y * w - qh * c.q;
+  x = u + t; y = u - t + c.q2;
+}
+// t-chain: s = u + y*w + qh*nq (mod 2^64) with mad chains; cross terms via a second 64-bit chain
+__device__ __forceinline__ u64 chain_s(u64 u, u64 y, u64 w, u64 qh, const Q& c) {
+  u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+  u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)c.nq, n1 = (u32)(c.nq >> 32);
+  u64 acc = mad64(y0, w0, u);
+  acc = mad64(h0, n0, acc);
+  u64 H = mad64(y0, w1, 0);
+  H = mad64(y1, w0, H);
+  H = mad64(h0, n1, H);
+  H = mad64(h1, n0, H);
+  u32 hi = (u32)(acc >> 32) + (u32)H;
+  return ((u64)hi << 32) | (u32)acc;
+}
+// variant 1: exact qh (compiler), fused chain, y' = 2u+2q+1 + ~s, csub each stage via compare
+__device__ __forceinline__ void bf_v1(u64& x, u64& y, u64 w, u64 wp, const Q& c) {
+  u64 u = x >= c.q2 ? x - c.q2 : x;
+  u64 qh = __umul64hi(y, wp);
+  u64 s = chain_s(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+// variant 2: as v1 but csub by sign of (x - 2q) computed with one 64-bit add
+__device__ __forceinline__ void bf_v2(u64& x, u64& y, u64 w, u64 wp, const Q& c) {
+  u64 d = add64(x, c.neg2q);
+  u64 u = ((long long)d < 0) ? x : d;
+  u64 qh = __umul64hi(y, wp);
+  u64 s = chain_s(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+// variant 3: WIDE (q < 2^61): no csub (the kernel applies one csub(4q) every other stage)
+__device__ __forceinline__ void bf_v3(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) { u64 d = add64(x, c.neg4q); u = ((long long)d < 0) ? x : d; }
+  u64 qh = __umul64hi(y, wp);
+  u64 s = chain_s(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+// variant 4: v3 but the cross terms with mul_lo + add3 (compiler's choice) instead of the H chain
+__device__ __forceinline__ void bf_v4(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) { u64 d = add64(x, c.neg4q); u = ((long long)d < 0) ? x : d; }
+  u64 qh = __umul64hi(y, wp);
+  u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+  u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)c.nq, n1 = (u32)(c.nq >> 32);
+  u64 acc = mad64(y0, w0, u);
+  acc = mad64(h0, n0, acc);
+  u32 hi = (u32)(acc >> 32) + y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
+  u64 s = ((u64)hi << 32) | (u32)acc;
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+
+template <int V>
+__global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
+  u64 x[4], y[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { x[j] = p[threadIdx.x + 64 * j] % c.q; y[j] = p[threadIdx.x + 64 * j + 256] % c.q; }
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (V == 0) bf_v0(x[j], y[j], w, wp, c);
+      if (V == 1) bf_v1(x[j], y[j], w, wp, c);
+      if (V == 2) bf_v2(x[j], y[j], w, wp, c);
+      if (V == 3) { bf_v3(x[j], y[j], w, wp, c, false); }
+      if (V == 4) { bf_v4(x[j], y[j], w, wp, c, false); }
+    }
+    if (V == 3 || V == 4) {  // second stage of the pair carries the csub
+      i++;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (V == 3) bf_v3(x[j], y[j], w, wp, c, true);
+        if (V == 4) bf_v4(x[j], y[j], w, wp, c, true);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { p[threadIdx.x + 64 * j] = x[j]; p[threadIdx.x + 64 * j + 256] = y[j]; }
+}
+
+static u64 href(u64 x, u64 y, u64 w, u64 q, int iters, u64* yo) {  // canonical reference
+  for (int i = 0; i < iters; i++) {
+    u64 t = (u64)(((u128)y * w) % q);
+    u64 s = (x + t) % q, d = (x + q - t) % q;
+    x = s; y = d;
+  }
+  *yo = y; return x;
+}
+
+int main() {
+  hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+  int cus = prop.multiProcessorCount; double clk = prop.clockRate * 1e3;
+  u64 q = 2305843009211596801ull, w = 1681162619342215248ull;
+  u64 wp = (u64)((((u128)w) << 64) / q);
+  Q c{q, 2 * q, (u64)0 - q, (u64)0 - 4 * q, (u64)0 - 2 * q, 2 * q + 1, 4 * q};
+  u64* p; hipMalloc(&p, 4096 * 8);
+  std::vector<u64> h(512), o(512);
+  for (int i = 0; i < 512; i++) h[i] = (0x9E3779B97F4A7C15ull * (i + 1)) ^ (0xD1B54A32D192ED03ull * (i + 7));
+  const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo"};
+  for (int v = 0; v < 5; v++) {
+    // correctness at 6 iterations (even, so v3/v4 pairs are whole)
+    hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
+    int it = 6;
+    switch (v) { case 0: k<0><<<1, 64>>>(p, c, w, wp, it); break; case 1: k<1><<<1, 64>>>(p, c, w, wp, it); break;
+      case 2: k<2><<<1, 64>>>(p, c, w, wp, it); break; case 3: k<3><<<1, 64>>>(p, c, w, wp, it); break; case 4: k<4><<<1, 64>>>(p, c, w, wp, it); break; }
+    hipMemcpy(o.data(), p, 512 * 8, hipMemcpyDeviceToHost);
+    int bad = 0; u64 mx = 0;
+    for (int t = 0; t < 64; t++) for (int j = 0; j < 4; j++) {
+      u64 yo, xo = href(h[t + 64 * j] % q, h[t + 64 * j + 256] % q, w, q, it, &yo);
+      u64 gx = o[t + 64 * j], gy = o[t + 64 * j + 256];
+      if (gx % q != xo || gy % q != yo) bad++;
+      if (gx > mx) mx = gx; if (gy > mx) mx = gy;
+    }
+    printf("%-20s correctness: %s (max value / q = %.3f)\n", names[v], bad ? "FAIL" : "ok", (double)mx / (double)q);
+    for (int wpS : {2, 4, 8}) {
+      int blocks = cus * wpS, threads = 256, iters = 2000;
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      float best = 1e30f;
+      for (int r = 0; r < 4; r++) {
+        hipEventRecord(e0);
+        switch (v) { case 0: k<0><<<blocks, threads>>>(p, c, w, wp, iters); break; case 1: k<1><<<blocks, threads>>>(p, c, w, wp, iters); break;
+          case 2: k<2><<<blocks, threads>>>(p, c, w, wp, iters); break; case 3: k<3><<<blocks, threads>>>(p, c, w, wp, iters); break; case 4: k<4><<<blocks, threads>>>(p, c, w, wp, iters); break; }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
+      }
+      double bf = (double)blocks * threads * 4 * iters;
+      printf("   wpS=%d %8.3f ms  %8.1f Gbfly/s  %6.1f cyc/bfly-wave/SIMD(nominal clk)\n", wpS, best, bf / best * 1e-6,
+             best * 1e-3 * clk / ((double)iters * 4 * wpS));
+    }
+  }
+  return 0;
+}

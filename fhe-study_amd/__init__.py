@@ -13,5 +13,14 @@ from . import binding  # noqa: F401
 from .binding import FheError, Plan, build, load_library  # noqa: F401
 from .arith import NTT, RingParam, Rq, mul, mul_mut  # noqa: F401
 
+
+def __getattr__(name):
+    # `sharding` needs torch.distributed; keep it off the import path of torch-free users
+    if name == "sharding":
+        import importlib
+
+        return importlib.import_module(__name__ + ".sharding")
+    raise AttributeError(name)
+
 Q61 = 2305843009211596801  # 2^61 - 2^21 + 1, the engine's headline modulus
 Q16 = 65537                # the modulus of every reference test

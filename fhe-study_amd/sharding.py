@@ -1,0 +1,52 @@
+"""Batch sharding across the GPUs of one node.
+
+The transform has no exchange step: polynomials are independent, so rank r owns the
+contiguous block of rows [r*ceil(B/G), min(B, (r+1)*ceil(B/G))) and runs the
+single-GPU engine on it (one process per GPU).  The only collective is the optional
+all-gather of result shards for a consumer that needs the whole batch on every rank
+(RCCL over xGMI: backend "nccl"; "gloo" in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(batch, world, rank):
+    """Rows [b0, b1) of the global batch owned by `rank`."""
+    per = -(-batch // world)
+    b0 = min(batch, rank * per)
+    return b0, min(batch, b0 + per)
+
+
+def all_gather_rows(local_rows, batch, group=None):
+    """local_rows: (b1-b0, n) int64 tensor of this rank's shard → (batch, n) on every rank.
+    Shards are padded to ceil(B/G) rows so that one all_gather_into_tensor moves them
+    (a single large collective per call: xGMI links are per-peer, so fewer/larger is
+    better than per-row traffic)."""
+    world = dist.get_world_size(group)
+    per = -(-batch // world)
+    n = local_rows.shape[1]
+    send = local_rows
+    if local_rows.shape[0] != per:
+        send = torch.zeros((per, n), dtype=local_rows.dtype, device=local_rows.device)
+        send[: local_rows.shape[0]] = local_rows
+    out = torch.empty((world * per, n), dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    return out[:batch]
+
+
+class ShardedNTT:
+    """Per-rank driver: `transform(rows) -> rows` is the single-device engine applied to
+    this rank's block (on a GPU box: Plan.forward_dev on device tensors)."""
+
+    def __init__(self, transform, group=None):
+        self.transform = transform
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def forward_sharded(self, full_batch_rows_fn, batch, gather=False):
+        """full_batch_rows_fn(b0, b1) materialises this rank's input rows (inputs are
+        generated / loaded on the owning rank, never broadcast)."""
+        b0, b1 = shard_range(batch, self.world, self.rank)
+        local = self.transform(full_batch_rows_fn(b0, b1))
+        return all_gather_rows(local, batch, self.group) if gather else local

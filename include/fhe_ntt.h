@@ -65,8 +65,9 @@ typedef struct fhe_ntt_plan fhe_ntt_plan; /* opaque */
 /* ---- plan cache: replaces `roots(q,n)` + CACHE, arith/src/ntt.rs:18-38 ---
  * Memoised per (q,n).  Derives psi by the reference's k=1,2,.. search
  * (ntt.rs:115-131), roots[i] = psi^bitrev(i) (ntt.rs:133-147), roots_inv[i] =
- * roots[i]^-1 (ntt.rs:149-161; computed with one inversion + products, the
- * values are identical) and n_inv (ntt.rs:27-30).  Host-only: needs no GPU. */
+ * roots[i]^(q-2) (ntt.rs:149-161, the same Fermat power, so the tables agree
+ * with the reference even for a composite q) and n_inv (ntt.rs:27-30).
+ * Host-only: needs no GPU. */
 int fhe_ntt_plan_get(uint64_t q, uint64_t n, const fhe_ntt_plan **out);
 int fhe_ntt_plan_info(const fhe_ntt_plan *plan, uint64_t *q, uint64_t *n, uint64_t *psi,
                       uint64_t *n_inv);
@@ -123,9 +124,10 @@ int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_index, size
                            void *d_out, void *hip_stream);
 
 /* ---- tuning / measurement ----------------------------------------------- */
-/* Polynomials per launch for two-pass sizes (n >= 2^14): the batch is walked
- * in tiles so the intermediate of pass A is still in the 256 MiB Infinity
- * Cache when pass B reads it.  0 restores the default. */
+/* Polynomials per launch for two-pass sizes (n >= 2^14): the batch can be
+ * walked in tiles so that the intermediate of the first pass is still in the
+ * 256 MiB Infinity Cache when the second pass reads it.  0 restores the default
+ * (one launch per pass over the whole batch — measured fastest). */
 int fhe_ntt_set_batch_tile(size_t polys);
 /* When enabled, every kernel launch is bracketed by HIP events on its stream;
  * fhe_ntt_kernel_timing_read() synchronises, and returns per-kernel totals

@@ -1,0 +1,29 @@
+"""The C++ host mirror (fhe-study_amd/host/arith.hpp) restates the reference's own
+NTT-path tests over the C ABI.  The program is built on CPU (it needs only
+include/fhe_ntt.h and the .so) and run on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HOST = os.path.join(ROOT, "fhe-study_amd", "host")
+
+
+def _build(pkg):
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return os.path.join(HOST, "test_arith")
+
+
+def test_host_mirror_builds_against_the_c_abi(pkg):
+    exe = _build(pkg)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_host_mirror_reference_tests(pkg):
+    exe = _build(pkg)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all host C++ tests passed" in r.stdout

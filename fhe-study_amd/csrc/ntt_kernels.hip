@@ -108,6 +108,35 @@ __device__ __forceinline__ u32 field_of(u32 tf, int k) {
 // elements so that the a=0 window (lane stride 16 elements) is conflict-free.
 __device__ __forceinline__ u32 pad16(u32 e) { return e + (e >> 4); }
 
+// stage a pass-local twiddle table into LDS: local index li in [1, M): ls = floor(log2 li),
+// global index (1 << (s0+ls)) + (blk << ls) + (li - 2^ls); the rounds then index it with
+// T0 = (1 << ls0) + H, i.e. as if the pass were a transform of its own.
+template <int M, int TH>
+__device__ __forceinline__ void stage_twiddles(Tw *ltw, const Tw *__restrict__ tw, u32 s0, u32 blk,
+                                               u32 tid) {
+    for (u32 li = tid; li < (u32)M; li += TH) {
+        const u32 ls = 31u - (u32)__builtin_clz(li | 1u);   // entry 0 is never used: copy tw[.] of li = 1
+        const u32 l1 = li | (li == 0);
+        ltw[li] = tw[(1u << (s0 + ls)) + (blk << ls) + (l1 - (1u << ls))];
+    }
+}
+
+// one LDS-DMA wave-instruction: lane l copies 16 B from gsrc to LDS byte lds_dst + 16*l.
+// m0 is compiler-reserved: saved and restored inside the statement (guide §5.7).
+__device__ __forceinline__ void dma16(const void *gsrc, u32 lds_dst_uniform) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---------------------------------------------------------------------------
 // CONTIGUOUS pass: blocks of M = 2^LP consecutive coefficients.
 // Workgroup = W units (unit = one M-block of one polynomial, all W units share
@@ -123,21 +152,29 @@ struct ContigCfg {
     static constexpr int NR = (LP + 3) / 4;
     static constexpr int R0 = LP - 4 * (NR - 1);
     static constexpr int A0 = LP - 4;  // register window of round 0 = top 4 field bits
-    static constexpr size_t LDS_BYTES = (size_t)(TILE + TILE / 16) * 8;
+    // a pass whose twiddle table is small is staged into LDS once per workgroup (all W units
+    // share `blk`): 30 ds_read_b128 per thread instead of 30 global loads through L1
+    static constexpr bool LDS_TW = LP <= 9;
+    static constexpr size_t DATA_BYTES = (size_t)(TILE + TILE / 16) * 8;
+    static constexpr size_t LDS_BYTES = DATA_BYTES + (LDS_TW ? (size_t)M * sizeof(Tw) : 0);
     // window base of round j >= 1
     static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
     static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
 };
 
-template <int LP, int AF, int AT>
+// scatter registers (window AF) -> barrier -> gather registers (window AT).
+// FIRST = false: the tile was read by an earlier exchange, so a barrier precedes the scatter.
+// No trailing barrier: whoever writes the tile next either is this function (FIRST = false)
+// or writes exactly the slots it has just gathered (the store transpose of the forward pass).
+template <int LP, int AF, int AT, bool FIRST>
 __device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u32 tf) {
     constexpr int M = 1 << LP;
+    if (!FIRST) __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[pad16(w * M + field_of<AF>(tf, k))] = v[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
-    __syncthreads();
 }
 
 template <int LP, bool FINAL, bool WIDE>
@@ -154,27 +191,36 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     const bool active = poly < a.batch;
     const u64 base = poly * n + (u64)blk * C::M;
     const Mod &m = a.mod;
-    const Tw *__restrict__ tw = a.tw;
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    const Tw *tw = C::LDS_TW ? ltw : a.tw;
+    // twiddle index of (local stage ls0, high field bits H): pass-local in LDS, global otherwise
+    auto T0 = [&](int ls, u32 H) -> u32 {
+        return C::LDS_TW ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    };
 
     u64 v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = active ? a.in[base + field_of<C::A0>(tf, k)] : 0ull;
+    // Round 0's twiddles are the same for the whole workgroup (H = 0): read from the global
+    // table at a wave-uniform address (scalar loads, SGPR operands).  The LDS copy is only
+    // needed from round 1 on, so the barrier of the first exchange also publishes it.
+    if constexpr (C::LDS_TW) stage_twiddles<C::M, C::TH>(ltw, a.tw, s0, blk, tid);
 
-    round_fwd<C::R0, WIDE>(v, tw, (1u << s0) + blk, m);
+    round_fwd<C::R0, WIDE>(v, a.tw, (1u << s0) + blk, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        exchange_contig<LP, C::A0, A>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m);
+        exchange_contig<LP, C::A0, A, true>(v, lds, w, tf);
+        round_fwd<4, WIDE>(v, tw, T0(LS, tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        exchange_contig<LP, C::a_of(1), A>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m);
+        exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
+        round_fwd<4, WIDE>(v, tw, T0(LS, tf >> A), m);
     }
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
-        exchange_contig<LP, C::a_of(2), A>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m);
+        exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
+        round_fwd<4, WIDE>(v, tw, T0(LS, tf >> A), m);
     }
     // transpose through LDS so the store is one contiguous slab per wave.  (Storing the 128
     // contiguous bytes a thread owns after the last round as 8 x 16 B straight from registers
@@ -213,7 +259,12 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     const bool active = poly < a.batch;
     const u64 base = poly * n + (u64)blk * C::M;
     const Mod &m = a.mod;
-    const Tw *__restrict__ tw = a.tw;
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    const Tw *tw = C::LDS_TW ? ltw : a.tw;
+    auto T0 = [&](int ls, u32 H) -> u32 {
+        return C::LDS_TW ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    };
+    if constexpr (C::LDS_TW) stage_twiddles<C::M, C::TH>(ltw, a.tw, s0, blk, tid);  // barrier below
 
     // first window = field bits [0,4): a thread's 16 coefficients are 128 contiguous bytes,
     // fetched as 8 x 16 B straight into registers (no staging through LDS)
@@ -247,23 +298,24 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
         }
     }
 
+    if constexpr (C::LDS_TW) __syncthreads();
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
-        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m, a.ninv, a.s_ninv);
-        exchange_contig<LP, A, C::a_of(2)>(v, lds, w, tf);
+        round_inv<4, false>(v, tw, T0(LS, tf >> A), m, a.ninv, a.s_ninv);
+        exchange_contig<LP, A, C::a_of(2), true>(v, lds, w, tf);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m, a.ninv, a.s_ninv);
-        exchange_contig<LP, A, C::a_of(1)>(v, lds, w, tf);
+        round_inv<4, false>(v, tw, T0(LS, tf >> A), m, a.ninv, a.s_ninv);
+        exchange_contig<LP, A, C::a_of(1), (C::NR <= 3)>(v, lds, w, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv<4, false>(v, tw, (1u << (s0 + LS)) + (blk << LS) + (tf >> A), m, a.ninv, a.s_ninv);
-        exchange_contig<LP, A, C::A0>(v, lds, w, tf);
+        round_inv<4, false>(v, tw, T0(LS, tf >> A), m, a.ninv, a.s_ninv);
+        exchange_contig<LP, A, C::A0, (C::NR <= 2)>(v, lds, w, tf);
     }
     // FINAL implies s0 == 0 (this pass holds the m = 1 stage)
-    round_inv<C::R0, FINAL>(v, tw, (1u << s0) + blk, m, a.ninv, a.s_ninv);
+    round_inv<C::R0, FINAL>(v, tw, T0(0, 0), m, a.ninv, a.s_ninv);
 
     if (active) {
 #pragma unroll
@@ -286,19 +338,20 @@ struct StridedCfg {
     static constexpr int NR = (LA + 3) / 4;
     static constexpr int R0 = LA - 4 * (NR - 1);
     static constexpr int A0 = LA - 4;
-    static constexpr size_t LDS_BYTES = (size_t)F * CW * 8;
+    static constexpr size_t DATA_BYTES = (size_t)F * CW * 8;
+    static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)F * sizeof(Tw);  // + the 2^LA twiddles
     static constexpr int a_of(int j) { return j == 0 ? A0 : LA - R0 - 4 * j; }
     static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
 };
 
-template <int CW, int AF, int AT>
+template <int CW, int AF, int AT, bool FIRST>
 __device__ __forceinline__ void exchange_strided(u64 (&v)[16], u64 *lds, u32 c, u32 tf) {
+    if (!FIRST) __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[field_of<AF>(tf, k) * CW + c] = v[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = lds[field_of<AT>(tf, k) * CW + c];
-    __syncthreads();
 }
 
 template <int LA, int CW, bool WIDE>
@@ -313,21 +366,23 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     const u64 poly = (u64)(blockIdx.x >> lcg);
     const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
     const Mod &m = a.mod;
-    const Tw *__restrict__ tw = a.tw;
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    const Tw *tw = ltw;
 
     u64 v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = a.in[base + ((u64)field_of<C::A0>(tf, k) << lb)];
+    for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];   // first pass: s0 = 0, blk = 0
 
-    round_fwd<C::R0, WIDE>(v, tw, 1u, m);
+    round_fwd<C::R0, WIDE>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        exchange_strided<CW, C::A0, A>(v, lds, c, tf);
+        exchange_strided<CW, C::A0, A, true>(v, lds, c, tf);   // its barrier also publishes ltw
         round_fwd<4, WIDE>(v, tw, (1u << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        exchange_strided<CW, C::a_of(1), A>(v, lds, c, tf);
+        exchange_strided<CW, C::a_of(1), A, false>(v, lds, c, tf);
         round_fwd<4, WIDE>(v, tw, (1u << LS) + (tf >> A), m);
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
@@ -347,22 +402,25 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     const u64 poly = (u64)(blockIdx.x >> lcg);
     const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
     const Mod &m = a.mod;
-    const Tw *__restrict__ tw = a.tw;
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    const Tw *tw = ltw;
 
     constexpr int ALAST = C::a_of(C::NR - 1);
     u64 v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = a.in[base + ((u64)field_of<ALAST>(tf, k) << lb)];  // < 2q
+    for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
+    __syncthreads();
 
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
-        exchange_strided<CW, A, C::a_of(1)>(v, lds, c, tf);
+        exchange_strided<CW, A, C::a_of(1), true>(v, lds, c, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
-        exchange_strided<CW, A, C::A0>(v, lds, c, tf);
+        exchange_strided<CW, A, C::A0, (C::NR <= 2)>(v, lds, c, tf);
     }
     round_inv<C::R0, true>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
@@ -391,38 +449,6 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
 //     global stores of item i;  barrier (E);  cur ^= 1
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
-
-// stage a pass-local twiddle table into LDS: local index li in [1, M): ls = floor(log2 li),
-// global index (1 << (s0+ls)) + (blk << ls) + (li - 2^ls); the rounds then index it with
-// T0 = (1 << ls0) + H, i.e. as if the pass were a transform of its own.
-template <int M, int TH>
-__device__ __forceinline__ void stage_twiddles(Tw *ltw, const Tw *__restrict__ tw, u32 s0, u32 blk,
-                                               u32 tid) {
-    for (u32 li = tid; li < (u32)M; li += TH) {
-        Tw t{0, 0};
-        if (li) {
-            const u32 ls = 31u - (u32)__builtin_clz(li);
-            t = tw[(1u << (s0 + ls)) + (blk << ls) + (li - (1u << ls))];
-        }
-        ltw[li] = t;
-    }
-}
-
-// one LDS-DMA wave-instruction: lane l copies 16 B from gsrc to LDS byte lds_dst + 16*l.
-// m0 is compiler-reserved: saved and restored inside the statement (guide §5.7).
-__device__ __forceinline__ void dma16(const void *gsrc, u32 lds_dst_uniform) {
-    u32 keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst_uniform)
-        : "memory");
-}
-__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ u32 xrow(u32 f) { return f ^ ((f >> 4) & 1u); }
 

@@ -14,8 +14,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")  # env: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "ntt_kernels.hip"]
-HEADERS = ["ntt_kernels.hpp", "zq_device.hpp", os.path.join("..", "..", "include", "fhe_ntt.h")]
+SOURCES = ["capi.hip", "ntt_kernels.hip", "zring.hip"]
+HEADERS = ["ntt_kernels.hpp", "zq_device.hpp", "capi_internal.hpp",
+           os.path.join("..", "..", "include", "fhe_ntt.h")]
+OBJ_DIR = os.path.join(_HERE, "build")
+# -ffp-contract=off: zring.hip restates the reference's f64 scale-and-round (one IEEE rounding
+# per operation); nothing else in the library uses floating point.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+               "-ffp-contract=off"]
 
 FHE_OK = 0
 FHE_E_BAD_N = -1
@@ -38,6 +44,10 @@ EXPORTS = [
     "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
+    # next rows: exact products over Z / mod 2^64 on top of the engine
+    "fhe_r_naive_mul", "fhe_r_naive_mul_dev", "fhe_mul_div_round_dev",
+    "fhe_bfv_tensor", "fhe_bfv_tensor_dev", "fhe_bfv_relinearize_dev", "fhe_bfv_mul", "fhe_bfv_mul_dev",
+    "fhe_tn_mul", "fhe_tn_mul_dev", "fhe_tggsw_external_product", "fhe_tggsw_external_product_dev",
 ]
 
 
@@ -49,21 +59,41 @@ class FheError(RuntimeError):
         self.code = code
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    t = os.path.getmtime(target)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(src):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+
+
+def needs_build():
+    return _stale(LIB_PATH, [d for s in SOURCES for d in _deps(s)])
+
+
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 → fhe-study_amd/libfhe_ntt.so (in-tree)."""
+    """hipcc --offload-arch=gfx950: one object per source (only stale ones are recompiled),
+    linked into fhe-study_amd/libfhe_ntt.so (in-tree, so it travels to the GPU box)."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, _deps(src)):
+            cmd = [hipcc] + HIPCC_FLAGS + ["-c", "-o", obj, os.path.join(CSRC, src)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:   # sources compile in parallel (3 processes)
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -129,6 +159,20 @@ def load_library():
     L.fhe_ntt_kernel_timing_enable.argtypes = [_int]
     L.fhe_ntt_kernel_timing_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), _p64, _int]
     L.fhe_ntt_kernel_timing_reset.argtypes = []
+    _i64p = ctypes.POINTER(ctypes.c_int64)
+    _uint = ctypes.c_uint
+    L.fhe_r_naive_mul.argtypes = [_u64, _vp, _vp, _vp, _sz]
+    L.fhe_r_naive_mul_dev.argtypes = [_u64, _vp, _vp, _vp, _sz, _uint, _uint, _vp]
+    L.fhe_mul_div_round_dev.argtypes = [_u64, _u64, _vp, _u64, _u64, _vp, _sz, _vp]
+    L.fhe_bfv_tensor.argtypes = [_u64, _u64, _u64, _vp, _vp, _sz]
+    L.fhe_bfv_tensor_dev.argtypes = [_u64, _u64, _u64, _vp, _vp, _sz, _vp]
+    L.fhe_bfv_relinearize_dev.argtypes = [_u64, _u64, _u64, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_bfv_mul.argtypes = [_u64, _u64, _u64, _u64, _vp, _vp, _vp, _sz]
+    L.fhe_bfv_mul_dev.argtypes = [_u64, _u64, _u64, _u64, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_tn_mul.argtypes = [_u64, _vp, _vp, _vp, _sz]
+    L.fhe_tn_mul_dev.argtypes = [_u64, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_tggsw_external_product.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz]
+    L.fhe_tggsw_external_product_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
     L.fhe_ntt_device_count.argtypes = []
     L.fhe_last_error.restype = ctypes.c_char_p
     L.fhe_ntt_version.restype = ctypes.c_char_p
@@ -243,6 +287,58 @@ def rq_mul_checked(plan_a, plan_b, a, b):
     _check(load_library().fhe_rq_mul_checked(plan_a.handle, plan_b.handle, pa, pb,
                                              c.ctypes.data_as(_vp), None, a.size // plan_a.n))
     return c
+
+
+# ---- next rows: exact products over Z / mod 2^64 (host buffers) -----------------------------
+
+def r_naive_mul(n, a, b):
+    """arith::ring_n::naive_mul (ring_n.rs:307-320) → (batch, 2n-1) int64"""
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    b = np.ascontiguousarray(b, dtype=np.int64)
+    batch = a.size // n
+    out = np.empty(batch * 2 * n, dtype=np.int64)
+    _check(load_library().fhe_r_naive_mul(n, a.ctypes.data_as(_vp), b.ctypes.data_as(_vp),
+                                          out.ctypes.data_as(_vp), batch))
+    return out.reshape(batch, 2 * n)[:, :2 * n - 1]
+
+
+def bfv_tensor(q, n, t, a0, a1, b0, b1):
+    """RLWE::tensor (bfv/src/lib.rs:59-85) → (c0, c1, c2), each (batch, n)"""
+    ab = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64).reshape(-1, n) for x in (a0, a1, b0, b1)]))
+    batch = ab.shape[1]
+    c = np.empty((3, batch, n), dtype=np.uint64)
+    _check(load_library().fhe_bfv_tensor(q, n, t, ab.ctypes.data_as(_vp), c.ctypes.data_as(_vp), batch))
+    return c[0], c[1], c[2]
+
+
+def bfv_mul(q, n, t, pq, rlk0, rlk1, a0, a1, b0, b1):
+    """RLWE::mul (bfv/src/lib.rs:87-90) → (o0, o1), each (batch, n)"""
+    ab = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64).reshape(-1, n) for x in (a0, a1, b0, b1)]))
+    rlk = np.ascontiguousarray(np.stack([np.asarray(rlk0, dtype=np.uint64), np.asarray(rlk1, dtype=np.uint64)]))
+    batch = ab.shape[1]
+    out = np.empty((2, batch, n), dtype=np.uint64)
+    _check(load_library().fhe_bfv_mul(q, n, t, pq, rlk.ctypes.data_as(_vp), ab.ctypes.data_as(_vp),
+                                      out.ctypes.data_as(_vp), batch))
+    return out[0], out[1]
+
+
+def tn_mul(n, a, b):
+    """Tn x Tn (ring_torus.rs:266-298) → (batch, n) uint64"""
+    a, pa = _host(a)
+    b, pb = _host(b)
+    out = np.empty_like(a)
+    _check(load_library().fhe_tn_mul(n, pa, pb, out.ctypes.data_as(_vp), a.size // n))
+    return out
+
+
+def tggsw_external_product(n, k, l, tggsw, tglwe):
+    """TGGSW x TGLWE (tfhe/src/tggsw.rs:45-62); tggsw [(k+1)][l][(k+1)][n], tglwe [batch][(k+1)][n]"""
+    g, pg = _host(tggsw)
+    t, pt = _host(tglwe)
+    batch = t.size // ((k + 1) * n)
+    out = np.empty_like(t)
+    _check(load_library().fhe_tggsw_external_product(n, k, l, pg, pt, out.ctypes.data_as(_vp), batch))
+    return out
 
 
 def fill_synthetic_dev(q, seed, first_index, count, d_out, stream=None):

@@ -15,8 +15,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/fhe_ntt.h"
-#include "ntt_kernels.hpp"
+#include "capi_internal.hpp"
 
 using fhe::u64;
 typedef unsigned __int128 u128;
@@ -26,21 +25,18 @@ typedef unsigned __int128 u128;
 // ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...) {
+int fhe_fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-static int hip_fail(hipError_t e, const char *what) {
-    return fail(FHE_E_HIP, "%s: %s", what, hipGetErrorString(e));
+int fhe_hip_fail(hipError_t e, const char *what) {
+    return fhe_fail(FHE_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
-#define HIP_TRY(expr)                                     \
-    do {                                                  \
-        hipError_t e_ = (expr);                           \
-        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
-    } while (0)
+#define fail fhe_fail
+#define hip_fail fhe_hip_fail
 
 // ---------------------------------------------------------------------------
 // host number theory (one-off, per plan) — follows arith/src/ntt.rs:115-185
@@ -72,24 +68,6 @@ static inline u64 bitrev(u64 i, unsigned log_n) {
 // ---------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------
-static constexpr int kMaxDevices = 16;
-
-struct DeviceTables {
-    fhe::Tw *tw_fwd = nullptr;
-    fhe::Tw *tw_inv = nullptr;
-    bool ready = false;
-};
-
-struct fhe_ntt_plan {
-    u64 q = 0, n = 0, psi = 0, n_inv = 0;
-    unsigned log_n = 0;
-    std::vector<u64> roots, roots_inv;  // as the reference's CACHE value (ntt.rs:18)
-    fhe::Mod mod{};
-    fhe::Tw ninv{}, s_ninv{};
-    mutable std::mutex dev_lock;
-    mutable DeviceTables dev[kMaxDevices];
-};
-
 static std::mutex g_plans_lock;
 static std::map<std::pair<u64, u64>, std::unique_ptr<fhe_ntt_plan>> g_plans;
 
@@ -186,7 +164,7 @@ extern "C" int fhe_ntt_plan_tables(const fhe_ntt_plan *plan, uint64_t *roots, ui
 // ---------------------------------------------------------------------------
 // device state
 // ---------------------------------------------------------------------------
-static int current_device(int *dev) {
+int fhe_current_device(int *dev) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -199,9 +177,9 @@ static int current_device(int *dev) {
     return FHE_OK;
 }
 
-static int device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
+int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     int dev = 0;
-    int rc = current_device(&dev);
+    int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     std::lock_guard<std::mutex> lk(plan->dev_lock);
     DeviceTables &t = plan->dev[dev];
@@ -239,7 +217,7 @@ static size_t g_batch_tile_override = 0;
 // launches lose more in ramp-up and tail than that.
 static constexpr u64 kMaxTilePolys = 1ull << 24;
 
-static u64 batch_tile_for(const fhe_ntt_plan *plan) {
+u64 fhe_batch_tile_for(const fhe_ntt_plan *plan) {
     size_t ov;
     {
         std::lock_guard<std::mutex> lk(g_cfg_lock);
@@ -262,20 +240,20 @@ extern "C" int fhe_ntt_set_batch_tile(size_t polys) {
     return FHE_OK;
 }
 
-// grow-only per-device workspace for fhe_rq_mul_dev(d_work = NULL)
+// grow-only per-device workspaces (slot 0: fhe_rq_mul_dev(d_work = NULL), slot 1: zring)
 struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
 static std::mutex g_ws_lock;
-static Workspace g_ws[kMaxDevices];
+static Workspace g_ws[2][kMaxDevices];
 
-static int workspace_get(size_t bytes, void **out) {
+int fhe_workspace_get(int slot, size_t bytes, void **out) {
     int dev = 0;
-    int rc = current_device(&dev);
+    int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     std::lock_guard<std::mutex> lk(g_ws_lock);
-    Workspace &w = g_ws[dev];
+    Workspace &w = g_ws[slot][dev];
     if (w.bytes < bytes) {
         if (w.ptr) {
             HIP_TRY(hipDeviceSynchronize());
@@ -288,6 +266,15 @@ static int workspace_get(size_t bytes, void **out) {
     }
     *out = w.ptr;
     return FHE_OK;
+}
+void fhe_workspace_free_all() {
+    std::lock_guard<std::mutex> lk(g_ws_lock);
+    for (auto &slot : g_ws)
+        for (auto &w : slot) {
+            if (w.ptr) (void)hipFree(w.ptr);
+            w.ptr = nullptr;
+            w.bytes = 0;
+        }
 }
 
 // ---------------------------------------------------------------------------
@@ -372,14 +359,6 @@ extern "C" int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_
 // ---------------------------------------------------------------------------
 // device-resident entry points
 // ---------------------------------------------------------------------------
-// the kernels move 16 bytes per lane where a thread owns consecutive coefficients
-static inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
-#define REQUIRE_ALIGNED(p)                                                                   \
-    do {                                                                                     \
-        if ((p) && misaligned(p))                                                            \
-            return fail(FHE_E_INVALID, #p " must be 16-byte aligned (got %p)", (const void *)(p)); \
-    } while (0)
-
 extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, void *d_out,
                                    size_t batch, void *hip_stream) {
     if (!plan) return fail(FHE_E_NULL, "plan is NULL");
@@ -388,10 +367,10 @@ extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, v
     REQUIRE_ALIGNED(d_in);
     REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
-    int rc = device_plan(plan, &dp);
+    int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
     hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_in, (u64 *)d_out, batch,
-                                           batch_tile_for(plan), (hipStream_t)hip_stream);
+                                           fhe_batch_tile_for(plan), (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward");
     return FHE_OK;
 }
@@ -404,10 +383,10 @@ extern "C" int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, v
     REQUIRE_ALIGNED(d_in);
     REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
-    int rc = device_plan(plan, &dp);
+    int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
     hipError_t e = fhe::launch_ntt_inverse(dp, (const u64 *)d_in, nullptr, nullptr, (u64 *)d_out,
-                                           batch, batch_tile_for(plan), (hipStream_t)hip_stream);
+                                           batch, fhe_batch_tile_for(plan), (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_inverse");
     return FHE_OK;
 }
@@ -432,18 +411,18 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
     REQUIRE_ALIGNED(d_b_evals_out);
     REQUIRE_ALIGNED(d_work);
     fhe::DevicePlan dp;
-    int rc = device_plan(plan, &dp);
+    int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t elems = batch * plan->n, bytes = elems * sizeof(u64);
-    const u64 tile = batch_tile_for(plan);
+    const u64 tile = fhe_batch_tile_for(plan);
 
     const bool need_wa = !a_is_evals && !d_a_evals_out;
     const bool need_wb = !b_is_evals && !d_b_evals_out;
     u64 *work = (u64 *)d_work;
     if ((need_wa || need_wb) && !work) {
         void *w = nullptr;
-        rc = workspace_get(2 * bytes, &w);
+        rc = fhe_workspace_get(0, 2 * bytes, &w);
         if (rc != FHE_OK) return rc;
         work = (u64 *)w;
     }
@@ -478,7 +457,7 @@ extern "C" int fhe_rq_pointwise_mul_dev(const fhe_ntt_plan *plan, const void *d_
     if (batch == 0) return FHE_OK;
     if (!d_a || !d_b || !d_c) return fail(FHE_E_NULL, "fhe_rq_pointwise_mul_dev: NULL buffer");
     fhe::DevicePlan dp;
-    int rc = device_plan(plan, &dp);
+    int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
     hipError_t e = fhe::launch_pointwise_mul(dp, (const u64 *)d_a, (const u64 *)d_b, (u64 *)d_c,
                                              batch * plan->n, (hipStream_t)hip_stream);
@@ -492,7 +471,7 @@ extern "C" int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_
     if (!d_out) return fail(FHE_E_NULL, "fhe_fill_synthetic_dev: NULL buffer");
     if (q == 0) return fail(FHE_E_BAD_Q, "q is 0");
     int dev;
-    int rc = current_device(&dev);
+    int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     hipError_t e = fhe::launch_fill_synthetic((u64 *)d_out, count, q, seed, first_index,
                                               (hipStream_t)hip_stream);
@@ -519,7 +498,7 @@ static int host_transform(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t
     if (batch == 0) return FHE_OK;
     if (!in || !out) return fail(FHE_E_NULL, "NULL buffer");
     int dev;
-    int rc = current_device(&dev);
+    int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     const size_t bytes = batch * plan->n * sizeof(u64);
     DevBuf d;
@@ -550,7 +529,7 @@ extern "C" int fhe_rq_mul(const fhe_ntt_plan *plan, const uint64_t *a, int a_is_
     if (batch == 0) return FHE_OK;
     if (!a || !b || !c) return fail(FHE_E_NULL, "fhe_rq_mul: NULL operand");
     int dev;
-    int rc = current_device(&dev);
+    int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     const size_t bytes = batch * plan->n * sizeof(u64);
     DevBuf da, db, dc, dce;
@@ -592,7 +571,7 @@ extern "C" int fhe_rq_pointwise_mul(const fhe_ntt_plan *plan, const uint64_t *a,
     if (batch == 0) return FHE_OK;
     if (!a || !b || !c) return fail(FHE_E_NULL, "fhe_rq_pointwise_mul: NULL buffer");
     int dev;
-    int rc = current_device(&dev);
+    int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     const size_t bytes = batch * plan->n * sizeof(u64);
     DevBuf da, db;
@@ -613,7 +592,7 @@ extern "C" int fhe_rq_check_canonical(const fhe_ntt_plan *plan, const uint64_t *
     if (batch == 0) return FHE_OK;
     if (!x) return fail(FHE_E_NULL, "fhe_rq_check_canonical: NULL buffer");
     int dev;
-    int rc = current_device(&dev);
+    int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     const size_t count = batch * plan->n, bytes = count * sizeof(u64);
     DevBuf dx, df;
@@ -652,14 +631,7 @@ extern "C" int fhe_ntt_shutdown(void) {
         timing_drain_locked();
         g_timing.clear();
     }
-    {
-        std::lock_guard<std::mutex> lk(g_ws_lock);
-        for (auto &w : g_ws) {
-            if (w.ptr) (void)hipFree(w.ptr);
-            w.ptr = nullptr;
-            w.bytes = 0;
-        }
-    }
+    fhe_workspace_free_all();
     std::lock_guard<std::mutex> lk(g_plans_lock);
     for (auto &kv : g_plans) {
         fhe_ntt_plan *p = kv.second.get();

@@ -1,0 +1,622 @@
+// zring.hip — exact integer polynomial products on top of the NTT engine, for the
+// reference's two schoolbook callers either side of the NTT path:
+//
+//   N1  BFV ciphertext multiply      bfv/src/lib.rs:59-90 (tensor), :251-271 (relinearize_204)
+//         arith::ring_n::naive_mul     ring_n.rs:307-320  linear convolution over Z, `as i64` wrap
+//         arith::ring_n::mul_div_round ring_n.rs:130-138  f64 scale, round, Zq::from_f64, fold
+//   N2  TFHE                         arith/src/ring_torus.rs:266-298 (Tn x Tn mod 2^64, X^n+1)
+//         TGGSW x TGLWE                tfhe/src/tggsw.rs:45-62,139-149, tglwe.rs:182-194
+//
+// The reference does these with O(n^2) loops in i128 / wrapping u128.  Here a product over Z
+// is computed EXACTLY as K <= 3 products modulo NTT-friendly 61-bit primes (the engine's
+// kernels, with one plan per prime), recombined by Garner's CRT and only then reduced
+// mod 2^64 — which is what the reference's truncation keeps.  A linear convolution of two
+// length-n inputs is the negacyclic product of their zero-padded length-2n images (degree
+// < 2n: nothing wraps); the torus product is negacyclic at length n with a centred lift.
+// K is chosen from a caller-supplied bound on the true coefficient magnitude.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "capi_internal.hpp"
+#include "zq_device.hpp"
+
+using fhe::Mod;
+using fhe::Tw;
+using fhe::u32;
+using fhe::u64;
+typedef unsigned __int128 u128;
+
+// ---------------------------------------------------------------------------
+// CRT primes: p = 1 (mod 2^21), p < 2^61 (the engine's wide lazy range), pairwise coprime.
+// ---------------------------------------------------------------------------
+static const u64 kCrtPrimes[3] = {
+    2305843009211596801ull,  // 2^61 - 2^21 + 1  (the engine's headline modulus)
+    2305843009196916737ull,  // 0x1fffffffff000001
+    2305843009146585089ull,  // 0x1ffffffffc000001
+};
+
+namespace fhe {
+
+struct CrtConsts {
+    Mod m[3];
+    Tw inv1_mod2;    // P1^-1            mod P2
+    Tw inv12_mod3;   // (P1*P2)^-1       mod P3
+    Tw p1_mod3;      // P1               mod P3
+    u64 p1;          // P1
+    u64 p12_lo;      // P1*P2            mod 2^64
+    u64 prod_lo[3];  // P1, P1*P2, P1*P2*P3  mod 2^64  (what a negative lift subtracts)
+    u64 half1;       // ceil(P1 / 2)
+    u64 half2;       // (P2 - 1) / 2
+    u64 half3;       // (P3 - 1) / 2
+};
+
+// x mod p for any 64-bit x (Shoup with w = 1), canonical
+__device__ __forceinline__ u64 reduce_any(u64 x, const Mod &m) {
+    const u64 r = x - __umul64hi(x, m.onep) * m.q;  // [0, 2p)
+    return canon2(r, m);
+}
+
+__global__ __launch_bounds__(256) void zr_reduce_pad_kernel(const u64 *__restrict__ in,
+                                                            u64 *__restrict__ out, u64 rows, u32 n,
+                                                            u32 n2, Mod m) {
+    const u64 total = rows * n2, stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 r = i / n2;
+        const u32 j = (u32)(i - r * n2);
+        out[i] = j < n ? reduce_any(in[r * n + j], m) : 0ull;
+    }
+}
+
+// Tn::decompose(beta = 2, l), ring_torus.rs:67-77 / torus.rs:43-52: digit d of coefficient x is
+// bit l-1-d.  out[(row*l + d)][j]
+__global__ __launch_bounds__(256) void zr_digits_kernel(const u64 *__restrict__ in,
+                                                        u64 *__restrict__ out, u64 rows, u32 n, u32 l) {
+    const u64 total = rows * l * n, stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 rd = i / n;
+        const u32 j = (u32)(i - rd * n);
+        const u64 r = rd / l;
+        const u32 d = (u32)(rd - r * l);
+        out[i] = (in[r * n + j] >> (l - 1 - d)) & 1ull;
+    }
+}
+
+// BFV tensor in the NTT domain (bfv/src/lib.rs:71-77): c0 = a0*b0, c1 = a0*b1 + a1*b0, c2 = a1*b1.
+// ab = [a0 | a1 | b0 | b1], each `count` words; c = [c0 | c1 | c2].
+__global__ __launch_bounds__(256) void zr_tensor_kernel(const u64 *__restrict__ ab, u64 *__restrict__ c,
+                                                        u64 count, Mod m) {
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const u64 a0 = ab[i], a1 = ab[count + i], b0 = ab[2 * count + i], b1 = ab[3 * count + i];
+        c[i] = mul_mod_var(a0, b0, m);
+        const u64 s = mul_mod_var(a0, b1, m) + mul_mod_var(a1, b0, m);
+        c[count + i] = canon2(s, m);
+        c[2 * count + i] = mul_mod_var(a1, b1, m);
+    }
+}
+
+// c[r][b][j] = x[b][j] * y[r][j]   (one key polynomial y[r] against the whole batch)
+__global__ __launch_bounds__(256) void zr_mul_bcast_kernel(const u64 *__restrict__ x,
+                                                           const u64 *__restrict__ y, u64 *__restrict__ c,
+                                                           u64 batch, u32 n2, u32 rows, Mod m) {
+    const u64 per = batch * n2, total = per * rows, stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 r = i / per, bj = i - r * per;
+        const u32 j = (u32)(bj % n2);
+        c[i] = mul_mod_var(x[bj], y[r * n2 + j], m);
+    }
+}
+
+// External product accumulation in the NTT domain (tggsw.rs:57-59, 145):
+//   out[b][c][j] = sum_{i<k1} sum_{d<l} G[i][d][c][j] * D[b][i][d][j]      (mod p)
+__global__ __launch_bounds__(256) void zr_extprod_mac_kernel(const u64 *__restrict__ G,
+                                                             const u64 *__restrict__ D,
+                                                             u64 *__restrict__ out, u64 batch, u32 n,
+                                                             u32 k1, u32 l, Mod m) {
+    const u64 total = batch * k1 * n, stride = (u64)gridDim.x * 256;
+    for (u64 idx = (u64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const u32 j = (u32)(idx % n);
+        const u64 bc = idx / n;
+        const u32 c = (u32)(bc % k1);
+        const u64 b = bc / k1;
+        u64 acc = 0;
+        for (u32 i = 0; i < k1; i++)
+            for (u32 d = 0; d < l; d++) {
+                const u64 g = G[(((u64)i * l + d) * k1 + c) * n + j];
+                const u64 x = D[((b * k1 + i) * l + d) * n + j];
+                acc = canon2(acc + mul_mod_var(g, x, m), m);
+            }
+        out[idx] = acc;
+    }
+}
+
+// Garner: residues r1 (mod P1), r2 (mod P2), r3 (mod P3) of an integer V with |V| < P/2
+// (SIGNED) or 0 <= V < P  ->  V mod 2^64.
+template <int K, bool SIGNED>
+__global__ __launch_bounds__(256) void zr_crt_kernel(const u64 *__restrict__ r1,
+                                                     const u64 *__restrict__ r2,
+                                                     const u64 *__restrict__ r3, u64 *__restrict__ out,
+                                                     u64 count, CrtConsts cc) {
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const u64 x1 = r1[i];
+        u64 v = x1;
+        bool neg = false;
+        if (K == 1) {
+            neg = x1 >= cc.half1;
+        } else {
+            const Mod &m2 = cc.m[1];
+            // d2 = (r2 - r1) * P1^-1 mod P2      (r1 < P1 may exceed P2: reduce first)
+            const u64 x1m2 = canon2(x1, m2);                       // P1 < 2*P2
+            const u64 diff = canon2(r2[i] + m2.q - x1m2, m2);
+            const u64 d2 = canon2(mul_shoup_lazy(diff, cc.inv1_mod2.w, cc.inv1_mod2.wp, m2), m2);
+            v = x1 + cc.p1 * d2;                                    // mod 2^64
+            if (K == 2) {
+                neg = d2 > cc.half2 || (d2 == cc.half2 && x1 >= cc.half1);
+            } else {
+                const Mod &m3 = cc.m[2];
+                // d3 = (r3 - r1 - P1*d2) * (P1*P2)^-1 mod P3
+                const u64 x1m3 = canon2(x1, m3);
+                const u64 d2m3 = canon2(d2, m3);
+                const u64 t = canon2(mul_shoup_lazy(d2m3, cc.p1_mod3.w, cc.p1_mod3.wp, m3), m3);
+                u64 diff3 = canon2(r3[i] + m3.q - x1m3, m3);
+                diff3 = canon2(diff3 + m3.q - t, m3);
+                const u64 d3 = canon2(mul_shoup_lazy(diff3, cc.inv12_mod3.w, cc.inv12_mod3.wp, m3), m3);
+                v += cc.p12_lo * d3;
+                neg = d3 > cc.half3 ||
+                      (d3 == cc.half3 && (d2 > cc.half2 || (d2 == cc.half2 && x1 >= cc.half1)));
+            }
+        }
+        if (SIGNED && neg) v -= cc.prod_lo[K - 1];
+        out[i] = v;
+    }
+}
+
+// Rust `f64 as i64` (saturating, NaN -> 0)
+__device__ __forceinline__ long long f64_as_i64(double x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return 0x7fffffffffffffffll;
+    if (x <= -9223372036854775808.0) return (long long)0x8000000000000000ull;
+    return (long long)x;
+}
+// Zq::from_f64, arith/src/zq.rs:32-39
+__device__ __forceinline__ u64 zq_from_f64(u64 q, double ef) {
+    const long long e = f64_as_i64(round(ef));
+    const long long qi = (long long)q;
+    if (e < 0 || e >= qi) return (u64)(((e % qi) + qi) % qi);
+    return (u64)e;
+}
+
+// mul_div_round (ring_n.rs:130-138) + Rq::from_vec_f64 (ring_nq.rs:160-163) + the X^n+1 fold
+// (ring_nq.rs:132-141): v holds the 2n-1 convolution words (slot 2n-1 = 0) as i64;
+// out[j] = z[j] - z[j+n] in Z_q with z[i] = from_f64(round((num as f64 * v[i] as f64) / den as f64)).
+__global__ __launch_bounds__(256) void zr_mul_div_round_kernel(const u64 *__restrict__ v,
+                                                               u64 *__restrict__ out, u64 rows, u32 n,
+                                                               u64 q, u64 num, u64 den) {
+    const u64 total = rows * n, stride = (u64)gridDim.x * 256;
+    const double numf = (double)num, denf = (double)den;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 r = i / n;
+        const u32 j = (u32)(i - r * n);
+        const long long lo = (long long)v[r * 2 * n + j], hi = (long long)v[r * 2 * n + n + j];
+        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
+        const u64 zh = (j == n - 1) ? 0ull : zq_from_f64(q, round((numf * (double)hi) / denf));
+        out[i] = zl >= zh ? zl - zh : (q + zl) - zh;   // Zq::sub, zq.rs:259-276
+    }
+}
+
+// Zq::add over whole polynomials (c0 + &r0, bfv/src/lib.rs:269)
+__global__ __launch_bounds__(256) void zr_rq_add_kernel(const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                        u64 *__restrict__ c, u64 count, u64 q) {
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        u64 s = a[i] + b[i];
+        if (s >= q) s -= q;
+        c[i] = s;
+    }
+}
+
+}  // namespace fhe
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline unsigned ew_grid(u64 count) {
+    u64 g = (count + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    return (unsigned)(g ? g : 1);
+}
+static inline u64 hmulmod(u64 a, u64 b, u64 p) { return (u64)(((u128)a * b) % p); }
+static u64 hpow(u64 a, u64 e, u64 p) {
+    u64 r = 1;
+    a %= p;
+    while (e) { if (e & 1) r = hmulmod(r, a, p); a = hmulmod(a, a, p); e >>= 1; }
+    return r;
+}
+static inline Tw htw(u64 w, u64 p) { return Tw{w, (u64)((((u128)w) << 64) / p)}; }
+
+// number of primes for a bound of `bits` on |true value| (signed lift needs one more bit)
+static int primes_for_bits(unsigned bits, bool is_signed) {
+    const unsigned need = bits + (is_signed ? 1u : 0u);
+    if (need <= 60) return 1;
+    if (need <= 121) return 2;
+    if (need <= 182) return 3;
+    return 0;
+}
+
+struct ZCtx {
+    int K = 0;
+    const fhe_ntt_plan *plan[3] = {nullptr, nullptr, nullptr};
+    fhe::DevicePlan dp[3];
+    fhe::CrtConsts cc{};
+};
+
+static int zctx_init(ZCtx *z, u64 n2, int K) {
+    if (K < 1 || K > 3) return fhe_fail(FHE_E_INVALID, "coefficient bound too large for 3 CRT primes");
+    z->K = K;
+    for (int k = 0; k < K; k++) {
+        int rc = fhe_ntt_plan_get(kCrtPrimes[k], n2, &z->plan[k]);
+        if (rc != FHE_OK) return rc;
+        rc = fhe_device_plan(z->plan[k], &z->dp[k]);
+        if (rc != FHE_OK) return rc;
+        z->cc.m[k] = z->plan[k]->mod;
+    }
+    const u64 P1 = kCrtPrimes[0], P2 = kCrtPrimes[1], P3 = kCrtPrimes[2];
+    z->cc.p1 = P1;
+    z->cc.p12_lo = P1 * P2;
+    z->cc.prod_lo[0] = P1;
+    z->cc.prod_lo[1] = P1 * P2;
+    z->cc.prod_lo[2] = P1 * P2 * P3;
+    z->cc.half1 = (P1 + 1) / 2;
+    z->cc.half2 = (P2 - 1) / 2;
+    z->cc.half3 = (P3 - 1) / 2;
+    z->cc.inv1_mod2 = htw(hpow(P1 % P2, P2 - 2, P2), P2);
+    z->cc.p1_mod3 = htw(P1 % P3, P3);
+    z->cc.inv12_mod3 = htw(hpow(hmulmod(P1 % P3, P2 % P3, P3), P3 - 2, P3), P3);
+    if (K < 2) z->cc.m[1] = z->cc.m[0];
+    if (K < 3) z->cc.m[2] = z->cc.m[0];
+    return FHE_OK;
+}
+
+#define LAUNCH_OK(what)                                              \
+    do {                                                             \
+        hipError_t e_ = hipGetLastError();                           \
+        if (e_ != hipSuccess) return fhe_hip_fail(e_, what);         \
+    } while (0)
+
+static int z_forward(const ZCtx &z, int k, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
+    hipError_t e = fhe::launch_ntt_forward(z.dp[k], in, out, rows, fhe_batch_tile_for(z.plan[k]), st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "zring forward NTT");
+}
+static int z_inverse(const ZCtx &z, int k, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
+    hipError_t e = fhe::launch_ntt_inverse(z.dp[k], in, nullptr, nullptr, out, rows,
+                                           fhe_batch_tile_for(z.plan[k]), st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "zring inverse NTT");
+}
+static int z_crt(const ZCtx &z, bool is_signed, const u64 *r1, const u64 *r2, const u64 *r3, u64 *out,
+                 u64 count, hipStream_t st) {
+    const unsigned g = ew_grid(count);
+#define CRT_CASE(K_, S_) hipLaunchKernelGGL((fhe::zr_crt_kernel<K_, S_>), dim3(g), dim3(256), 0, st, r1, r2, r3, out, count, z.cc)
+    if (z.K == 1) { if (is_signed) CRT_CASE(1, true); else CRT_CASE(1, false); }
+    else if (z.K == 2) { if (is_signed) CRT_CASE(2, true); else CRT_CASE(2, false); }
+    else { if (is_signed) CRT_CASE(3, true); else CRT_CASE(3, false); }
+#undef CRT_CASE
+    LAUNCH_OK("zr_crt_kernel");
+    return FHE_OK;
+}
+
+static unsigned bits_of(u64 x) { unsigned b = 0; while (x) { b++; x >>= 1; } return b; }
+static unsigned ceil_log2(u64 x) { return x <= 1 ? 0 : bits_of(x - 1); }
+
+static int check_pow2_n(u64 n, const char *who) {
+    if (n < 2 || (n & (n - 1)) != 0 || n > (1ull << 19))
+        return fhe_fail(FHE_E_BAD_N, "%s: n=%llu must be a power of two in [2, 2^19]", who, (unsigned long long)n);
+    return FHE_OK;
+}
+
+// ---- arith::ring_n::naive_mul ---------------------------------------------------------------
+extern "C" int fhe_r_naive_mul_dev(uint64_t n, const void *d_a, const void *d_b, void *d_out, size_t batch,
+                                   unsigned a_bits, unsigned b_bits, void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_r_naive_mul_dev");
+    if (rc != FHE_OK) return rc;
+    if (batch == 0) return FHE_OK;
+    if (!d_a || !d_b || !d_out) return fhe_fail(FHE_E_NULL, "fhe_r_naive_mul_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_b); REQUIRE_ALIGNED(d_out);
+    if (a_bits == 0 || a_bits > 64) a_bits = 64;
+    if (b_bits == 0 || b_bits > 64) b_bits = 64;
+    const u64 n2 = 2 * n;
+    ZCtx z;
+    rc = zctx_init(&z, n2, primes_for_bits(a_bits + b_bits + ceil_log2(n), false));
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 words = batch * n2;
+    void *wsv = nullptr;
+    rc = fhe_workspace_get(1, (2 + (size_t)z.K) * words * 8, &wsv);
+    if (rc != FHE_OK) return rc;
+    u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;   // R: K residue arrays
+    for (int k = 0; k < z.K; k++) {
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
+        LAUNCH_OK("zr_reduce_pad_kernel");
+        if ((rc = z_forward(z, k, A, A, batch, st)) != FHE_OK) return rc;
+        if ((rc = z_forward(z, k, B, B, batch, st)) != FHE_OK) return rc;
+        hipError_t e = fhe::launch_ntt_inverse(z.dp[k], A, B, nullptr, R + (u64)k * words, batch,
+                                               fhe_batch_tile_for(z.plan[k]), st);
+        if (e != hipSuccess) return fhe_hip_fail(e, "zring inverse(A.*B)");
+    }
+    return z_crt(z, false, R, R + words, R + 2 * words, (u64 *)d_out, words, st);
+}
+
+// ---- arith::ring_n::mul_div_round -----------------------------------------------------------
+extern "C" int fhe_mul_div_round_dev(uint64_t q, uint64_t n, const void *d_v, uint64_t num, uint64_t den,
+                                     void *d_out, size_t batch, void *hip_stream) {
+    if (n < 1) return fhe_fail(FHE_E_BAD_N, "fhe_mul_div_round_dev: n = 0");
+    if (q == 0 || den == 0 || (q >> 63)) return fhe_fail(FHE_E_BAD_Q, "fhe_mul_div_round_dev: q must be in [1, 2^63), den > 0");
+    if (batch == 0) return FHE_OK;
+    if (!d_v || !d_out) return fhe_fail(FHE_E_NULL, "fhe_mul_div_round_dev: NULL buffer");
+    int dev;
+    int rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::zr_mul_div_round_kernel, dim3(ew_grid(batch * n)), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const u64 *)d_v, (u64 *)d_out, (u64)batch, (u32)n, (u64)q, (u64)num, (u64)den);
+    LAUNCH_OK("zr_mul_div_round_kernel");
+    return FHE_OK;
+}
+
+// ---- BFV: RLWE::tensor / relinearize_204 / RLWE::mul ------------------------------------------
+// d_ab: [a0 | a1 | b0 | b1], each batch x n (mod q).  d_c: [c0 | c1 | c2], each batch x n.
+extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, void *d_c, size_t batch,
+                                  void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_bfv_tensor_dev");
+    if (rc != FHE_OK) return rc;
+    if (q < 2 || (q >> 63)) return fhe_fail(FHE_E_BAD_Q, "fhe_bfv_tensor_dev: q must be in [2, 2^63)");
+    if (batch == 0) return FHE_OK;
+    if (!d_ab || !d_c) return fhe_fail(FHE_E_NULL, "fhe_bfv_tensor_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_ab); REQUIRE_ALIGNED(d_c);
+    const u64 n2 = 2 * n;
+    ZCtx z;
+    // c1 = a0*b1 + a1*b0 < 2 * n * q^2
+    rc = zctx_init(&z, n2, primes_for_bits(2 * bits_of(q - 1) + ceil_log2(n) + 1, false));
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 words = batch * n2;   // per polynomial set
+    void *wsv = nullptr;
+    rc = fhe_workspace_get(1, (4 + 3 * (size_t)z.K + 3) * words * 8, &wsv);
+    if (rc != FHE_OK) return rc;
+    u64 *AB = (u64 *)wsv, *R = AB + 4 * words, *V = R + 3 * (u64)z.K * words;
+    for (int k = 0; k < z.K; k++) {
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(4 * words)), dim3(256), 0, st, (const u64 *)d_ab, AB, (u64)(4 * batch), (u32)n, (u32)n2, z.cc.m[k]);
+        LAUNCH_OK("zr_reduce_pad_kernel");
+        if ((rc = z_forward(z, k, AB, AB, 4 * batch, st)) != FHE_OK) return rc;
+        u64 *Rk = R + 3 * (u64)k * words;
+        hipLaunchKernelGGL(fhe::zr_tensor_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)AB, Rk, words, z.cc.m[k]);
+        LAUNCH_OK("zr_tensor_kernel");
+        if ((rc = z_inverse(z, k, Rk, Rk, 3 * batch, st)) != FHE_OK) return rc;
+    }
+    rc = z_crt(z, false, R, R + 3 * words, R + 6 * words, V, 3 * words, st);
+    if (rc != FHE_OK) return rc;
+    return fhe_mul_div_round_dev(q, n, V, t, q, d_c, 3 * batch, st);
+}
+
+// d_rlk: [rlk0 | rlk1], each n words mod pq (one key for the whole batch).
+// d_c: [c0 | c1 | c2] as produced by fhe_bfv_tensor_dev.  d_out: [o0 | o1], each batch x n.
+extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, const void *d_c,
+                                       void *d_out, size_t batch, void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_bfv_relinearize_dev");
+    if (rc != FHE_OK) return rc;
+    if (q < 2 || (q >> 63) || pq < q || (pq >> 63)) return fhe_fail(FHE_E_BAD_Q, "fhe_bfv_relinearize_dev: need 2 <= q <= pq < 2^63");
+    if (batch == 0) return FHE_OK;
+    if (!d_rlk || !d_c || !d_out) return fhe_fail(FHE_E_NULL, "fhe_bfv_relinearize_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_c); REQUIRE_ALIGNED(d_out);
+    const u64 n2 = 2 * n, p = pq / q;
+    ZCtx z;
+    rc = zctx_init(&z, n2, primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false));
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 words = batch * n2, bn = batch * n;
+    void *wsv = nullptr;
+    rc = fhe_workspace_get(1, (1 + 2 * (size_t)z.K + 2 + 1) * words * 8 + 2 * n2 * 8, &wsv);
+    if (rc != FHE_OK) return rc;
+    u64 *X = (u64 *)wsv, *R = X + words, *V = R + 2 * (u64)z.K * words, *Rr = V + 2 * words, *Y = Rr + words;
+    const u64 *c2 = (const u64 *)d_c + 2 * bn;
+    for (int k = 0; k < z.K; k++) {
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, c2, X, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(2 * n2)), dim3(256), 0, st, (const u64 *)d_rlk, Y, (u64)2, (u32)n, (u32)n2, z.cc.m[k]);
+        LAUNCH_OK("zr_reduce_pad_kernel");
+        if ((rc = z_forward(z, k, X, X, batch, st)) != FHE_OK) return rc;
+        if ((rc = z_forward(z, k, Y, Y, 2, st)) != FHE_OK) return rc;
+        u64 *Rk = R + 2 * (u64)k * words;
+        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, (const u64 *)Y, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
+        LAUNCH_OK("zr_mul_bcast_kernel");
+        if ((rc = z_inverse(z, k, Rk, Rk, 2 * batch, st)) != FHE_OK) return rc;
+    }
+    rc = z_crt(z, false, R, R + 2 * words, R + 4 * words, V, 2 * words, st);
+    if (rc != FHE_OK) return rc;
+    // r0, r1 = mul_div_round(.., 1, p); reuse Rr (2*bn <= words) for them
+    rc = fhe_mul_div_round_dev(q, n, V, 1, p, Rr, 2 * batch, st);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::zr_rq_add_kernel, dim3(ew_grid(2 * bn)), dim3(256), 0, st, (const u64 *)d_c, (const u64 *)Rr, (u64 *)d_out, 2 * bn, (u64)q);
+    LAUNCH_OK("zr_rq_add_kernel");
+    return FHE_OK;
+}
+
+extern "C" int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, const void *d_ab,
+                               void *d_out, size_t batch, void *hip_stream) {
+    if (batch == 0) return FHE_OK;
+    // the tensor result lives in its own allocation: both stages use the shared workspace
+    void *c = nullptr;
+    HIP_TRY(hipMallocAsync(&c, 3 * batch * n * 8, (hipStream_t)hip_stream));
+    int rc = fhe_bfv_tensor_dev(q, n, t, d_ab, c, batch, hip_stream);
+    if (rc == FHE_OK) rc = fhe_bfv_relinearize_dev(q, n, pq, d_rlk, c, d_out, batch, hip_stream);
+    (void)hipFreeAsync(c, (hipStream_t)hip_stream);
+    return rc;
+}
+
+// ---- TFHE: Tn x Tn -----------------------------------------------------------------------------
+extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void *d_out, size_t batch,
+                              void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_tn_mul_dev");
+    if (rc != FHE_OK) return rc;
+    if (batch == 0) return FHE_OK;
+    if (!d_a || !d_b || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tn_mul_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_b); REQUIRE_ALIGNED(d_out);
+    ZCtx z;
+    rc = zctx_init(&z, n, primes_for_bits(128 + ceil_log2(n), true));   // |c_k| < n * 2^128
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 words = batch * n;
+    void *wsv = nullptr;
+    rc = fhe_workspace_get(1, (2 + (size_t)z.K) * words * 8, &wsv);
+    if (rc != FHE_OK) return rc;
+    u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;
+    for (int k = 0; k < z.K; k++) {
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
+        LAUNCH_OK("zr_reduce_pad_kernel");
+        if ((rc = z_forward(z, k, A, A, batch, st)) != FHE_OK) return rc;
+        if ((rc = z_forward(z, k, B, B, batch, st)) != FHE_OK) return rc;
+        hipError_t e = fhe::launch_ntt_inverse(z.dp[k], A, B, nullptr, R + (u64)k * words, batch,
+                                               fhe_batch_tile_for(z.plan[k]), st);
+        if (e != hipSuccess) return fhe_hip_fail(e, "zring inverse(A.*B)");
+    }
+    return z_crt(z, true, R, R + words, R + 2 * words, (u64 *)d_out, words, st);
+}
+
+// ---- TFHE: TGGSW x TGLWE external product -------------------------------------------------------
+// d_tggsw [(k+1)][l][(k+1)][n], one key for the batch; d_tglwe [batch][(k+1)][n]; d_out likewise.
+extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw,
+                                              const void *d_tglwe, void *d_out, size_t batch, void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_tggsw_external_product_dev");
+    if (rc != FHE_OK) return rc;
+    if (l < 1 || l > 64 || k < 1 || k > 64) return fhe_fail(FHE_E_INVALID, "external product: need 1 <= l <= 64, 1 <= k <= 64");
+    if (batch == 0) return FHE_OK;
+    if (!d_tggsw || !d_tglwe || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tggsw_external_product_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_tggsw); REQUIRE_ALIGNED(d_tglwe); REQUIRE_ALIGNED(d_out);
+    const u32 k1 = k + 1;
+    ZCtx z;
+    // digits are 0/1: |sum| < (k+1) * l * n * 2^64
+    rc = zctx_init(&z, n, primes_for_bits(64 + ceil_log2(n) + ceil_log2((u64)k1 * l), true));
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 grows = (u64)k1 * l * k1, drows = batch * k1 * l, orows = batch * k1;
+    void *wsv = nullptr;
+    rc = fhe_workspace_get(1, (grows + 2 * drows + (size_t)z.K * orows) * n * 8, &wsv);
+    if (rc != FHE_OK) return rc;
+    u64 *G = (u64 *)wsv, *Dg = G + grows * n, *D = Dg + drows * n, *R = D + drows * n;
+    hipLaunchKernelGGL(fhe::zr_digits_kernel, dim3(ew_grid(drows * n)), dim3(256), 0, st, (const u64 *)d_tglwe, Dg, (u64)orows, (u32)n, (u32)l);
+    LAUNCH_OK("zr_digits_kernel");
+    for (int kk = 0; kk < z.K; kk++) {
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G, grows, (u32)n, (u32)n, z.cc.m[kk]);
+        LAUNCH_OK("zr_reduce_pad_kernel");
+        if ((rc = z_forward(z, kk, G, G, grows, st)) != FHE_OK) return rc;
+        if ((rc = z_forward(z, kk, Dg, D, drows, st)) != FHE_OK) return rc;   // digits are < every prime
+        u64 *Rk = R + (u64)kk * orows * n;
+        hipLaunchKernelGGL(fhe::zr_extprod_mac_kernel, dim3(ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)G, (const u64 *)D, Rk, (u64)batch, (u32)n, k1, (u32)l, z.cc.m[kk]);
+        LAUNCH_OK("zr_extprod_mac_kernel");
+        if ((rc = z_inverse(z, kk, Rk, Rk, orows, st)) != FHE_OK) return rc;
+    }
+    return z_crt(z, true, R, R + orows * n, R + 2 * orows * n, (u64 *)d_out, orows * n, st);
+}
+
+// ---- host-buffer wrappers (what a Rust shim binds) ------------------------------------------------
+namespace {
+struct HostStage {
+    std::vector<void *> bufs;
+    ~HostStage() { for (void *p : bufs) if (p) (void)hipFree(p); }
+    int up(const void *h, size_t bytes, void **d) {
+        *d = nullptr;
+        hipError_t e = hipMalloc(d, bytes ? bytes : 16);
+        if (e != hipSuccess) return fhe_hip_fail(e, "hipMalloc");
+        bufs.push_back(*d);
+        if (h && bytes) {
+            e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, hipStreamPerThread);
+            if (e != hipSuccess) return fhe_hip_fail(e, "hipMemcpyAsync H2D");
+        }
+        return FHE_OK;
+    }
+};
+int down(void *h, const void *d, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, hipStreamPerThread));
+    HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+    return FHE_OK;
+}
+}  // namespace
+
+extern "C" int fhe_bfv_mul(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const uint64_t *rlk, const uint64_t *ab,
+                           uint64_t *out, size_t batch) {
+    if (batch == 0) return FHE_OK;
+    if (!rlk || !ab || !out) return fhe_fail(FHE_E_NULL, "fhe_bfv_mul: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    HostStage hs;
+    void *drlk, *dab, *dout;
+    if ((rc = hs.up(rlk, 2 * n * 8, &drlk)) != FHE_OK) return rc;
+    if ((rc = hs.up(ab, 4 * batch * n * 8, &dab)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, 2 * batch * n * 8, &dout)) != FHE_OK) return rc;
+    rc = fhe_bfv_mul_dev(q, n, t, pq, drlk, dab, dout, batch, hipStreamPerThread);
+    if (rc != FHE_OK) return rc;
+    return down(out, dout, 2 * batch * n * 8);
+}
+
+extern "C" int fhe_bfv_tensor(uint64_t q, uint64_t n, uint64_t t, const uint64_t *ab, uint64_t *c, size_t batch) {
+    if (batch == 0) return FHE_OK;
+    if (!ab || !c) return fhe_fail(FHE_E_NULL, "fhe_bfv_tensor: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    HostStage hs;
+    void *dab, *dc;
+    if ((rc = hs.up(ab, 4 * batch * n * 8, &dab)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, 3 * batch * n * 8, &dc)) != FHE_OK) return rc;
+    rc = fhe_bfv_tensor_dev(q, n, t, dab, dc, batch, hipStreamPerThread);
+    if (rc != FHE_OK) return rc;
+    return down(c, dc, 3 * batch * n * 8);
+}
+
+extern "C" int fhe_r_naive_mul(uint64_t n, const int64_t *a, const int64_t *b, int64_t *out, size_t batch) {
+    if (batch == 0) return FHE_OK;
+    if (!a || !b || !out) return fhe_fail(FHE_E_NULL, "fhe_r_naive_mul: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    HostStage hs;
+    void *da, *db, *dout;
+    if ((rc = hs.up(a, batch * n * 8, &da)) != FHE_OK) return rc;
+    if ((rc = hs.up(b, batch * n * 8, &db)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, 2 * batch * n * 8, &dout)) != FHE_OK) return rc;
+    // operands are read as NON-NEGATIVE 64-bit integers (Rq::to_r gives values in [0,q), ring_n.rs:72-79)
+    rc = fhe_r_naive_mul_dev(n, da, db, dout, batch, 64, 64, hipStreamPerThread);
+    if (rc != FHE_OK) return rc;
+    return down(out, dout, 2 * batch * n * 8);
+}
+
+extern "C" int fhe_tn_mul(uint64_t n, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t batch) {
+    if (batch == 0) return FHE_OK;
+    if (!a || !b || !out) return fhe_fail(FHE_E_NULL, "fhe_tn_mul: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    HostStage hs;
+    void *da, *db, *dout;
+    if ((rc = hs.up(a, batch * n * 8, &da)) != FHE_OK) return rc;
+    if ((rc = hs.up(b, batch * n * 8, &db)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * n * 8, &dout)) != FHE_OK) return rc;
+    rc = fhe_tn_mul_dev(n, da, db, dout, batch, hipStreamPerThread);
+    if (rc != FHE_OK) return rc;
+    return down(out, dout, batch * n * 8);
+}
+
+extern "C" int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, const uint64_t *tggsw,
+                                          const uint64_t *tglwe, uint64_t *out, size_t batch) {
+    if (batch == 0) return FHE_OK;
+    if (!tggsw || !tglwe || !out) return fhe_fail(FHE_E_NULL, "fhe_tggsw_external_product: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    HostStage hs;
+    void *dg, *dt, *dout;
+    const size_t k1 = k + 1;
+    if ((rc = hs.up(tggsw, k1 * l * k1 * n * 8, &dg)) != FHE_OK) return rc;
+    if ((rc = hs.up(tglwe, batch * k1 * n * 8, &dt)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * k1 * n * 8, &dout)) != FHE_OK) return rc;
+    rc = fhe_tggsw_external_product_dev(n, k, l, dg, dt, dout, batch, hipStreamPerThread);
+    if (rc != FHE_OK) return rc;
+    return down(out, dout, batch * k1 * n * 8);
+}

@@ -138,6 +138,63 @@ int fhe_ntt_kernel_timing_enable(int on);
 int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_t *launches, int cap);
 int fhe_ntt_kernel_timing_reset(void);
 
+/* ======================================================================== *
+ * Next rows: the reference's SCHOOLBOOK callers either side
+ * of the NTT path, rebuilt on the engine.  Products over Z are exact (K <= 3
+ * CRT primes of 61 bits, chosen from the operand sizes) and only then reduced
+ * mod 2^64, which is what the reference's `as i64` / `as u64` truncation keeps.
+ * ======================================================================== */
+
+/* arith::ring_n::naive_mul, arith/src/ring_n.rs:307-320: linear convolution of
+ * two length-n coefficient vectors over Z, truncated `as i64`.  Operands are read
+ * as NON-NEGATIVE 64-bit integers (Rq::to_r yields [0,q), ring_n.rs:72-79).
+ * out: batch x 2n words (the 2n-1 results, then one 0).  a_bits/b_bits: bound on
+ * the operands' bit length (0 = 64), used to pick the number of primes. */
+int fhe_r_naive_mul(uint64_t n, const int64_t *a, const int64_t *b, int64_t *out, size_t batch);
+int fhe_r_naive_mul_dev(uint64_t n, const void *d_a, const void *d_b, void *d_out, size_t batch,
+                        unsigned a_bits, unsigned b_bits, void *hip_stream);
+
+/* arith::ring_n::mul_div_round(q, n, v, num, den) -> Rq, arith/src/ring_n.rs:130-138:
+ * z[i] = Zq::from_f64(((num as f64 * v[i] as f64) / den as f64).round())  (zq.rs:32-39),
+ * then the X^n+1 fold of ring_nq.rs:132-141.  d_v: batch x 2n words read as i64
+ * (layout of fhe_r_naive_mul_dev); d_out: batch x n words mod q.  IEEE f64, one
+ * rounding per operation, round half away from zero — as the Rust. */
+int fhe_mul_div_round_dev(uint64_t q, uint64_t n, const void *d_v, uint64_t num, uint64_t den,
+                          void *d_out, size_t batch, void *hip_stream);
+
+/* RLWE::tensor(t, a, b) -> (c0, c1, c2), bfv/src/lib.rs:59-85.
+ * ab = [a0 | a1 | b0 | b1], each batch x n words mod q; c = [c0 | c1 | c2]. */
+int fhe_bfv_tensor(uint64_t q, uint64_t n, uint64_t t, const uint64_t *ab, uint64_t *c, size_t batch);
+int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, void *d_c, size_t batch,
+                       void *hip_stream);
+/* BFV::relinearize_204(rlk, c0, c1, c2) -> (c0 + r0, c1 + r1), bfv/src/lib.rs:251-271.
+ * rlk = [rlk0 | rlk1], n words each mod pq (one key for the whole batch), p = pq / q;
+ * c as produced by fhe_bfv_tensor_dev; out = [o0 | o1], each batch x n. */
+int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, const void *d_c,
+                            void *d_out, size_t batch, void *hip_stream);
+/* RLWE::mul(t, rlk, a, b) = relinearize_204(tensor(..)), bfv/src/lib.rs:87-90. */
+int fhe_bfv_mul(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const uint64_t *rlk, const uint64_t *ab,
+                uint64_t *out, size_t batch);
+int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, const void *d_ab,
+                    void *d_out, size_t batch, void *hip_stream);
+
+/* Tn x Tn, arith/src/ring_torus.rs:251-298 (naive_poly_mul): negacyclic product of
+ * coefficient vectors mod 2^64. */
+int fhe_tn_mul(uint64_t n, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t batch);
+int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void *d_out, size_t batch,
+                   void *hip_stream);
+
+/* TGGSW x TGLWE external product, tfhe/src/tggsw.rs:45-62 with TGLev x Vec<Tn> (:139-149),
+ * TGLWE x Tn (tglwe.rs:182-194) and Tn::decompose(beta = 2, l) (ring_torus.rs:67-77,
+ * torus.rs:43-52; the reference hard-codes l = 64).
+ *   tggsw [(k+1)][l][(k+1)][n]   TGLev i (i < k: the `a` rows; i = k: the `b` row), level d,
+ *                                component c (c < k: mask a_c; c = k: body)   — one key
+ *   tglwe [batch][(k+1)][n]      (a_0 .. a_{k-1}, b) per ciphertext;  out likewise. */
+int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, const uint64_t *tggsw,
+                               const uint64_t *tglwe, uint64_t *out, size_t batch);
+int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw,
+                                   const void *d_tglwe, void *d_out, size_t batch, void *hip_stream);
+
 /* ---- misc ---------------------------------------------------------------- */
 int fhe_ntt_device_count(void);            /* HIP devices visible (0 if none) */
 const char *fhe_last_error(void);          /* thread-local, never NULL */

@@ -69,6 +69,27 @@ class Oracle:
                                                ctypes.c_int]
         L.oracle_fill_synthetic.restype = None
         L.oracle_fill_synthetic.argtypes = [_u64, _u64, _u64, _u64, _p64]
+        _i64p = ctypes.POINTER(ctypes.c_int64)
+        L.oracle_r_naive_mul.restype = None
+        L.oracle_r_naive_mul.argtypes = [_u64, _i64p, _i64p, _i64p]
+        L.oracle_r_modulus.restype = None
+        L.oracle_r_modulus.argtypes = [_u64, _i64p, _u64, _i64p]
+        L.oracle_mul_div_round.restype = None
+        L.oracle_mul_div_round.argtypes = [_u64, _u64, _i64p, _u64, _u64, _u64, _p64]
+        L.oracle_zq_from_f64.restype = _u64
+        L.oracle_zq_from_f64.argtypes = [_u64, ctypes.c_double]
+        L.oracle_bfv_tensor.restype = None
+        L.oracle_bfv_tensor.argtypes = [_u64, _u64, _u64] + [_p64] * 7
+        L.oracle_bfv_relinearize_204.restype = None
+        L.oracle_bfv_relinearize_204.argtypes = [_u64, _u64, _u64] + [_p64] * 7
+        L.oracle_bfv_mul.restype = None
+        L.oracle_bfv_mul.argtypes = [_u64, _u64, _u64, _u64] + [_p64] * 8
+        L.oracle_tn_mul.restype = None
+        L.oracle_tn_mul.argtypes = [_u64, _p64, _p64, _p64]
+        L.oracle_tn_decompose.restype = None
+        L.oracle_tn_decompose.argtypes = [_u64, ctypes.c_uint32, _p64, _p64]
+        L.oracle_external_product.restype = None
+        L.oracle_external_product.argtypes = [_u64, ctypes.c_uint32, ctypes.c_uint32, _p64, _p64, _p64]
         self._tables = {}
 
     # -- tables ---------------------------------------------------------------
@@ -152,6 +173,67 @@ class Oracle:
         out = np.empty(count, dtype=np.uint64)
         self.lib.oracle_fill_synthetic(q, seed, first_index, count, _ptr(out))
         return out
+
+    # -- next rows (oracle/fhe_next_oracle.c) -----------------------------------
+    def r_naive_mul(self, n, a, b):
+        a = np.ascontiguousarray(a, dtype=np.int64).reshape(-1, n)
+        b = np.ascontiguousarray(b, dtype=np.int64).reshape(-1, n)
+        out = np.empty((a.shape[0], 2 * n - 1), dtype=np.int64)
+        i64 = ctypes.POINTER(ctypes.c_int64)
+        for i in range(a.shape[0]):
+            self.lib.oracle_r_naive_mul(n, a[i].ctypes.data_as(i64), b[i].ctypes.data_as(i64),
+                                        out[i].ctypes.data_as(i64))
+        return out
+
+    def r_modulus(self, n, p):
+        p = np.ascontiguousarray(p, dtype=np.int64)
+        out = np.empty(n, dtype=np.int64)
+        i64 = ctypes.POINTER(ctypes.c_int64)
+        self.lib.oracle_r_modulus(n, p.ctypes.data_as(i64), p.size, out.ctypes.data_as(i64))
+        return out
+
+    def mul_div_round(self, q, n, v, num, den):
+        v = np.ascontiguousarray(v, dtype=np.int64).reshape(-1, 2 * n - 1)
+        out = np.empty((v.shape[0], n), dtype=np.uint64)
+        i64 = ctypes.POINTER(ctypes.c_int64)
+        for i in range(v.shape[0]):
+            self.lib.oracle_mul_div_round(q, n, v[i].ctypes.data_as(i64), 2 * n - 1, num, den, _ptr(out[i]))
+        return out
+
+    def bfv_tensor(self, q, n, t, a0, a1, b0, b1):
+        A = [_arr(x).reshape(-1, n) for x in (a0, a1, b0, b1)]
+        batch = A[0].shape[0]
+        c = np.empty((3, batch, n), dtype=np.uint64)
+        for i in range(batch):
+            self.lib.oracle_bfv_tensor(q, n, t, _ptr(A[0][i]), _ptr(A[1][i]), _ptr(A[2][i]), _ptr(A[3][i]),
+                                       _ptr(c[0][i]), _ptr(c[1][i]), _ptr(c[2][i]))
+        return c[0], c[1], c[2]
+
+    def bfv_mul(self, q, n, t, pq, rlk0, rlk1, a0, a1, b0, b1):
+        A = [_arr(x).reshape(-1, n) for x in (a0, a1, b0, b1)]
+        r0, r1 = _arr(rlk0), _arr(rlk1)
+        batch = A[0].shape[0]
+        o = np.empty((2, batch, n), dtype=np.uint64)
+        for i in range(batch):
+            self.lib.oracle_bfv_mul(q, n, t, pq, _ptr(r0), _ptr(r1), _ptr(A[0][i]), _ptr(A[1][i]),
+                                    _ptr(A[2][i]), _ptr(A[3][i]), _ptr(o[0][i]), _ptr(o[1][i]))
+        return o[0], o[1]
+
+    def tn_mul(self, n, a, b):
+        a = _arr(a).reshape(-1, n)
+        b = _arr(b).reshape(-1, n)
+        out = np.empty_like(a)
+        for i in range(a.shape[0]):
+            self.lib.oracle_tn_mul(n, _ptr(a[i]), _ptr(b[i]), _ptr(out[i]))
+        return out
+
+    def external_product(self, n, k, l, tggsw, tglwe):
+        g = _arr(tggsw)
+        t = _arr(tglwe).reshape(-1, (k + 1) * n)
+        out = np.empty_like(t)
+        for i in range(t.shape[0]):
+            self.lib.oracle_external_product(n, k, l, _ptr(g), _ptr(t[i]), _ptr(out[i]))
+        return out.reshape(-1, k + 1, n)
 
     def exp_mod(self, q, x, k):
         return int(self.lib.oracle_exp_mod(q, x, k))

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""tools/bench_next.py — throughput of the next-row paths (BASELINE.json configs[2], configs[3])
+on one GPU, with the oracle's schoolbook timed beside them.  Diagnostic (the contract bench is
+bench.py); numbers are quoted in DESIGN.md."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import fhe_study_amd as pkg
+from oracle import load_oracle
+
+B, L, O = pkg.binding, pkg.load_library(), load_oracle()
+st = torch.cuda.current_stream().cuda_stream
+dev = "cuda:0"
+U64 = 1 << 64
+
+
+def timeit(f, reps=5):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def bfv(n=8192, q=65537, t=2, batch=256):
+    pq = q * q * q
+    rng = np.random.default_rng(1)
+    ab = torch.from_numpy(rng.integers(0, q, (4, batch, n), dtype=np.int64)).to(dev)
+    rlk = torch.from_numpy(rng.integers(0, pq, (2, n), dtype=np.int64)).to(dev)
+    out = torch.empty((2, batch, n), dtype=torch.int64, device=dev)
+    f = lambda: B._check(L.fhe_bfv_mul_dev(q, n, t, pq, rlk.data_ptr(), ab.data_ptr(), out.data_ptr(), batch, st))
+    dt = timeit(f)
+    a = ab.cpu().numpy().view(np.uint64); r = rlk.cpu().numpy().view(np.uint64)
+    t0 = time.perf_counter()
+    w0, w1 = O.bfv_mul(q, n, t, pq, r[0], r[1], a[0, :1], a[1, :1], a[2, :1], a[3, :1])
+    cpu = time.perf_counter() - t0
+    ok = np.array_equal(out[0, 0].cpu().numpy().view(np.uint64), w0[0])
+    print(f"BFV ct x ct mul + relin  N={n} q={q} p=q^2  batch={batch}: {dt*1e3:.2f} ms  "
+          f"{batch/dt:,.0f} ct-mul/s   (oracle schoolbook, 1 core: {1/cpu:.2f} ct-mul/s)  parity={ok}")
+
+
+def extprod(n=1024, k=1, l=64, batch=630):
+    rng = np.random.default_rng(2)
+    g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).to(dev)
+    c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (batch, k + 1, n), dtype=np.int64)).to(dev)
+    out = torch.empty_like(c)
+    f = lambda: B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), out.data_ptr(), batch, st))
+    dt = timeit(f)
+    t0 = time.perf_counter()
+    w = O.external_product(n, k, l, g.cpu().numpy().view(np.uint64), c[:1].cpu().numpy().view(np.uint64))
+    cpu = time.perf_counter() - t0
+    ok = np.array_equal(out[0].cpu().numpy().view(np.uint64), w[0])
+    print(f"TGGSW x TGLWE external product  N={n} k={k} l={l}  batch={batch}: {dt*1e3:.2f} ms  "
+          f"{batch/dt:,.0f} products/s   (oracle schoolbook, 1 core: {1/cpu:.2f}/s)  parity={ok}")
+
+
+if __name__ == "__main__":
+    bfv()
+    extprod()
+    B.kernel_timing_reset(); B.kernel_timing_enable(True)
+    extprod(batch=630)
+    print({k: (round(v[0], 3), v[1]) for k, v in B.kernel_timing_read().items()})

@@ -18,7 +18,8 @@
 // (multiply AND 64-bit accumulate in one issue slot), 64-bit adds are
 // v_lshl_add_u64, subtraction of a value is "+ ~v + 1" with the +1 folded into a
 // constant, and subtraction of a constant is the addition of its negation.
-// Compiler-only code: 105 cycles/butterfly; this form: 81 (q < 2^61) / 89.
+// Compiler-only code: 105 cycles/butterfly-wave (at the nominal 2.4 GHz; the chip holds
+// ~1.8 GHz under this load); this form: 77 (q < 2^61) / ~86.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -51,6 +52,18 @@ __device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) {  // a*b + c  (mod 2^
     asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
     return d;
 }
+__device__ __forceinline__ u64 mad64z(u32 a, u32 b) {  // a*b (inline-constant addend: no zero pair)
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+}
+// opaque 32-bit add: written in C the compiler widens `hi += x` into a 64-bit add of {0,x},
+// i.e. two v_mov and a v_lshl_add_u64 instead of one v_add_u32 (tools/ubench_bfly.hip v6: -4 %)
+__device__ __forceinline__ u32 add32(u32 a, u32 b) {
+    u32 d;
+    asm("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ u64 add64(u64 a, u64 b) {  // a + b in one issue slot
     u64 d;
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -66,7 +79,7 @@ __device__ __forceinline__ u64 dbl_add64(u64 a, u64 b) {  // 2a + b
 // one 64-bit add, then the sign of the difference selects.
 __device__ __forceinline__ u64 csub_neg(u64 x, u64 negm) {
     const u64 d = add64(x, negm);
-    return ((long long)d < 0) ? x : d;
+    return ((int)(u32)(d >> 32) < 0) ? x : d;   // sign of the high word: a 32-bit compare
 }
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
 
@@ -79,11 +92,11 @@ __device__ __forceinline__ u64 mul_shoup_acc(u64 add, u64 y, u64 w, u64 wp, u64 
     const u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
     u64 acc = mad64(y0, w0, add);
     acc = mad64(h0, n0, acc);
-    u64 H = mad64(y0, w1, 0);
+    u64 H = mad64z(y0, w1);
     H = mad64(y1, w0, H);
     H = mad64(h0, n1, H);
     H = mad64(h1, n0, H);
-    const u32 hi = (u32)(acc >> 32) + (u32)H;
+    const u32 hi = add32((u32)(acc >> 32), (u32)H);
     return ((u64)hi << 32) | (u32)acc;
 }
 // y * w mod q  in [0, 2q)

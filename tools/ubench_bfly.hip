@@ -82,6 +82,55 @@ __device__ __forceinline__ void bf_v4(u64& x, u64& y, u64 w, u64 wp, const Q& c,
   x = s;
 }
 
+// ---- variant 5: v3 with the three sources of v_mov removed -------------------------------
+__device__ __forceinline__ u64 mad64z(u32 a, u32 b) {  // a*b
+  u64 d; asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc"); return d;
+}
+__device__ __forceinline__ u32 add32(u32 a, u32 b) { u32 d; asm("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u32 mulhi32(u32 a, u32 b) { u32 d; asm("v_mul_hi_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+// exact mulhi64 with carries in 32-bit adds instead of zero-extended 64-bit operands
+__device__ __forceinline__ u64 mulhi64_v5(u64 y, u64 p) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), p0 = (u32)p, p1 = (u32)(p >> 32);
+  const u32 t = mulhi32(y0, p0);
+  const u64 A = mad64(y1, p0, (u64)t);      // y1*p0 + hi(y0*p0): no overflow
+  const u64 B = mad64z(y0, p1);
+  u32 s, u, c2;
+  asm("v_add_co_u32 %0, vcc, %3, %4\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %5, %6, vcc\n\ts_nop 1\n\tv_addc_co_u32 %2, vcc, 0, 0, vcc"
+      : "=&v"(s), "=&v"(u), "=v"(c2)
+      : "v"((u32)A), "v"((u32)B), "v"((u32)(A >> 32)), "v"((u32)(B >> 32)) : "vcc");
+  (void)s;
+  return mad64(y1, p1, pack(u, c2));
+}
+__device__ __forceinline__ u64 chain_s5(u64 u, u64 y, u64 w, u64 qh, const Q& c) {
+  u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+  u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)c.nq, n1 = (u32)(c.nq >> 32);
+  u64 acc = mad64(y0, w0, u);
+  acc = mad64(h0, n0, acc);
+  u64 H = mad64z(y0, w1);
+  H = mad64(y1, w0, H);
+  H = mad64(h0, n1, H);
+  H = mad64(h1, n0, H);
+  return pack((u32)acc, add32((u32)(acc >> 32), (u32)H));
+}
+__device__ __forceinline__ void bf_v5(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) { u64 d = add64(x, c.neg4q); u = ((int)(u32)(d >> 32) < 0) ? x : d; }
+  u64 qh = mulhi64_v5(y, wp);
+  u64 s = chain_s5(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+// variant 6: v5's chain with the compiler's __umul64hi (isolates the mulhi rewrite)
+__device__ __forceinline__ void bf_v6(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) { u64 d = add64(x, c.neg4q); u = ((int)(u32)(d >> 32) < 0) ? x : d; }
+  u64 qh = __umul64hi(y, wp);
+  u64 s = chain_s5(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+
 template <int V>
 __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
   u64 x[4], y[4];
@@ -95,13 +144,17 @@ __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
       if (V == 2) bf_v2(x[j], y[j], w, wp, c);
       if (V == 3) { bf_v3(x[j], y[j], w, wp, c, false); }
       if (V == 4) { bf_v4(x[j], y[j], w, wp, c, false); }
+      if (V == 5) { bf_v5(x[j], y[j], w, wp, c, false); }
+      if (V == 6) { bf_v6(x[j], y[j], w, wp, c, false); }
     }
-    if (V == 3 || V == 4) {  // second stage of the pair carries the csub
+    if (V >= 3) {  // second stage of the pair carries the csub
       i++;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (V == 3) bf_v3(x[j], y[j], w, wp, c, true);
         if (V == 4) bf_v4(x[j], y[j], w, wp, c, true);
+        if (V == 5) bf_v5(x[j], y[j], w, wp, c, true);
+        if (V == 6) bf_v6(x[j], y[j], w, wp, c, true);
       }
     }
   }
@@ -127,13 +180,13 @@ int main() {
   u64* p; hipMalloc(&p, 4096 * 8);
   std::vector<u64> h(512), o(512);
   for (int i = 0; i < 512; i++) h[i] = (0x9E3779B97F4A7C15ull * (i + 1)) ^ (0xD1B54A32D192ED03ull * (i + 7));
-  const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo"};
-  for (int v = 0; v < 5; v++) {
+  const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo", "v5 no-mov mulhi+pack", "v6 no-mov pack only"};
+  for (int v = 0; v < 7; v++) {
     // correctness at 6 iterations (even, so v3/v4 pairs are whole)
     hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
     int it = 6;
     switch (v) { case 0: k<0><<<1, 64>>>(p, c, w, wp, it); break; case 1: k<1><<<1, 64>>>(p, c, w, wp, it); break;
-      case 2: k<2><<<1, 64>>>(p, c, w, wp, it); break; case 3: k<3><<<1, 64>>>(p, c, w, wp, it); break; case 4: k<4><<<1, 64>>>(p, c, w, wp, it); break; }
+      case 2: k<2><<<1, 64>>>(p, c, w, wp, it); break; case 3: k<3><<<1, 64>>>(p, c, w, wp, it); break; case 4: k<4><<<1, 64>>>(p, c, w, wp, it); break; case 5: k<5><<<1, 64>>>(p, c, w, wp, it); break; case 6: k<6><<<1, 64>>>(p, c, w, wp, it); break; }
     hipMemcpy(o.data(), p, 512 * 8, hipMemcpyDeviceToHost);
     int bad = 0; u64 mx = 0;
     for (int t = 0; t < 64; t++) for (int j = 0; j < 4; j++) {
@@ -150,7 +203,7 @@ int main() {
       for (int r = 0; r < 4; r++) {
         hipEventRecord(e0);
         switch (v) { case 0: k<0><<<blocks, threads>>>(p, c, w, wp, iters); break; case 1: k<1><<<blocks, threads>>>(p, c, w, wp, iters); break;
-          case 2: k<2><<<blocks, threads>>>(p, c, w, wp, iters); break; case 3: k<3><<<blocks, threads>>>(p, c, w, wp, iters); break; case 4: k<4><<<blocks, threads>>>(p, c, w, wp, iters); break; }
+          case 2: k<2><<<blocks, threads>>>(p, c, w, wp, iters); break; case 3: k<3><<<blocks, threads>>>(p, c, w, wp, iters); break; case 4: k<4><<<blocks, threads>>>(p, c, w, wp, iters); break; case 5: k<5><<<blocks, threads>>>(p, c, w, wp, iters); break; case 6: k<6><<<blocks, threads>>>(p, c, w, wp, iters); break; }
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
       }

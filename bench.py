@@ -28,6 +28,10 @@ if ROOT not in sys.path:
 
 Q61 = 2305843009211596801
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM traffic per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+# WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
+# prescribes for gfx950).  Counters cannot be read from inside this process.
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -163,9 +167,19 @@ def main():
             # each pass kernel reads and writes every coefficient of its polynomials once
             bytes_per_launch = alg_bytes_per_ntt * polys_per_launch
             achieved = bytes_per_launch / (kernels[dom]["avg_us"] * 1e-6) / 1e9
+            traffic, traffic_src = None, None
+            try:
+                with open(PMC_TRAFFIC_FILE) as f:
+                    pmc = json.load(f)
+                per_poly = pmc["kernels"][dom]["hbm_bytes_per_polynomial"]
+                traffic = per_poly * polys_per_launch
+                traffic_src = pmc["source"]
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_us": kernels[dom]["avg_us"], "polys_per_launch": polys_per_launch,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 # the whole transform (all its kernels): 16*N bytes per NTT over the timed region

@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--allgather", action="store_true",
                     help="also time an RCCL all-gather of a result slab (reported separately)")
     return ap.parse_args()
@@ -89,6 +93,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -98,7 +104,11 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective tensors live
 
     import fhe_study_amd as pkg  # after torch: both then share one libamdhip64
 
@@ -137,7 +147,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -221,7 +231,7 @@ def main():
             print(json.dumps(out))
             raise SystemExit(f"PARITY FAILURE: {bad} of {len(rows)} rows differ from the oracle")
 
-    if args.allgather and dist is not None:
+    if args.allgather and dist is not None and args.backend == "nccl":
         # optional: the one collective of SURVEY.md §8e, timed on its own (not part of `value`)
         slab = min(batch, 1024) * n
         gathered = torch.empty(world * slab, dtype=torch.int64, device=dev)

@@ -215,7 +215,7 @@ static size_t g_batch_tile_override = 0;
 // 16384 polynomials): 128-polynomial tiles (64 MiB, Infinity-Cache sized) 9.9 ms, 2048 8.5 ms,
 // untiled 8.3 ms — the cache buys ~13 % on a pure copy (tools/ubench_mall.hip) but short
 // launches lose more in ramp-up and tail than that.
-static constexpr u64 kMaxTilePolys = 1ull << 24;
+static constexpr u64 kMaxTilePolys = 1ull << 22;  // keeps every grid below 2^31 workgroups up to n = 2^20
 
 u64 fhe_batch_tile_for(const fhe_ntt_plan *plan) {
     size_t ov;

@@ -152,14 +152,18 @@ struct ContigCfg {
     static constexpr int NR = (LP + 3) / 4;
     static constexpr int R0 = LP - 4 * (NR - 1);
     static constexpr int A0 = LP - 4;  // register window of round 0 = top 4 field bits
-    // a pass whose twiddle table is small is staged into LDS once per workgroup (all W units
-    // share `blk`): 30 ds_read_b128 per thread instead of 30 global loads through L1
-    static constexpr bool LDS_TW = LP <= 9;
+    // The first 2^LTW_LOG entries of the pass-local twiddle table (all W units share `blk`) are
+    // staged into LDS once per workgroup: a round whose stages all lie below local stage
+    // LTW_LOG reads them with ds_read_b128 instead of 15 global loads through L1.  Later rounds
+    // (LP > 8: per-thread-unique twiddles, up to 64 KiB per block) stay on the global table.
+    static constexpr int LTW_LOG = LP < 8 ? LP : 8;
+    static constexpr int LTW_N = 1 << LTW_LOG;
     static constexpr size_t DATA_BYTES = (size_t)(TILE + TILE / 16) * 8;
-    static constexpr size_t LDS_BYTES = DATA_BYTES + (LDS_TW ? (size_t)M * sizeof(Tw) : 0);
+    static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)LTW_N * sizeof(Tw);
     // window base of round j >= 1
     static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
     static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
+    static constexpr bool in_lds(int j) { return ls0_of(j) + (j == 0 ? R0 : 4) <= LTW_LOG; }
 };
 
 // scatter registers (window AF) -> barrier -> gather registers (window AT).
@@ -192,10 +196,10 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     const u64 base = poly * n + (u64)blk * C::M;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
-    const Tw *tw = C::LDS_TW ? ltw : a.tw;
-    // twiddle index of (local stage ls0, high field bits H): pass-local in LDS, global otherwise
-    auto T0 = [&](int ls, u32 H) -> u32 {
-        return C::LDS_TW ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    // twiddle source and index of round j (local stage ls0, high field bits H)
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : a.tw; };
+    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
+        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
     };
 
     u64 v[16];
@@ -204,23 +208,26 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     // Round 0's twiddles are the same for the whole workgroup (H = 0): read from the global
     // table at a wave-uniform address (scalar loads, SGPR operands).  The LDS copy is only
     // needed from round 1 on, so the barrier of the first exchange also publishes it.
-    if constexpr (C::LDS_TW) stage_twiddles<C::M, C::TH>(ltw, a.tw, s0, blk, tid);
+    stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, s0, blk, tid);
 
     round_fwd<C::R0, WIDE>(v, a.tw, (1u << s0) + blk, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        constexpr bool L = C::in_lds(1);
         exchange_contig<LP, C::A0, A, true>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, tw, T0(LS, tf >> A), m);
+        round_fwd<4, WIDE>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        constexpr bool L = C::in_lds(2);
         exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, tw, T0(LS, tf >> A), m);
+        round_fwd<4, WIDE>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        constexpr bool L = C::in_lds(3);
         exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, tw, T0(LS, tf >> A), m);
+        round_fwd<4, WIDE>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     // transpose through LDS so the store is one contiguous slab per wave.  (Storing the 128
     // contiguous bytes a thread owns after the last round as 8 x 16 B straight from registers
@@ -260,11 +267,11 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     const u64 base = poly * n + (u64)blk * C::M;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
-    const Tw *tw = C::LDS_TW ? ltw : a.tw;
-    auto T0 = [&](int ls, u32 H) -> u32 {
-        return C::LDS_TW ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : a.tw; };
+    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
+        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
     };
-    if constexpr (C::LDS_TW) stage_twiddles<C::M, C::TH>(ltw, a.tw, s0, blk, tid);  // barrier below
+    stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, s0, blk, tid);  // published by the barrier below
 
     // first window = field bits [0,4): a thread's 16 coefficients are 128 contiguous bytes,
     // fetched as 8 x 16 B straight into registers (no staging through LDS)
@@ -298,24 +305,27 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
         }
     }
 
-    if constexpr (C::LDS_TW) __syncthreads();
+    __syncthreads();
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
-        round_inv<4, false>(v, tw, T0(LS, tf >> A), m, a.ninv, a.s_ninv);
+        constexpr bool L = C::in_lds(3);
+        round_inv<4, false>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::a_of(2), true>(v, lds, w, tf);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv<4, false>(v, tw, T0(LS, tf >> A), m, a.ninv, a.s_ninv);
+        constexpr bool L = C::in_lds(2);
+        round_inv<4, false>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::a_of(1), (C::NR <= 3)>(v, lds, w, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv<4, false>(v, tw, T0(LS, tf >> A), m, a.ninv, a.s_ninv);
+        constexpr bool L = C::in_lds(1);
+        round_inv<4, false>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::A0, (C::NR <= 2)>(v, lds, w, tf);
     }
     // FINAL implies s0 == 0 (this pass holds the m = 1 stage)
-    round_inv<C::R0, FINAL>(v, tw, T0(0, 0), m, a.ninv, a.s_ninv);
+    round_inv<C::R0, FINAL>(v, TW(C::in_lds(0)), T0(C::in_lds(0), 0, 0), m, a.ninv, a.s_ninv);
 
     if (active) {
 #pragma unroll

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")  # env: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "ntt_kernels.hip", "zring.hip"]
+SOURCES = ["capi.hip", "ntt_kernels.hip", "zring.hip", "glue.hip"]
 HEADERS = ["ntt_kernels.hpp", "zq_device.hpp", "capi_internal.hpp",
            os.path.join("..", "..", "include", "fhe_ntt.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
@@ -48,6 +48,10 @@ EXPORTS = [
     "fhe_r_naive_mul", "fhe_r_naive_mul_dev", "fhe_mul_div_round_dev",
     "fhe_bfv_tensor", "fhe_bfv_tensor_dev", "fhe_bfv_relinearize_dev", "fhe_bfv_mul", "fhe_bfv_mul_dev",
     "fhe_tn_mul", "fhe_tn_mul_dev", "fhe_tggsw_external_product", "fhe_tggsw_external_product_dev",
+    # rows N3/N4: batch surfaces and element-wise glue
+    "fhe_tr_dot_dev", "fhe_tr_mul_r_dev", "fhe_glev_mul_dev", "fhe_glwe_key_switch_dev",
+    "fhe_rq_add_dev", "fhe_rq_sub_dev", "fhe_rq_neg_dev", "fhe_rq_mul_by_u64_dev",
+    "fhe_rq_mod_switch_dev", "fhe_rq_mul_div_round_dev", "fhe_rq_decompose_dev",
 ]
 
 
@@ -173,6 +177,17 @@ def load_library():
     L.fhe_tn_mul_dev.argtypes = [_u64, _vp, _vp, _vp, _sz, _vp]
     L.fhe_tggsw_external_product.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz]
     L.fhe_tggsw_external_product_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_tr_dot_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _vp]
+    L.fhe_tr_mul_r_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _vp]
+    L.fhe_glev_mul_dev.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_glwe_key_switch_dev.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_rq_add_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_rq_sub_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_rq_neg_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]
+    L.fhe_rq_mul_by_u64_dev.argtypes = [_vp, _vp, _u64, _vp, _sz, _vp]
+    L.fhe_rq_mod_switch_dev.argtypes = [_u64, _u64, _vp, _vp, _sz, _vp]
+    L.fhe_rq_mul_div_round_dev.argtypes = [_u64, _u64, _u64, _vp, _vp, _sz, _vp]
+    L.fhe_rq_decompose_dev.argtypes = [_u64, _u64, _uint, _uint, _vp, _vp, _sz, _vp]
     L.fhe_ntt_device_count.argtypes = []
     L.fhe_last_error.restype = ctypes.c_char_p
     L.fhe_ntt_version.restype = ctypes.c_char_p

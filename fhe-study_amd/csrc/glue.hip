@@ -1,0 +1,335 @@
+// glue.hip — rows N3 / N4 of SURVEY.md §8f: the reference's batch surfaces around `Rq * Rq`
+// and the element-wise operations between them, on the device, so that a caller can stay
+// resident between NTT products.
+//
+//   N3  TR<Rq> . TR<Rq>                 arith/src/tuple_ring.rs:117-134   fhe_tr_dot_dev
+//       TR<Rq> x Rq, GLWE<Rq> x Rq      tuple_ring.rs:137-155, gfhe/src/glwe.rs:263-280   fhe_tr_mul_r_dev
+//       GLev<Rq> x Vec<Rq> -> GLWE      gfhe/src/glev.rs:68-80            fhe_glev_mul_dev
+//       GLWE<Rq>::key_switch            gfhe/src/glwe.rs:126-137          fhe_glwe_key_switch_dev
+//   N4  Rq + - neg, mul_by_u64          arith/src/ring_nq.rs:406-488,551-561,274-281
+//       mod_switch, mul_div_round       ring_nq.rs:88-113, arith/src/zq.rs:134-139,32-39
+//       decompose(beta, l)              ring_nq.rs:67-78, zq.rs:141-207
+//
+// The reference forms every product with its own pair of forward NTTs and an inverse and then
+// sums canonical polynomials.  Arithmetic mod q is exact, so summing in the NTT domain and
+// transforming back once gives the same canonical words: k (or l*(k+1)) products cost their
+// forward transforms, one multiply-accumulate pass and ONE inverse per output polynomial.
+#include <vector>
+
+#include "capi_internal.hpp"
+#include "zq_device.hpp"
+
+using fhe::Mod;
+using fhe::u32;
+using fhe::u64;
+
+namespace fhe {
+
+enum class Ew { Add, Sub, Neg, MulScalar };
+
+template <Ew OP>
+__global__ __launch_bounds__(256) void ew_kernel(const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                 u64 *__restrict__ c, u64 count, Mod m, u64 s) {
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const u64 x = a[i];
+        u64 r;
+        if (OP == Ew::Add) { r = x + b[i]; r = r >= m.q ? r - m.q : r; }                 // zq.rs:219-231
+        else if (OP == Ew::Sub) { const u64 y = b[i]; r = x >= y ? x - y : (m.q + x) - y; }  // zq.rs:259-276
+        else if (OP == Ew::Neg) r = x == 0 ? 0 : m.q - x;                                // zq.rs:301-313
+        else r = mul_mod_var(x, s, m);                                                   // zq.rs:315-328
+        c[i] = r;
+    }
+}
+
+__device__ __forceinline__ u64 f64_as_u64(double x) {   // Rust `f64 as u64`
+    if (x != x || x <= 0.0) return 0;
+    if (x >= 18446744073709551616.0) return ~0ull;
+    return (u64)x;
+}
+__device__ __forceinline__ long long f64_as_i64_sat(double x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return 0x7fffffffffffffffll;
+    if (x <= -9223372036854775808.0) return (long long)0x8000000000000000ull;
+    return (long long)x;
+}
+
+// Zq::mod_switch, zq.rs:134-139
+__global__ __launch_bounds__(256) void mod_switch_kernel(const u64 *__restrict__ a, u64 *__restrict__ c,
+                                                         u64 count, u64 q, u64 p) {
+    const u64 stride = (u64)gridDim.x * 256;
+    const double qf = (double)q, pf = (double)p;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const u64 v = f64_as_u64(round(((double)a[i] * pf) / qf));
+        c[i] = v >= p ? v % p : v;
+    }
+}
+
+// Ring::mul_div_round for Rq, ring_nq.rs:100-113 (+ Zq::from_f64, zq.rs:32-39)
+__global__ __launch_bounds__(256) void rq_mul_div_round_kernel(const u64 *__restrict__ a, u64 *__restrict__ c,
+                                                               u64 count, u64 q, u64 num, u64 den) {
+    const u64 stride = (u64)gridDim.x * 256;
+    const double nf = (double)num, df = (double)den;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const long long e = f64_as_i64_sat(round(round((nf * (double)a[i]) / df)));
+        const long long qi = (long long)q;
+        c[i] = (e < 0 || e >= qi) ? (u64)(((e % qi) + qi) % qi) : (u64)e;
+    }
+}
+
+// Rq::decompose(beta, l), ring_nq.rs:67-78 with Zq::decompose zq.rs:141-207.
+// input row r = (group r / grp, member r % grp) lives at a + group*gstride + member*n (so the k
+// mask rows of each (k+1)-row ciphertext can be picked without a gather); out [rows][l][n]
+__global__ __launch_bounds__(256) void decompose_kernel(const u64 *__restrict__ a, u64 *__restrict__ out,
+                                                        u64 rows, u32 n, u64 q, u32 beta, u32 l, u32 grp,
+                                                        u64 gstride) {
+    const u64 total = rows * n, stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 r = i / n;
+        const u32 j = (u32)(i - r * n);
+        const u64 v = a[(r / grp) * gstride + (r % grp) * n + j];
+        u64 *o = out + r * l * n + j;
+        if (beta == 2) {
+            if (v >= (1ull << (l & 63u))) {                       // zq.rs:176-180 (--release shift wrap)
+                for (u32 d = 0; d < l; d++) o[(u64)d * n] = 1 % q;
+            } else {
+                for (u32 d = 0; d < l; d++) {
+                    const u64 bit = (v >> (l - 1 - d)) & 1ull;
+                    o[(u64)d * n] = bit >= q ? bit % q : bit;
+                }
+            }
+        } else {
+            u32 bl = 1;
+            for (u32 t = 0; t < l; t++) bl *= beta;                // beta.pow(l) in u32
+            if (v >= (u64)bl) {                                    // zq.rs:152-160
+                for (u32 d = 0; d < l; d++) o[(u64)d * n] = (u64)beta - 1;
+            } else {
+                u64 rem = v;
+                u32 bi = 1;
+                for (u32 d = 0; d < l; d++) {
+                    bi *= beta;
+                    const u64 den = q / (u64)bi;
+                    const u64 x = rem / den;
+                    o[(u64)d * n] = x >= q ? x % q : x;
+                    if (x != 0) rem = rem % den;
+                }
+            }
+        }
+    }
+}
+
+// out[b][c][j] = sum_{t<T} G[g_b][t][c][j] * D[b][t][j]  (mod q); G is shared by the batch
+// (gstride = 0) or per batch element (gstride = T*nc*n).  D may have a single shared row per
+// batch element broadcast over c (that is the shape of TR x R: T = 1, G per batch).
+__global__ __launch_bounds__(256) void mac_rows_kernel(const u64 *__restrict__ G, const u64 *__restrict__ D,
+                                                       u64 *__restrict__ out, u64 batch, u32 n, u32 T, u32 nc,
+                                                       u64 gstride, Mod m) {
+    const u64 total = batch * nc * n, stride = (u64)gridDim.x * 256;
+    for (u64 idx = (u64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const u32 j = (u32)(idx % n);
+        const u64 bc = idx / n;
+        const u32 c = (u32)(bc % nc);
+        const u64 b = bc / nc;
+        const u64 *g = G + b * gstride + (u64)c * n + j;
+        const u64 *d = D + b * T * n + j;
+        u64 acc = 0;
+        for (u32 t = 0; t < T; t++)
+            acc = canon2(acc + mul_mod_var(g[(u64)t * nc * n], d[(u64)t * n], m), m);
+        out[idx] = acc;
+    }
+}
+
+// key_switch tail, glwe.rs:129-136: out[c] = (c < k ? 0 : b) - rhs[c]
+__global__ __launch_bounds__(256) void ks_tail_kernel(const u64 *__restrict__ glwe, const u64 *__restrict__ rhs,
+                                                      u64 *__restrict__ out, u64 batch, u32 n, u32 k, u64 q) {
+    const u32 k1 = k + 1;
+    const u64 total = batch * k1 * n, stride = (u64)gridDim.x * 256;
+    for (u64 idx = (u64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const u32 c = (u32)((idx / n) % k1);
+        const u64 x = c < k ? 0ull : glwe[idx], y = rhs[idx];
+        out[idx] = x >= y ? x - y : (q + x) - y;
+    }
+}
+
+}  // namespace fhe
+
+static inline unsigned ew_grid(u64 count) {
+    u64 g = (count + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    return (unsigned)(g ? g : 1);
+}
+#define LAUNCH_OK(what)                                      \
+    do {                                                     \
+        hipError_t e_ = hipGetLastError();                   \
+        if (e_ != hipSuccess) return fhe_hip_fail(e_, what); \
+    } while (0)
+
+static int fwd(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
+    hipError_t e = fhe::launch_ntt_forward(dp, in, out, rows, fhe_batch_tile_for(plan), st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "glue forward NTT");
+}
+static int inv(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
+    hipError_t e = fhe::launch_ntt_inverse(dp, in, nullptr, nullptr, out, rows, fhe_batch_tile_for(plan), st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "glue inverse NTT");
+}
+
+// ---- N4 ------------------------------------------------------------------------------------
+template <fhe::Ew OP>
+static int ew_call(const fhe_ntt_plan *plan, const void *a, const void *b, void *c, size_t batch, u64 s, void *stream,
+                   const char *who) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "%s: plan is NULL", who);
+    if (batch == 0) return FHE_OK;
+    if (!a || !c || ((OP == fhe::Ew::Add || OP == fhe::Ew::Sub) && !b)) return fhe_fail(FHE_E_NULL, "%s: NULL buffer", who);
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const u64 count = batch * plan->n;
+    hipLaunchKernelGGL((fhe::ew_kernel<OP>), dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (const u64 *)a,
+                       (const u64 *)b, (u64 *)c, count, plan->mod, s);
+    LAUNCH_OK(who);
+    return FHE_OK;
+}
+extern "C" int fhe_rq_add_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, size_t batch, void *st) {
+    return ew_call<fhe::Ew::Add>(plan, d_a, d_b, d_c, batch, 0, st, "fhe_rq_add_dev");
+}
+extern "C" int fhe_rq_sub_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, size_t batch, void *st) {
+    return ew_call<fhe::Ew::Sub>(plan, d_a, d_b, d_c, batch, 0, st, "fhe_rq_sub_dev");
+}
+extern "C" int fhe_rq_neg_dev(const fhe_ntt_plan *plan, const void *d_a, void *d_c, size_t batch, void *st) {
+    return ew_call<fhe::Ew::Neg>(plan, d_a, nullptr, d_c, batch, 0, st, "fhe_rq_neg_dev");
+}
+extern "C" int fhe_rq_mul_by_u64_dev(const fhe_ntt_plan *plan, const void *d_a, uint64_t s, void *d_c, size_t batch, void *st) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_rq_mul_by_u64_dev: plan is NULL");
+    return ew_call<fhe::Ew::MulScalar>(plan, d_a, nullptr, d_c, batch, s % plan->q, st, "fhe_rq_mul_by_u64_dev");
+}
+extern "C" int fhe_rq_mod_switch_dev(uint64_t q, uint64_t p, const void *d_a, void *d_c, size_t count, void *st) {
+    if (q == 0 || p == 0) return fhe_fail(FHE_E_BAD_Q, "fhe_rq_mod_switch_dev: q and p must be non-zero");
+    if (count == 0) return FHE_OK;
+    if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mod_switch_dev: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::mod_switch_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)p);
+    LAUNCH_OK("mod_switch_kernel");
+    return FHE_OK;
+}
+extern "C" int fhe_rq_mul_div_round_dev(uint64_t q, uint64_t num, uint64_t den, const void *d_a, void *d_c, size_t count, void *st) {
+    if (q == 0 || den == 0 || (q >> 63)) return fhe_fail(FHE_E_BAD_Q, "fhe_rq_mul_div_round_dev: need 0 < q < 2^63, den > 0");
+    if (count == 0) return FHE_OK;
+    if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mul_div_round_dev: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::rq_mul_div_round_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)num, (u64)den);
+    LAUNCH_OK("rq_mul_div_round_kernel");
+    return FHE_OK;
+}
+extern "C" int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, const void *d_a, void *d_out, size_t rows, void *st) {
+    if (q == 0 || n == 0 || beta < 2 || l < 1) return fhe_fail(FHE_E_INVALID, "fhe_rq_decompose_dev: need q, n > 0, beta >= 2, l >= 1");
+    if (rows == 0) return FHE_OK;
+    if (!d_a || !d_out) return fhe_fail(FHE_E_NULL, "fhe_rq_decompose_dev: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(ew_grid(rows * n)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_out, (u64)rows, (u32)n, (u64)q, (u32)beta, (u32)l, (u32)1, (u64)n);
+    LAUNCH_OK("decompose_kernel");
+    return FHE_OK;
+}
+
+// ---- N3 ------------------------------------------------------------------------------------
+// c[b] = sum_{i<k} a[b][i] * b[b][i];  a, b: [batch][k][n];  c: [batch][n]
+extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, unsigned k, size_t batch, void *stream) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_tr_dot_dev: plan is NULL");
+    if (batch == 0 || k == 0) return FHE_OK;
+    if (!d_a || !d_b || !d_c) return fhe_fail(FHE_E_NULL, "fhe_tr_dot_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_b); REQUIRE_ALIGNED(d_c);
+    fhe::DevicePlan dp;
+    int rc = fhe_device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const u64 n = plan->n, rows = batch * k;
+    void *w = nullptr;
+    if ((rc = fhe_workspace_get(1, (2 * rows + batch) * n * 8, &w)) != FHE_OK) return rc;
+    u64 *A = (u64 *)w, *B = A + rows * n, *C = B + rows * n;
+    if ((rc = fwd(plan, dp, (const u64 *)d_a, A, rows, st)) != FHE_OK) return rc;
+    if ((rc = fwd(plan, dp, (const u64 *)d_b, B, rows, st)) != FHE_OK) return rc;
+    // T = k terms, nc = 1 output row, "G" = A per batch element
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(ew_grid(batch * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
+    LAUNCH_OK("mac_rows_kernel");
+    return inv(plan, dp, C, (u64 *)d_c, batch, st);
+}
+
+// out[b][i] = a[b][i] * p[b], i < rows;  a, out: [batch][rows][n];  p: [batch][n]
+extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_p, void *d_out, unsigned rows, size_t batch, void *stream) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_tr_mul_r_dev: plan is NULL");
+    if (batch == 0 || rows == 0) return FHE_OK;
+    if (!d_a || !d_p || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tr_mul_r_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_p); REQUIRE_ALIGNED(d_out);
+    fhe::DevicePlan dp;
+    int rc = fhe_device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const u64 n = plan->n, total = batch * rows;
+    void *w = nullptr;
+    if ((rc = fhe_workspace_get(1, (2 * total + batch) * n * 8, &w)) != FHE_OK) return rc;
+    u64 *A = (u64 *)w, *C = A + total * n, *P = C + total * n;
+    if ((rc = fwd(plan, dp, (const u64 *)d_a, A, total, st)) != FHE_OK) return rc;
+    if ((rc = fwd(plan, dp, (const u64 *)d_p, P, batch, st)) != FHE_OK) return rc;
+    // T = 1, nc = rows: out[b][c] = A[b][c] * P[b]
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(ew_grid(total * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
+    LAUNCH_OK("mac_rows_kernel");
+    return inv(plan, dp, C, (u64 *)d_out, total, st);
+}
+
+// shared worker: out[b][c] = sum_{t<T} key[t][c] * v[b][t]; key [T][nc][n] (one for the batch)
+static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *d_key, const u64 *d_v, u64 *d_out_evals_then_coeffs,
+                     u32 T, u32 nc, u64 batch, u64 *ws, hipStream_t st) {
+    const u64 n = plan->n;
+    u64 *K = ws, *V = K + (u64)T * nc * n;
+    int rc;
+    if ((rc = fwd(plan, dp, d_key, K, (u64)T * nc, st)) != FHE_OK) return rc;
+    if ((rc = fwd(plan, dp, d_v, V, batch * T, st)) != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(ew_grid(batch * nc * n)), dim3(256), 0, st, (const u64 *)K, (const u64 *)V, d_out_evals_then_coeffs, batch, (u32)n, T, nc, (u64)0, plan->mod);
+    LAUNCH_OK("mac_rows_kernel");
+    return inv(plan, dp, d_out_evals_then_coeffs, d_out_evals_then_coeffs, batch * nc, st);
+}
+
+// GLev x Vec<R> -> GLWE: glev [l][k+1][n] (a key, shared), v [batch][l][n], out [batch][k+1][n]
+extern "C" int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l, const void *d_glev, const void *d_v, void *d_out, size_t batch, void *stream) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_glev_mul_dev: plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (l == 0) return fhe_fail(FHE_E_INVALID, "fhe_glev_mul_dev: l = 0");
+    if (!d_glev || !d_v || !d_out) return fhe_fail(FHE_E_NULL, "fhe_glev_mul_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_glev); REQUIRE_ALIGNED(d_v); REQUIRE_ALIGNED(d_out);
+    fhe::DevicePlan dp;
+    int rc = fhe_device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    const u64 n = plan->n;
+    void *w = nullptr;
+    if ((rc = fhe_workspace_get(1, ((u64)l * (k + 1) + batch * l) * n * 8, &w)) != FHE_OK) return rc;
+    return keyed_mac(plan, dp, (const u64 *)d_glev, (const u64 *)d_v, (u64 *)d_out, l, k + 1, batch, (u64 *)w, (hipStream_t)stream);
+}
+
+// GLWE::key_switch: glwe [batch][k+1][n]; ksk [k][l][k+1][n] (shared); out [batch][k+1][n]
+extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const void *d_glwe, const void *d_ksk,
+                                       void *d_out, size_t batch, void *stream) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch_dev: plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (k == 0 || l == 0 || beta < 2) return fhe_fail(FHE_E_INVALID, "fhe_glwe_key_switch_dev: need k, l >= 1, beta >= 2");
+    if (!d_glwe || !d_ksk || !d_out) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_ksk); REQUIRE_ALIGNED(d_out);
+    fhe::DevicePlan dp;
+    int rc = fhe_device_plan(plan, &dp);
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const u64 n = plan->n;
+    const u32 k1 = k + 1, T = k * l;
+    void *w = nullptr;
+    // [decomposition: batch*k*l rows] [rhs: batch*k1 rows] [keyed_mac scratch: T*k1 + batch*T rows]
+    if ((rc = fhe_workspace_get(1, (batch * T + batch * k1 + (u64)T * k1 + batch * T) * n * 8, &w)) != FHE_OK) return rc;
+    u64 *DEC = (u64 *)w, *RHS = DEC + batch * T * n, *WS = RHS + batch * k1 * n;
+    // decompose the k mask polynomials of every ciphertext (the body row is skipped): rows (b, i) -> [b][i][d]
+    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(ew_grid(batch * k * n)), dim3(256), 0, st, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)n, (u64)plan->q, (u32)beta, (u32)l, (u32)k, (u64)k1 * n);
+    LAUNCH_OK("decompose_kernel");
+    // ksk viewed as [T = k*l][k1][n]; DEC as [batch][T][n]
+    if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, DEC, RHS, T, k1, batch, WS, st)) != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
+    LAUNCH_OK("ks_tail_kernel");
+    return FHE_OK;
+}

@@ -195,6 +195,41 @@ int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, const uint64_
 int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw,
                                    const void *d_tglwe, void *d_out, size_t batch, void *hip_stream);
 
+/* ---- rows N3 / N4: batch surfaces and element-wise glue, device-resident ----
+ * Sums of products are accumulated in the NTT domain and transformed back once; arithmetic
+ * mod q is exact, so the words equal the reference's sum of canonical products. */
+
+/* TR<Rq> . TR<Rq>, arith/src/tuple_ring.rs:117-134: c[b] = sum_{i<k} a[b][i] * b[b][i].
+ * a, b: [batch][k][n]; c: [batch][n]. */
+int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, unsigned k,
+                   size_t batch, void *hip_stream);
+/* TR<Rq> x Rq (tuple_ring.rs:137-155) and GLWE<Rq> x Rq (gfhe/src/glwe.rs:263-280):
+ * out[b][i] = a[b][i] * p[b], i < rows.  a, out: [batch][rows][n]; p: [batch][n]. */
+int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_p, void *d_out,
+                     unsigned rows, size_t batch, void *hip_stream);
+/* GLev<Rq> x Vec<Rq> -> GLWE, gfhe/src/glev.rs:68-80: out[b][c] = sum_{d<l} glev[d][c] * v[b][d].
+ * glev: [l][k+1][n] (a key: shared by the batch); v: [batch][l][n]; out: [batch][k+1][n]. */
+int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l, const void *d_glev,
+                     const void *d_v, void *d_out, size_t batch, void *hip_stream);
+/* GLWE<Rq>::key_switch, gfhe/src/glwe.rs:126-137: (0, b) - sum_{i<k} ksk[i] * decompose(a_i, beta, l).
+ * glwe, out: [batch][k+1][n] as (a_0..a_{k-1}, b); ksk: [k][l][k+1][n] (shared). */
+int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l,
+                            const void *d_glwe, const void *d_ksk, void *d_out, size_t batch,
+                            void *hip_stream);
+
+/* Rq + Rq, Rq - Rq, -Rq (ring_nq.rs:406-488,551-561), Rq::mul_by_u64 (ring_nq.rs:274-281). */
+int fhe_rq_add_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, size_t batch, void *hip_stream);
+int fhe_rq_sub_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, size_t batch, void *hip_stream);
+int fhe_rq_neg_dev(const fhe_ntt_plan *plan, const void *d_a, void *d_c, size_t batch, void *hip_stream);
+int fhe_rq_mul_by_u64_dev(const fhe_ntt_plan *plan, const void *d_a, uint64_t s, void *d_c, size_t batch, void *hip_stream);
+/* Rq::mod_switch(p), ring_nq.rs:88-98 / zq.rs:134-139: round(v * p / q) in f64, mod p. */
+int fhe_rq_mod_switch_dev(uint64_t q, uint64_t p, const void *d_a, void *d_c, size_t count, void *hip_stream);
+/* Ring::mul_div_round for Rq, ring_nq.rs:100-113: Zq::from_f64(round(num * v / den)). */
+int fhe_rq_mul_div_round_dev(uint64_t q, uint64_t num, uint64_t den, const void *d_a, void *d_c, size_t count, void *hip_stream);
+/* Rq::decompose(beta, l), ring_nq.rs:67-78 with Zq::decompose zq.rs:141-207 (base 2 and
+ * base beta, including their saturation branch).  a: [rows][n] -> out: [rows][l][n]. */
+int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, const void *d_a, void *d_out, size_t rows, void *hip_stream);
+
 /* ---- misc ---------------------------------------------------------------- */
 int fhe_ntt_device_count(void);            /* HIP devices visible (0 if none) */
 const char *fhe_last_error(void);          /* thread-local, never NULL */

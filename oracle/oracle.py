@@ -90,6 +90,19 @@ class Oracle:
         L.oracle_tn_decompose.argtypes = [_u64, ctypes.c_uint32, _p64, _p64]
         L.oracle_external_product.restype = None
         L.oracle_external_product.argtypes = [_u64, ctypes.c_uint32, ctypes.c_uint32, _p64, _p64, _p64]
+        for name, at in (("oracle_rq_add", [_u64, _u64, _p64, _p64, _p64]), ("oracle_rq_sub", [_u64, _u64, _p64, _p64, _p64]),
+                         ("oracle_rq_neg", [_u64, _u64, _p64, _p64]), ("oracle_rq_mul_by_u64", [_u64, _u64, _p64, _u64, _p64]),
+                         ("oracle_rq_mod_switch", [_u64, _u64, _p64, _u64, _p64]),
+                         ("oracle_rq_mul_div_round", [_u64, _u64, _p64, _u64, _u64, _p64]),
+                         ("oracle_rq_decompose", [_u64, _u64, _p64, ctypes.c_uint32, ctypes.c_uint32, _p64])):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = at
+        u32 = ctypes.c_uint32
+        for name, at in (("oracle_tr_dot", [_u64, _u64, u32, _p64, _p64, _p64]), ("oracle_tr_mul_r", [_u64, _u64, u32, _p64, _p64, _p64]),
+                         ("oracle_glev_mul", [_u64, _u64, u32, u32, _p64, _p64, _p64]),
+                         ("oracle_key_switch", [_u64, _u64, u32, u32, u32, _p64, _p64, _p64])):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = at
         self._tables = {}
 
     # -- tables ---------------------------------------------------------------
@@ -234,6 +247,14 @@ class Oracle:
         for i in range(t.shape[0]):
             self.lib.oracle_external_product(n, k, l, _ptr(g), _ptr(t[i]), _ptr(out[i]))
         return out.reshape(-1, k + 1, n)
+
+    # -- rows N3/N4 (oracle/fhe_glue_oracle.c) -------------------------------------
+    def glue(self, name, *args):
+        """call oracle_<name>(...) with numpy arrays converted to u64 pointers; returns nothing"""
+        conv = [(_ptr(a) if isinstance(a, np.ndarray) else a) for a in args]
+        rc = getattr(self.lib, "oracle_" + name)(*conv)
+        if rc not in (None, 0):
+            raise ValueError(f"oracle_{name} failed")
 
     def exp_mod(self, q, x, k):
         return int(self.lib.oracle_exp_mod(q, x, k))

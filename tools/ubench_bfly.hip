@@ -121,6 +121,31 @@ __device__ __forceinline__ void bf_v5(u64& x, u64& y, u64 w, u64 wp, const Q& c,
   y = add64(shl1add64(u, c.q2p1), ~s);
   x = s;
 }
+// variant 7: exact mulhi64 without any zero-extension move: 64-bit shifts produce the {hi,0}
+// pairs, the one possible overflow is taken from the mad's carry-out SGPR
+__device__ __forceinline__ u64 shr32(u64 a) { u64 d; asm("v_lshrrev_b64 %0, 32, %1" : "=v"(d) : "v"(a)); return d; }
+__device__ __forceinline__ u64 mad64c(u32 a, u32 b, u64 c, u32& cbit) {
+  u64 d, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+  asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(cbit) : "s"(carry));
+  return d;
+}
+__device__ __forceinline__ u64 mulhi64_v7(u64 y, u64 p) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), p0 = (u32)p, p1 = (u32)(p >> 32);
+  const u64 A = mad64(y1, p0, shr32(mad64z(y0, p0)));
+  u32 cbit;
+  const u64 B = mad64c(y0, p1, A, cbit);
+  const u64 r = mad64(y1, p1, shr32(B));
+  return pack((u32)r, add32((u32)(r >> 32), cbit));
+}
+__device__ __forceinline__ void bf_v7(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) { u64 d = add64(x, c.neg4q); u = ((int)(u32)(d >> 32) < 0) ? x : d; }
+  u64 qh = mulhi64_v7(y, wp);
+  u64 s = chain_s5(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
 // variant 6: v5's chain with the compiler's __umul64hi (isolates the mulhi rewrite)
 __device__ __forceinline__ void bf_v6(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
   u64 u = x;
@@ -146,6 +171,7 @@ __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
       if (V == 4) { bf_v4(x[j], y[j], w, wp, c, false); }
       if (V == 5) { bf_v5(x[j], y[j], w, wp, c, false); }
       if (V == 6) { bf_v6(x[j], y[j], w, wp, c, false); }
+      if (V == 7) { bf_v7(x[j], y[j], w, wp, c, false); }
     }
     if (V >= 3) {  // second stage of the pair carries the csub
       i++;
@@ -155,6 +181,7 @@ __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
         if (V == 4) bf_v4(x[j], y[j], w, wp, c, true);
         if (V == 5) bf_v5(x[j], y[j], w, wp, c, true);
         if (V == 6) bf_v6(x[j], y[j], w, wp, c, true);
+        if (V == 7) bf_v7(x[j], y[j], w, wp, c, true);
       }
     }
   }
@@ -180,13 +207,13 @@ int main() {
   u64* p; hipMalloc(&p, 4096 * 8);
   std::vector<u64> h(512), o(512);
   for (int i = 0; i < 512; i++) h[i] = (0x9E3779B97F4A7C15ull * (i + 1)) ^ (0xD1B54A32D192ED03ull * (i + 7));
-  const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo", "v5 no-mov mulhi+pack", "v6 no-mov pack only"};
-  for (int v = 0; v < 7; v++) {
+  const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo", "v5 no-mov mulhi+pack", "v6 no-mov pack only", "v7 shift-zext mulhi"};
+  for (int v = 3; v < 8; v++) {
     // correctness at 6 iterations (even, so v3/v4 pairs are whole)
     hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
     int it = 6;
     switch (v) { case 0: k<0><<<1, 64>>>(p, c, w, wp, it); break; case 1: k<1><<<1, 64>>>(p, c, w, wp, it); break;
-      case 2: k<2><<<1, 64>>>(p, c, w, wp, it); break; case 3: k<3><<<1, 64>>>(p, c, w, wp, it); break; case 4: k<4><<<1, 64>>>(p, c, w, wp, it); break; case 5: k<5><<<1, 64>>>(p, c, w, wp, it); break; case 6: k<6><<<1, 64>>>(p, c, w, wp, it); break; }
+      case 2: k<2><<<1, 64>>>(p, c, w, wp, it); break; case 3: k<3><<<1, 64>>>(p, c, w, wp, it); break; case 4: k<4><<<1, 64>>>(p, c, w, wp, it); break; case 5: k<5><<<1, 64>>>(p, c, w, wp, it); break; case 6: k<6><<<1, 64>>>(p, c, w, wp, it); break; case 7: k<7><<<1, 64>>>(p, c, w, wp, it); break; }
     hipMemcpy(o.data(), p, 512 * 8, hipMemcpyDeviceToHost);
     int bad = 0; u64 mx = 0;
     for (int t = 0; t < 64; t++) for (int j = 0; j < 4; j++) {
@@ -203,7 +230,7 @@ int main() {
       for (int r = 0; r < 4; r++) {
         hipEventRecord(e0);
         switch (v) { case 0: k<0><<<blocks, threads>>>(p, c, w, wp, iters); break; case 1: k<1><<<blocks, threads>>>(p, c, w, wp, iters); break;
-          case 2: k<2><<<blocks, threads>>>(p, c, w, wp, iters); break; case 3: k<3><<<blocks, threads>>>(p, c, w, wp, iters); break; case 4: k<4><<<blocks, threads>>>(p, c, w, wp, iters); break; case 5: k<5><<<blocks, threads>>>(p, c, w, wp, iters); break; case 6: k<6><<<blocks, threads>>>(p, c, w, wp, iters); break; }
+          case 2: k<2><<<blocks, threads>>>(p, c, w, wp, iters); break; case 3: k<3><<<blocks, threads>>>(p, c, w, wp, iters); break; case 4: k<4><<<blocks, threads>>>(p, c, w, wp, iters); break; case 5: k<5><<<blocks, threads>>>(p, c, w, wp, iters); break; case 6: k<6><<<blocks, threads>>>(p, c, w, wp, iters); break; case 7: k<7><<<blocks, threads>>>(p, c, w, wp, iters); break; }
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
       }

@@ -240,13 +240,17 @@ extern "C" int fhe_ntt_set_batch_tile(size_t polys) {
     return FHE_OK;
 }
 
-// grow-only per-device workspaces (slot 0: fhe_rq_mul_dev(d_work = NULL), slot 1: zring)
+// grow-only per-device workspaces (slot 0: fhe_rq_mul_dev(d_work = NULL), slot 1: zring / glue).
+// Growing never frees a buffer that enqueued work may still be using: the old buffer is retired
+// and released at fhe_ntt_shutdown().  Callers that rely on the library workspace must issue
+// those calls on ONE stream at a time per device (the contents are per call, not per stream).
 struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
 static std::mutex g_ws_lock;
 static Workspace g_ws[2][kMaxDevices];
+static std::vector<void *> g_ws_retired;
 
 int fhe_workspace_get(int slot, size_t bytes, void **out) {
     int dev = 0;
@@ -255,13 +259,10 @@ int fhe_workspace_get(int slot, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lk(g_ws_lock);
     Workspace &w = g_ws[slot][dev];
     if (w.bytes < bytes) {
-        if (w.ptr) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(w.ptr));
-            w.ptr = nullptr;
-            w.bytes = 0;
-        }
-        HIP_TRY(hipMalloc(&w.ptr, bytes));
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes));
+        if (w.ptr) g_ws_retired.push_back(w.ptr);
+        w.ptr = p;
         w.bytes = bytes;
     }
     *out = w.ptr;
@@ -275,6 +276,8 @@ void fhe_workspace_free_all() {
             w.ptr = nullptr;
             w.bytes = 0;
         }
+    for (void *p : g_ws_retired) (void)hipFree(p);
+    g_ws_retired.clear();
 }
 
 // ---------------------------------------------------------------------------

@@ -48,3 +48,15 @@ static inline bool fhe_misaligned(const void *p) { return (reinterpret_cast<uint
         if ((p) && fhe_misaligned(p))                                                               \
             return fhe_fail(FHE_E_INVALID, #p " must be 16-byte aligned (got %p)", (const void *)(p)); \
     } while (0)
+
+// grid of a grid-stride element-wise kernel: at most 16 blocks of 256 per CU
+static inline unsigned fhe_ew_grid(fhe::u64 count) {
+    fhe::u64 g = (count + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    return (unsigned)(g ? g : 1);
+}
+#define LAUNCH_OK(what)                                      \
+    do {                                                     \
+        hipError_t e_ = hipGetLastError();                   \
+        if (e_ != hipSuccess) return fhe_hip_fail(e_, what); \
+    } while (0)

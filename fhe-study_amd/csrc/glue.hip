@@ -153,16 +153,6 @@ __global__ __launch_bounds__(256) void ks_tail_kernel(const u64 *__restrict__ gl
 
 }  // namespace fhe
 
-static inline unsigned ew_grid(u64 count) {
-    u64 g = (count + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
-    return (unsigned)(g ? g : 1);
-}
-#define LAUNCH_OK(what)                                      \
-    do {                                                     \
-        hipError_t e_ = hipGetLastError();                   \
-        if (e_ != hipSuccess) return fhe_hip_fail(e_, what); \
-    } while (0)
 
 static int fwd(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
     hipError_t e = fhe::launch_ntt_forward(dp, in, out, rows, fhe_batch_tile_for(plan), st);
@@ -183,7 +173,7 @@ static int ew_call(const fhe_ntt_plan *plan, const void *a, const void *b, void 
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     const u64 count = batch * plan->n;
-    hipLaunchKernelGGL((fhe::ew_kernel<OP>), dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (const u64 *)a,
+    hipLaunchKernelGGL((fhe::ew_kernel<OP>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (const u64 *)a,
                        (const u64 *)b, (u64 *)c, count, plan->mod, s);
     LAUNCH_OK(who);
     return FHE_OK;
@@ -207,7 +197,7 @@ extern "C" int fhe_rq_mod_switch_dev(uint64_t q, uint64_t p, const void *d_a, vo
     if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mod_switch_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::mod_switch_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)p);
+    hipLaunchKernelGGL(fhe::mod_switch_kernel, dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)p);
     LAUNCH_OK("mod_switch_kernel");
     return FHE_OK;
 }
@@ -217,7 +207,7 @@ extern "C" int fhe_rq_mul_div_round_dev(uint64_t q, uint64_t num, uint64_t den, 
     if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mul_div_round_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::rq_mul_div_round_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)num, (u64)den);
+    hipLaunchKernelGGL(fhe::rq_mul_div_round_kernel, dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)num, (u64)den);
     LAUNCH_OK("rq_mul_div_round_kernel");
     return FHE_OK;
 }
@@ -227,7 +217,7 @@ extern "C" int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsig
     if (!d_a || !d_out) return fhe_fail(FHE_E_NULL, "fhe_rq_decompose_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(ew_grid(rows * n)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_out, (u64)rows, (u32)n, (u64)q, (u32)beta, (u32)l, (u32)1, (u64)n);
+    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(fhe_ew_grid(rows * n)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_out, (u64)rows, (u32)n, (u64)q, (u32)beta, (u32)l, (u32)1, (u64)n);
     LAUNCH_OK("decompose_kernel");
     return FHE_OK;
 }
@@ -250,7 +240,7 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     if ((rc = fwd(plan, dp, (const u64 *)d_a, A, rows, st)) != FHE_OK) return rc;
     if ((rc = fwd(plan, dp, (const u64 *)d_b, B, rows, st)) != FHE_OK) return rc;
     // T = k terms, nc = 1 output row, "G" = A per batch element
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(ew_grid(batch * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
     return inv(plan, dp, C, (u64 *)d_c, batch, st);
 }
@@ -272,7 +262,7 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     if ((rc = fwd(plan, dp, (const u64 *)d_a, A, total, st)) != FHE_OK) return rc;
     if ((rc = fwd(plan, dp, (const u64 *)d_p, P, batch, st)) != FHE_OK) return rc;
     // T = 1, nc = rows: out[b][c] = A[b][c] * P[b]
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(ew_grid(total * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(total * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
     return inv(plan, dp, C, (u64 *)d_out, total, st);
 }
@@ -285,7 +275,7 @@ static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const 
     int rc;
     if ((rc = fwd(plan, dp, d_key, K, (u64)T * nc, st)) != FHE_OK) return rc;
     if ((rc = fwd(plan, dp, d_v, V, batch * T, st)) != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(ew_grid(batch * nc * n)), dim3(256), 0, st, (const u64 *)K, (const u64 *)V, d_out_evals_then_coeffs, batch, (u32)n, T, nc, (u64)0, plan->mod);
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * nc * n)), dim3(256), 0, st, (const u64 *)K, (const u64 *)V, d_out_evals_then_coeffs, batch, (u32)n, T, nc, (u64)0, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
     return inv(plan, dp, d_out_evals_then_coeffs, d_out_evals_then_coeffs, batch * nc, st);
 }
@@ -325,11 +315,11 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     if ((rc = fhe_workspace_get(1, (batch * T + batch * k1 + (u64)T * k1 + batch * T) * n * 8, &w)) != FHE_OK) return rc;
     u64 *DEC = (u64 *)w, *RHS = DEC + batch * T * n, *WS = RHS + batch * k1 * n;
     // decompose the k mask polynomials of every ciphertext (the body row is skipped): rows (b, i) -> [b][i][d]
-    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(ew_grid(batch * k * n)), dim3(256), 0, st, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)n, (u64)plan->q, (u32)beta, (u32)l, (u32)k, (u64)k1 * n);
+    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(fhe_ew_grid(batch * k * n)), dim3(256), 0, st, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)n, (u64)plan->q, (u32)beta, (u32)l, (u32)k, (u64)k1 * n);
     LAUNCH_OK("decompose_kernel");
     // ksk viewed as [T = k*l][k1][n]; DEC as [batch][T][n]
     if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, DEC, RHS, T, k1, batch, WS, st)) != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
+    hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(fhe_ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
     LAUNCH_OK("ks_tail_kernel");
     return FHE_OK;
 }

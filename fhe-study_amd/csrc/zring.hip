@@ -222,11 +222,6 @@ __global__ __launch_bounds__(256) void zr_rq_add_kernel(const u64 *__restrict__ 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static inline unsigned ew_grid(u64 count) {
-    u64 g = (count + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
-    return (unsigned)(g ? g : 1);
-}
 static inline u64 hmulmod(u64 a, u64 b, u64 p) { return (u64)(((u128)a * b) % p); }
 static u64 hpow(u64 a, u64 e, u64 p) {
     u64 r = 1;
@@ -279,11 +274,6 @@ static int zctx_init(ZCtx *z, u64 n2, int K) {
     return FHE_OK;
 }
 
-#define LAUNCH_OK(what)                                              \
-    do {                                                             \
-        hipError_t e_ = hipGetLastError();                           \
-        if (e_ != hipSuccess) return fhe_hip_fail(e_, what);         \
-    } while (0)
 
 static int z_forward(const ZCtx &z, int k, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
     hipError_t e = fhe::launch_ntt_forward(z.dp[k], in, out, rows, fhe_batch_tile_for(z.plan[k]), st);
@@ -296,7 +286,7 @@ static int z_inverse(const ZCtx &z, int k, const u64 *in, u64 *out, u64 rows, hi
 }
 static int z_crt(const ZCtx &z, bool is_signed, const u64 *r1, const u64 *r2, const u64 *r3, u64 *out,
                  u64 count, hipStream_t st) {
-    const unsigned g = ew_grid(count);
+    const unsigned g = fhe_ew_grid(count);
 #define CRT_CASE(K_, S_) hipLaunchKernelGGL((fhe::zr_crt_kernel<K_, S_>), dim3(g), dim3(256), 0, st, r1, r2, r3, out, count, z.cc)
     if (z.K == 1) { if (is_signed) CRT_CASE(1, true); else CRT_CASE(1, false); }
     else if (z.K == 2) { if (is_signed) CRT_CASE(2, true); else CRT_CASE(2, false); }
@@ -336,8 +326,8 @@ extern "C" int fhe_r_naive_mul_dev(uint64_t n, const void *d_a, const void *d_b,
     if (rc != FHE_OK) return rc;
     u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;   // R: K residue arrays
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
         LAUNCH_OK("zr_reduce_pad_kernel");
         if ((rc = z_forward(z, k, A, A, batch, st)) != FHE_OK) return rc;
         if ((rc = z_forward(z, k, B, B, batch, st)) != FHE_OK) return rc;
@@ -358,7 +348,7 @@ extern "C" int fhe_mul_div_round_dev(uint64_t q, uint64_t n, const void *d_v, ui
     int dev;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::zr_mul_div_round_kernel, dim3(ew_grid(batch * n)), dim3(256), 0, (hipStream_t)hip_stream,
+    hipLaunchKernelGGL(fhe::zr_mul_div_round_kernel, dim3(fhe_ew_grid(batch * n)), dim3(256), 0, (hipStream_t)hip_stream,
                        (const u64 *)d_v, (u64 *)d_out, (u64)batch, (u32)n, (u64)q, (u64)num, (u64)den);
     LAUNCH_OK("zr_mul_div_round_kernel");
     return FHE_OK;
@@ -386,11 +376,11 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
     if (rc != FHE_OK) return rc;
     u64 *AB = (u64 *)wsv, *R = AB + 4 * words, *V = R + 3 * (u64)z.K * words;
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(4 * words)), dim3(256), 0, st, (const u64 *)d_ab, AB, (u64)(4 * batch), (u32)n, (u32)n2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(4 * words)), dim3(256), 0, st, (const u64 *)d_ab, AB, (u64)(4 * batch), (u32)n, (u32)n2, z.cc.m[k]);
         LAUNCH_OK("zr_reduce_pad_kernel");
         if ((rc = z_forward(z, k, AB, AB, 4 * batch, st)) != FHE_OK) return rc;
         u64 *Rk = R + 3 * (u64)k * words;
-        hipLaunchKernelGGL(fhe::zr_tensor_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)AB, Rk, words, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_tensor_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)AB, Rk, words, z.cc.m[k]);
         LAUNCH_OK("zr_tensor_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 3 * batch, st)) != FHE_OK) return rc;
     }
@@ -421,13 +411,13 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
     u64 *X = (u64 *)wsv, *R = X + words, *V = R + 2 * (u64)z.K * words, *Rr = V + 2 * words, *Y = Rr + words;
     const u64 *c2 = (const u64 *)d_c + 2 * bn;
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, c2, X, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(2 * n2)), dim3(256), 0, st, (const u64 *)d_rlk, Y, (u64)2, (u32)n, (u32)n2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, c2, X, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(2 * n2)), dim3(256), 0, st, (const u64 *)d_rlk, Y, (u64)2, (u32)n, (u32)n2, z.cc.m[k]);
         LAUNCH_OK("zr_reduce_pad_kernel");
         if ((rc = z_forward(z, k, X, X, batch, st)) != FHE_OK) return rc;
         if ((rc = z_forward(z, k, Y, Y, 2, st)) != FHE_OK) return rc;
         u64 *Rk = R + 2 * (u64)k * words;
-        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, (const u64 *)Y, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, (const u64 *)Y, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
         LAUNCH_OK("zr_mul_bcast_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 2 * batch, st)) != FHE_OK) return rc;
     }
@@ -436,7 +426,7 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
     // r0, r1 = mul_div_round(.., 1, p); reuse Rr (2*bn <= words) for them
     rc = fhe_mul_div_round_dev(q, n, V, 1, p, Rr, 2 * batch, st);
     if (rc != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::zr_rq_add_kernel, dim3(ew_grid(2 * bn)), dim3(256), 0, st, (const u64 *)d_c, (const u64 *)Rr, (u64 *)d_out, 2 * bn, (u64)q);
+    hipLaunchKernelGGL(fhe::zr_rq_add_kernel, dim3(fhe_ew_grid(2 * bn)), dim3(256), 0, st, (const u64 *)d_c, (const u64 *)Rr, (u64 *)d_out, 2 * bn, (u64)q);
     LAUNCH_OK("zr_rq_add_kernel");
     return FHE_OK;
 }
@@ -471,8 +461,8 @@ extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void
     if (rc != FHE_OK) return rc;
     u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
         LAUNCH_OK("zr_reduce_pad_kernel");
         if ((rc = z_forward(z, k, A, A, batch, st)) != FHE_OK) return rc;
         if ((rc = z_forward(z, k, B, B, batch, st)) != FHE_OK) return rc;
@@ -504,15 +494,15 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
     rc = fhe_workspace_get(1, (grows + 2 * drows + (size_t)z.K * orows) * n * 8, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *G = (u64 *)wsv, *Dg = G + grows * n, *D = Dg + drows * n, *R = D + drows * n;
-    hipLaunchKernelGGL(fhe::zr_digits_kernel, dim3(ew_grid(drows * n)), dim3(256), 0, st, (const u64 *)d_tglwe, Dg, (u64)orows, (u32)n, (u32)l);
+    hipLaunchKernelGGL(fhe::zr_digits_kernel, dim3(fhe_ew_grid(drows * n)), dim3(256), 0, st, (const u64 *)d_tglwe, Dg, (u64)orows, (u32)n, (u32)l);
     LAUNCH_OK("zr_digits_kernel");
     for (int kk = 0; kk < z.K; kk++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G, grows, (u32)n, (u32)n, z.cc.m[kk]);
+        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G, grows, (u32)n, (u32)n, z.cc.m[kk]);
         LAUNCH_OK("zr_reduce_pad_kernel");
         if ((rc = z_forward(z, kk, G, G, grows, st)) != FHE_OK) return rc;
         if ((rc = z_forward(z, kk, Dg, D, drows, st)) != FHE_OK) return rc;   // digits are < every prime
         u64 *Rk = R + (u64)kk * orows * n;
-        hipLaunchKernelGGL(fhe::zr_extprod_mac_kernel, dim3(ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)G, (const u64 *)D, Rk, (u64)batch, (u32)n, k1, (u32)l, z.cc.m[kk]);
+        hipLaunchKernelGGL(fhe::zr_extprod_mac_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)G, (const u64 *)D, Rk, (u64)batch, (u32)n, k1, (u32)l, z.cc.m[kk]);
         LAUNCH_OK("zr_extprod_mac_kernel");
         if ((rc = z_inverse(z, kk, Rk, Rk, orows, st)) != FHE_OK) return rc;
     }

@@ -125,3 +125,24 @@ def test_compute_without_gpu_fails_loudly(pkg):
         pkg.Plan(Q16, 4).forward(np.array([1, 2, 3, 4], dtype=np.uint64))
     assert ei.value.code == pkg.binding.FHE_E_NO_DEVICE
     assert "no CPU fallback" in str(ei.value)
+
+
+def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
+    """argument errors of the N1-N4 entry points are reported without a device"""
+    L, B = pkg.load_library(), pkg.binding
+    plan = pkg.Plan(Q16, 8)
+    d = 16  # any non-NULL, 16-byte aligned fake device address: validation must fail first
+    assert L.fhe_tn_mul_dev(3, d, d, d, 1, None) == B.FHE_E_BAD_N
+    assert L.fhe_r_naive_mul_dev(1 << 20, d, d, d, 1, 0, 0, None) == B.FHE_E_BAD_N      # 2n would exceed 2^20
+    assert L.fhe_bfv_tensor_dev(0, 16, 2, d, d, 1, None) == B.FHE_E_BAD_Q
+    assert L.fhe_bfv_relinearize_dev(Q16, 16, Q16 - 1, d, d, d, 1, None) == B.FHE_E_BAD_Q  # pq < q
+    assert L.fhe_tggsw_external_product_dev(64, 4, 65, d, d, d, 1, None) == B.FHE_E_INVALID
+    assert L.fhe_rq_decompose_dev(Q16, 8, 1, 4, d, d, 1, None) == B.FHE_E_INVALID
+    assert L.fhe_glwe_key_switch_dev(plan.handle, 0, 2, 4, d, d, d, 1, None) == B.FHE_E_INVALID
+    assert L.fhe_tr_dot_dev(None, d, d, d, 2, 1, None) == B.FHE_E_NULL
+    assert L.fhe_rq_add_dev(plan.handle, None, d, d, 1, None) == B.FHE_E_NULL
+    assert L.fhe_mul_div_round_dev(Q16, 8, d, 1, 0, d, 1, None) == B.FHE_E_BAD_Q           # den = 0
+    # empty batches are no-ops everywhere
+    assert L.fhe_tn_mul_dev(8, None, None, None, 0, None) == 0
+    assert L.fhe_bfv_mul_dev(Q16, 16, 2, Q16 * Q16 * Q16, None, None, None, 0, None) == 0
+    assert L.fhe_tr_dot_dev(plan.handle, None, None, None, 2, 0, None) == 0

@@ -796,13 +796,6 @@ static bool use_dma_kernels() {
     }();
     return on;
 }
-static int strided_cw8() {   // FHE_NTT_CW=16|32: column-group width of the LA=8 strided pass
-    static const int cw = [] {
-        const char *e = getenv("FHE_NTT_CW");
-        return e ? atoi(e) : 32;
-    }();
-    return cw;
-}
 
 // persistent DMA kernels: exactly the workgroups a CU can hold (2 per CU by LDS), each
 // walking a strided share of the items
@@ -874,10 +867,7 @@ static hipError_t strided_dispatch(int la, const PassArgs &a, hipStream_t st) {
     switch (la) {
         case 6: return launch_strided<6, 128, INV, WIDE>(a, st);
         case 7: return launch_strided<7, 64, INV, WIDE>(a, st);
-        case 8:
-            if (strided_cw8() == 16) return launch_strided<8, 16, INV, WIDE>(a, st);
-            if (strided_cw8() == 64) return launch_strided<8, 64, INV, WIDE>(a, st);
-            return launch_strided<8, 32, INV, WIDE>(a, st);
+        case 8: return launch_strided<8, 32, INV, WIDE>(a, st);   // 16 / 64 columns measured equal / slower
     }
     return hipErrorInvalidValue;
 }

@@ -301,3 +301,57 @@ def test_experimental_dma_kernels_parity(pkg, oracle):
     env = dict(os.environ, FHE_NTT_DMA="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dma parity ok" in r.stdout, r.stdout + r.stderr
+
+
+def _is_prime(n):
+    if n < 2:
+        return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % p == 0:
+            return n == p
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def _prime_below(limit, step):
+    k = (limit - 2) // step
+    while k > 0 and not _is_prime(k * step + 1):
+        k -= 1
+    if k <= 0:
+        raise ValueError(f"no prime = 1 mod {step} below {limit}")
+    return k * step + 1
+
+
+@pytest.mark.parametrize("bits", [20, 31, 32, 33, 48, 60, 61, 62])
+def test_moduli_across_bit_lengths_and_lazy_range_boundaries(pkg, oracle, bits):
+    """The largest NTT-friendly prime below 2^bits for each bit length: 2^61 is where the
+    forward kernels switch between the every-other-stage (8q < 2^64) and every-stage lazy
+    ranges; 2^32/2^33 exercise the 32-bit limb carries.  Inputs include the extreme patterns
+    that maximise the redundant representation."""
+    q = _prime_below(1 << bits, 1 << 17)          # q = 1 (mod 2^17): n up to 2^16
+    assert (1 << (bits - 1)) < q < (1 << bits)
+    for n in (32, 4096, 65536):
+        rows = [np.full(n, q - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64)]
+        alt = np.zeros(n, dtype=np.uint64); alt[::2] = q - 1; rows.append(alt)
+        rows.append(oracle.fill_synthetic(q, bits, 0, n))
+        a = np.stack(rows)
+        b = np.stack([rows[3], rows[0], rows[0], rows[2]])
+        plan = pkg.Plan(q, n)
+        A = plan.forward(a)
+        assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.rq_mul(a, b, want_evals=False)[0].reshape(-1),
+                              oracle.rq_mul(q, n, a, b)[0].reshape(-1)), (q, n)

@@ -121,6 +121,17 @@ __device__ __forceinline__ void stage_twiddles(Tw *ltw, const Tw *__restrict__ t
     }
 }
 
+// Global access as (wave-uniform 64-bit base) + (32-bit per-lane BYTE offset): the form the
+// saddr/voffset addressing mode takes, so an access costs one v_add_u32, not 64-bit arithmetic.
+template <typename T>
+__device__ __forceinline__ T ld_at(const u64 *ubase, u32 byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(ubase) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_at(u64 *ubase, u32 byte_off, T x) {
+    *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ubase) + byte_off) = x;
+}
+
 // one LDS-DMA wave-instruction: lane l copies 16 B from gsrc to LDS byte lds_dst + 16*l.
 // m0 is compiler-reserved: saved and restored inside the statement (guide §5.7).
 __device__ __forceinline__ void dma16(const void *gsrc, u32 lds_dst_uniform) {
@@ -191,9 +202,14 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     const u32 blk = blockIdx.x & ((1u << s0) - 1u);
     const u64 pg = (u64)(blockIdx.x >> s0);
     const u64 n = 1ull << a.log_n;
-    const u64 poly = pg * C::W + w;
-    const bool active = poly < a.batch;
-    const u64 base = poly * n + (u64)blk * C::M;
+    // polynomials of this group that exist (the last group of a batch may be ragged); lanes of
+    // a missing polynomial transform a copy of the group's first one and store nothing
+    const u32 live = (u32)min((u64)C::W, a.batch - pg * C::W);
+    // wave-uniform 64-bit base + 32-bit per-lane byte offsets (W*n*8 < 2^32)
+    const u64 ubase = pg * C::W * n + (u64)blk * C::M;
+    const u64 *__restrict__ pin = a.in + ubase;
+    u64 *__restrict__ pout = a.out + ubase;
+    const u32 off = ((w < live ? w : 0u) << a.log_n) * 8u;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     // twiddle source and index of round j (local stage ls0, high field bits H)
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
 
     u64 v[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = active ? a.in[base + field_of<C::A0>(tf, k)] : 0ull;
+    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, off + field_of<C::A0>(tf, k) * 8u);
     // Round 0's twiddles are the same for the whole workgroup (H = 0): read from the global
     // table at a wave-uniform address (scalar loads, SGPR operands).  The LDS copy is only
     // needed from round 1 on, so the barrier of the first exchange also publishes it.
@@ -244,8 +260,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     for (int i = 0; i < 16; i++) {
         const u32 e = i * C::TH + tid;
         const u32 wu = e >> LP, f = e & (C::M - 1);
-        const u64 p = pg * C::W + wu;
-        if (p < a.batch) a.out[p * n + (u64)blk * C::M + f] = lds[pad16(e)];
+        if (wu < live) st_at<u64>(pout, ((wu << a.log_n) + f) * 8u, lds[pad16(e)]);
     }
 }
 
@@ -262,9 +277,11 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     const u32 blk = blockIdx.x & ((1u << s0) - 1u);
     const u64 pg = (u64)(blockIdx.x >> s0);
     const u64 n = 1ull << a.log_n;
-    const u64 poly = pg * C::W + w;
-    const bool active = poly < a.batch;
-    const u64 base = poly * n + (u64)blk * C::M;
+    const u32 live = (u32)min((u64)C::W, a.batch - pg * C::W);   // see the forward kernel
+    const bool active = w < live;
+    const u64 ubase = pg * C::W * n + (u64)blk * C::M;
+    const u32 off = ((active ? w : 0u) << a.log_n) * 8u;
+    u64 *__restrict__ pout = a.out + ubase;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : a.tw; };
@@ -279,28 +296,26 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     static_assert(ALAST == 0, "first inverse window is the low 4 bits");
     u64 v[16];
     {
-        const u64 g0 = base + (u64)tf * 16;
-        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.in + g0);
+        const u32 g0 = off + tf * 128u;
+        const u64 *__restrict__ pin = a.in + ubase;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            ulonglong2 x{0, 0};
-            if (active) x = src[j];
+            const ulonglong2 x = ld_at<ulonglong2>(pin, g0 + j * 16u);
             v[2 * j] = x.x;
             v[2 * j + 1] = x.y;
         }
         if constexpr (MUL_IN) {
-            const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(a.in2 + g0);
-            ulonglong2 *dst2 = reinterpret_cast<ulonglong2 *>(a.out2 + g0);
+            const u64 *__restrict__ pin2 = a.in2 + ubase;
+            u64 *__restrict__ pout2 = a.out2 + ubase;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                ulonglong2 y{0, 0};
-                if (active) y = src2[j];
+                const ulonglong2 y = ld_at<ulonglong2>(pin2, g0 + j * 16u);
                 ulonglong2 p;
                 p.x = mul_mod_var(v[2 * j], y.x, a.mod);
                 p.y = mul_mod_var(v[2 * j + 1], y.y, a.mod);
                 v[2 * j] = p.x;
                 v[2 * j + 1] = p.y;
-                if (a.out2 && active) dst2[j] = p;
+                if (a.out2 && active) st_at<ulonglong2>(pout2, g0 + j * 16u, p);
             }
         }
     }
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     if (active) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            a.out[base + field_of<C::A0>(tf, k)] = FINAL ? canon2(v[k], m) : v[k];
+            st_at<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, FINAL ? canon2(v[k], m) : v[k]);
     }
 }
 
@@ -374,14 +389,18 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     const u32 lcg = lb - __builtin_ctz(CW);    // log2(column groups per polynomial)
     const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
     const u64 poly = (u64)(blockIdx.x >> lcg);
-    const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
+    // wave-uniform 64-bit base (SGPRs) + 32-bit per-lane element offsets: one v_add_u32 per
+    // access instead of 64-bit address arithmetic (a polynomial spans < 2^32 bytes)
+    const u64 ubase = (poly << a.log_n) + (u64)cg * CW;
+    const u64 *__restrict__ pin = a.in + ubase;
+    u64 *__restrict__ pout = a.out + ubase;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     const Tw *tw = ltw;
 
     u64 v[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = a.in[base + ((u64)field_of<C::A0>(tf, k) << lb)];
+    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<C::A0>(tf, k) << lb) + c) * 8u);
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];   // first pass: s0 = 0, blk = 0
 
     round_fwd<C::R0, WIDE>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
@@ -397,7 +416,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
-    for (int k = 0; k < 16; k++) a.out[base + ((u64)field_of<ALAST>(tf, k) << lb)] = v[k];  // lazy: < 4q, or < 6q (WIDE)
+    for (int k = 0; k < 16; k++) st_at<u64>(pout, ((field_of<ALAST>(tf, k) << lb) + c) * 8u, v[k]);  // lazy: < 4q, or < 6q (WIDE)
 }
 
 template <int LA, int CW>
@@ -410,7 +429,9 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     const u32 lcg = lb - __builtin_ctz(CW);
     const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
     const u64 poly = (u64)(blockIdx.x >> lcg);
-    const u64 base = (poly << a.log_n) + (u64)cg * CW + c;
+    const u64 ubase = (poly << a.log_n) + (u64)cg * CW;
+    const u64 *__restrict__ pin = a.in + ubase;
+    u64 *__restrict__ pout = a.out + ubase;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     const Tw *tw = ltw;
@@ -418,7 +439,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     constexpr int ALAST = C::a_of(C::NR - 1);
     u64 v[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = a.in[base + ((u64)field_of<ALAST>(tf, k) << lb)];  // < 2q
+    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<ALAST>(tf, k) << lb) + c) * 8u);  // < 2q
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
     __syncthreads();
 
@@ -434,8 +455,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     }
     round_inv<C::R0, true>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        a.out[base + ((u64)field_of<C::A0>(tf, k) << lb)] = canon2(v[k], m);
+    for (int k = 0; k < 16; k++) st_at<u64>(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, canon2(v[k], m));
 }
 
 // ---------------------------------------------------------------------------

@@ -90,12 +90,19 @@ __device__ __forceinline__ u64 mul_shoup_acc(u64 add, u64 y, u64 w, u64 wp, u64 
     const u64 qh = __umul64hi(y, wp);
     const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
     const u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
-    u64 acc = mad64(y0, w0, add);
-    acc = mad64(h0, n0, acc);
-    u64 H = mad64z(y0, w1);
-    H = mad64(y1, w0, H);
-    H = mad64(h0, n1, H);
-    H = mad64(h1, n0, H);
+    // One statement, the two chains interleaved by hand: between two dependent asm STATEMENTS the
+    // compiler inserts an s_nop (it assumes a dst-forwarding hazard for any inline asm), ~4 per
+    // butterfly; v_mad_u64_u32 has no such hazard.  Measured -0.5 % on the 2^16 transform.
+    u64 acc, H;
+    asm("v_mad_u64_u32 %0, vcc, %3, %5, %2\n\t"
+        "v_mad_u64_u32 %1, vcc, %3, %6, 0\n\t"
+        "v_mad_u64_u32 %0, vcc, %7, %9, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %4, %5, %1\n\t"
+        "v_mad_u64_u32 %1, vcc, %7, %10, %1\n\t"
+        "v_mad_u64_u32 %1, vcc, %8, %9, %1"
+        : "=&v"(acc), "=&v"(H)
+        : "v"(add), "v"(y0), "v"(y1), "v"(w0), "v"(w1), "v"(h0), "v"(h1), "v"(n0), "v"(n1)
+        : "vcc");
     const u32 hi = add32((u32)(acc >> 32), (u32)H);
     return ((u64)hi << 32) | (u32)acc;
 }

@@ -19,7 +19,7 @@ __device__ __forceinline__ u64 shl1add64(u64 a, u64 b) {  // (a<<1)+b
   u64 d; asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b)); return d;
 }
 
-struct Q { u64 q, q2, nq, neg4q, neg2q, q2p1, q4; };
+struct Q { u64 q, q2, nq, neg4q, neg2q, q2p1, q4, q4p1; };
 
 // variant 0: what the product kernels do today (compiler everything), [0,4q)
 __device__ __forceinline__ void bf_v0(u64& x, u64& y, u64 w, u64 wp, const Q& c) {
@@ -156,6 +156,80 @@ __device__ __forceinline__ void bf_v6(u64& x, u64& y, u64 w, u64 wp, const Q& c,
   x = s;
 }
 
+// ---- variants 8..11: what the kernels run today (v8) and three candidate trims ---------------
+// v8: v6 with both mad chains in ONE asm statement (no compiler s_nop between dependent asm)
+__device__ __forceinline__ u64 chain_s8(u64 u, u64 y, u64 w, u64 qh, const Q& c) {
+  u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+  u32 h0 = (u32)qh, h1 = (u32)(qh >> 32), n0 = (u32)c.nq, n1 = (u32)(c.nq >> 32);
+  u64 acc, H;
+  asm("v_mad_u64_u32 %0, vcc, %3, %5, %2\n\t"
+      "v_mad_u64_u32 %1, vcc, %3, %6, 0\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %9, %0\n\t"
+      "v_mad_u64_u32 %1, vcc, %4, %5, %1\n\t"
+      "v_mad_u64_u32 %1, vcc, %7, %10, %1\n\t"
+      "v_mad_u64_u32 %1, vcc, %8, %9, %1"
+      : "=&v"(acc), "=&v"(H)
+      : "v"(u), "v"(y0), "v"(y1), "v"(w0), "v"(w1), "v"(h0), "v"(h1), "v"(n0), "v"(n1) : "vcc");
+  return pack((u32)acc, add32((u32)(acc >> 32), (u32)H));
+}
+__device__ __forceinline__ void bf_v8(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) { u64 d = add64(x, c.neg4q); u = ((int)(u32)(d >> 32) < 0) ? x : d; }
+  u64 qh = __umul64hi(y, wp);
+  u64 s = chain_s8(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+// v9: v8 with the csub's compare forced to 32 bits (the compiler widens `(int)hi < 0` of a
+// 64-bit value to v_cmp_gt_i64, a half-rate op): the high word goes through an empty asm
+__device__ __forceinline__ u64 csub32(u64 x, u64 negm) {
+  const u64 d = add64(x, negm);
+  u32 d1 = (u32)(d >> 32);
+  asm("" : "+v"(d1));
+  return ((int)d1 < 0) ? x : d;
+}
+__device__ __forceinline__ void bf_v9(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) u = csub32(x, c.neg4q);
+  u64 qh = __umul64hi(y, wp);
+  u64 s = chain_s8(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+// v10: exact mulhi64 whose last step adds the zero-extended word with a multiply by 1
+// (v_mad_u64_u32 d, B.hi, 1, C) instead of v_mov + v_lshl_add_u64
+__device__ __forceinline__ u64 mad64_1(u32 a, u64 c) {
+  u64 d; asm("v_mad_u64_u32 %0, vcc, %1, 1, %2" : "=v"(d) : "v"(a), "v"(c) : "vcc"); return d;
+}
+__device__ __forceinline__ u64 mulhi64_v10(u64 y, u64 p) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), p0 = (u32)p, p1 = (u32)(p >> 32);
+  const u32 t = mulhi32(y0, p0);
+  const u64 A = mad64(y1, p0, (u64)t);
+  const u64 B = mad64(y0, p1, (u64)(u32)A);
+  const u64 C = mad64(y1, p1, (u64)(u32)(A >> 32));
+  return mad64_1((u32)(B >> 32), C);
+}
+__device__ __forceinline__ void bf_v10(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool do_csub) {
+  u64 u = x;
+  if (do_csub) u = csub32(x, c.neg4q);
+  u64 qh = mulhi64_v10(y, wp);
+  u64 s = chain_s8(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q2p1), ~s);
+  x = s;
+}
+// v11: APPROXIMATE quotient qh' = y1*p1 + hi32(y1*p0) + hi32(y0*p1) in [qh-2, qh]: the lazy
+// product is then in [0,4q); with q < 2^61 every stage does csub(4q) on x and all values stay
+// below 8q <= 2^64:  x' = u + t < 8q,  y' = u - t + 4q in (0, 8q).
+__device__ __forceinline__ void bf_v11(u64& x, u64& y, u64 w, u64 wp, const Q& c, bool) {
+  const u64 u = csub32(x, c.neg4q);
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), p0 = (u32)wp, p1 = (u32)(wp >> 32);
+  const u32 a = mulhi32(y1, p0), b = mulhi32(y0, p1);
+  const u64 qh = mad64_1(b, mad64(y1, p1, (u64)a));
+  u64 s = chain_s8(u, y, w, qh, c);
+  y = add64(shl1add64(u, c.q4p1), ~s);
+  x = s;
+}
+
 template <int V>
 __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
   u64 x[4], y[4];
@@ -172,6 +246,10 @@ __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
       if (V == 5) { bf_v5(x[j], y[j], w, wp, c, false); }
       if (V == 6) { bf_v6(x[j], y[j], w, wp, c, false); }
       if (V == 7) { bf_v7(x[j], y[j], w, wp, c, false); }
+      if (V == 8) bf_v8(x[j], y[j], w, wp, c, false);
+      if (V == 9) bf_v9(x[j], y[j], w, wp, c, false);
+      if (V == 10) bf_v10(x[j], y[j], w, wp, c, false);
+      if (V == 11) bf_v11(x[j], y[j], w, wp, c, false);
     }
     if (V >= 3) {  // second stage of the pair carries the csub
       i++;
@@ -182,6 +260,10 @@ __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
         if (V == 5) bf_v5(x[j], y[j], w, wp, c, true);
         if (V == 6) bf_v6(x[j], y[j], w, wp, c, true);
         if (V == 7) bf_v7(x[j], y[j], w, wp, c, true);
+        if (V == 8) bf_v8(x[j], y[j], w, wp, c, true);
+        if (V == 9) bf_v9(x[j], y[j], w, wp, c, true);
+        if (V == 10) bf_v10(x[j], y[j], w, wp, c, true);
+        if (V == 11) bf_v11(x[j], y[j], w, wp, c, true);
       }
     }
   }
@@ -198,22 +280,32 @@ static u64 href(u64 x, u64 y, u64 w, u64 q, int iters, u64* yo) {  // canonical 
   *yo = y; return x;
 }
 
+static void launch(int v, int blocks, int threads, u64* p, Q c, u64 w, u64 wp, int it) {
+  switch (v) {
+    case 0: k<0><<<blocks, threads>>>(p, c, w, wp, it); break;   case 1: k<1><<<blocks, threads>>>(p, c, w, wp, it); break;
+    case 2: k<2><<<blocks, threads>>>(p, c, w, wp, it); break;   case 3: k<3><<<blocks, threads>>>(p, c, w, wp, it); break;
+    case 4: k<4><<<blocks, threads>>>(p, c, w, wp, it); break;   case 5: k<5><<<blocks, threads>>>(p, c, w, wp, it); break;
+    case 6: k<6><<<blocks, threads>>>(p, c, w, wp, it); break;   case 7: k<7><<<blocks, threads>>>(p, c, w, wp, it); break;
+    case 8: k<8><<<blocks, threads>>>(p, c, w, wp, it); break;   case 9: k<9><<<blocks, threads>>>(p, c, w, wp, it); break;
+    case 10: k<10><<<blocks, threads>>>(p, c, w, wp, it); break; case 11: k<11><<<blocks, threads>>>(p, c, w, wp, it); break;
+  }
+}
+
 int main() {
   hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
   int cus = prop.multiProcessorCount; double clk = prop.clockRate * 1e3;
   u64 q = 2305843009211596801ull, w = 1681162619342215248ull;
   u64 wp = (u64)((((u128)w) << 64) / q);
-  Q c{q, 2 * q, (u64)0 - q, (u64)0 - 4 * q, (u64)0 - 2 * q, 2 * q + 1, 4 * q};
+  Q c{q, 2 * q, (u64)0 - q, (u64)0 - 4 * q, (u64)0 - 2 * q, 2 * q + 1, 4 * q, 4 * q + 1};
   u64* p; hipMalloc(&p, 4096 * 8);
   std::vector<u64> h(512), o(512);
   for (int i = 0; i < 512; i++) h[i] = (0x9E3779B97F4A7C15ull * (i + 1)) ^ (0xD1B54A32D192ED03ull * (i + 7));
-  const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo", "v5 no-mov mulhi+pack", "v6 no-mov pack only", "v7 shift-zext mulhi"};
-  for (int v = 3; v < 8; v++) {
+  const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo", "v5 no-mov mulhi+pack", "v6 no-mov pack only", "v7 shift-zext mulhi", "v8 fused chains (prod)", "v9 v8+cmp32", "v10 v9+mad-by-1 mulhi", "v11 approx qh, csub/1"};
+  for (int v = 6; v < 12; v++) {
     // correctness at 6 iterations (even, so v3/v4 pairs are whole)
     hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
     int it = 6;
-    switch (v) { case 0: k<0><<<1, 64>>>(p, c, w, wp, it); break; case 1: k<1><<<1, 64>>>(p, c, w, wp, it); break;
-      case 2: k<2><<<1, 64>>>(p, c, w, wp, it); break; case 3: k<3><<<1, 64>>>(p, c, w, wp, it); break; case 4: k<4><<<1, 64>>>(p, c, w, wp, it); break; case 5: k<5><<<1, 64>>>(p, c, w, wp, it); break; case 6: k<6><<<1, 64>>>(p, c, w, wp, it); break; case 7: k<7><<<1, 64>>>(p, c, w, wp, it); break; }
+    launch(v, 1, 64, p, c, w, wp, it);
     hipMemcpy(o.data(), p, 512 * 8, hipMemcpyDeviceToHost);
     int bad = 0; u64 mx = 0;
     for (int t = 0; t < 64; t++) for (int j = 0; j < 4; j++) {
@@ -229,8 +321,7 @@ int main() {
       float best = 1e30f;
       for (int r = 0; r < 4; r++) {
         hipEventRecord(e0);
-        switch (v) { case 0: k<0><<<blocks, threads>>>(p, c, w, wp, iters); break; case 1: k<1><<<blocks, threads>>>(p, c, w, wp, iters); break;
-          case 2: k<2><<<blocks, threads>>>(p, c, w, wp, iters); break; case 3: k<3><<<blocks, threads>>>(p, c, w, wp, iters); break; case 4: k<4><<<blocks, threads>>>(p, c, w, wp, iters); break; case 5: k<5><<<blocks, threads>>>(p, c, w, wp, iters); break; case 6: k<6><<<blocks, threads>>>(p, c, w, wp, iters); break; case 7: k<7><<<blocks, threads>>>(p, c, w, wp, iters); break; }
+        launch(v, blocks, threads, p, c, w, wp, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
       }

@@ -33,6 +33,8 @@ FHE_E_NO_DEVICE = -6
 FHE_E_PARAM_MISMATCH = -7
 FHE_E_NOT_CANONICAL = -8
 FHE_E_INVALID = -9
+# flags of the N3 batch surfaces (include/fhe_ntt.h)
+FHE_A_IS_EVALS, FHE_B_IS_EVALS, FHE_OUT_EVALS = 1, 2, 4
 
 # every symbol include/fhe_ntt.h declares (tests check the .so exports them all)
 EXPORTS = [
@@ -177,10 +179,10 @@ def load_library():
     L.fhe_tn_mul_dev.argtypes = [_u64, _vp, _vp, _vp, _sz, _vp]
     L.fhe_tggsw_external_product.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz]
     L.fhe_tggsw_external_product_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
-    L.fhe_tr_dot_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _vp]
-    L.fhe_tr_mul_r_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _vp]
-    L.fhe_glev_mul_dev.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
-    L.fhe_glwe_key_switch_dev.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_tr_dot_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
+    L.fhe_tr_mul_r_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
+    L.fhe_glev_mul_dev.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]
+    L.fhe_glwe_key_switch_dev.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]
     L.fhe_rq_add_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
     L.fhe_rq_sub_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
     L.fhe_rq_neg_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]

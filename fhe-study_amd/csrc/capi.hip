@@ -252,6 +252,11 @@ static std::mutex g_ws_lock;
 static Workspace g_ws[2][kMaxDevices];
 static std::vector<void *> g_ws_retired;
 
+std::mutex &fhe_host_workspace_lock() {
+    static std::mutex m;
+    return m;
+}
+
 int fhe_workspace_get(int slot, size_t bytes, void **out) {
     int dev = 0;
     int rc = fhe_current_device(&dev);

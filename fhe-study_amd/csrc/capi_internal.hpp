@@ -40,6 +40,10 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp);
 fhe::u64 fhe_batch_tile_for(const fhe_ntt_plan *plan);
 // grow-only per-device scratch; slot 0 = fhe_rq_mul_dev, slot 1 = zring
 int fhe_workspace_get(int slot, size_t bytes, void **out);
+// Serialises HOST-buffer entry points that use the shared workspace (each runs on its own
+// per-thread stream, so two host threads would otherwise overlap in it).  Held from the first
+// launch until the results are back on the host.
+std::mutex &fhe_host_workspace_lock();
 void fhe_workspace_free_all();
 
 static inline bool fhe_misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }

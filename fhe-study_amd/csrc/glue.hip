@@ -223,90 +223,111 @@ extern "C" int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsig
 }
 
 // ---- N3 ------------------------------------------------------------------------------------
+// flags (include/fhe_ntt.h): FHE_A_IS_EVALS / FHE_B_IS_EVALS = that operand is already in the NTT
+// domain (the generalisation of Rq.evals, ring_nq.rs:24-26: a key transformed once serves every
+// later call); FHE_OUT_EVALS = leave the result there.
+static int bad_flags(const char *who, unsigned flags, unsigned allowed) {
+    if (flags & ~allowed) return fhe_fail(FHE_E_INVALID, "%s: unsupported flags 0x%x (allowed 0x%x)", who, flags, allowed);
+    return FHE_OK;
+}
+
 // c[b] = sum_{i<k} a[b][i] * b[b][i];  a, b: [batch][k][n];  c: [batch][n]
-extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, unsigned k, size_t batch, void *stream) {
+extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, unsigned k, size_t batch, unsigned flags, void *stream) {
     if (!plan) return fhe_fail(FHE_E_NULL, "fhe_tr_dot_dev: plan is NULL");
+    int rc = bad_flags("fhe_tr_dot_dev", flags, FHE_A_IS_EVALS | FHE_B_IS_EVALS | FHE_OUT_EVALS);
+    if (rc != FHE_OK) return rc;
     if (batch == 0 || k == 0) return FHE_OK;
     if (!d_a || !d_b || !d_c) return fhe_fail(FHE_E_NULL, "fhe_tr_dot_dev: NULL buffer");
     REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_b); REQUIRE_ALIGNED(d_c);
     fhe::DevicePlan dp;
-    int rc = fhe_device_plan(plan, &dp);
-    if (rc != FHE_OK) return rc;
+    if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n, rows = batch * k;
+    const bool a_ev = flags & FHE_A_IS_EVALS, b_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
     void *w = nullptr;
     if ((rc = fhe_workspace_get(1, (2 * rows + batch) * n * 8, &w)) != FHE_OK) return rc;
-    u64 *A = (u64 *)w, *B = A + rows * n, *C = B + rows * n;
-    if ((rc = fwd(plan, dp, (const u64 *)d_a, A, rows, st)) != FHE_OK) return rc;
-    if ((rc = fwd(plan, dp, (const u64 *)d_b, B, rows, st)) != FHE_OK) return rc;
+    u64 *WA = (u64 *)w, *WB = WA + rows * n, *WC = WB + rows * n;
+    const u64 *A = (const u64 *)d_a, *B = (const u64 *)d_b;
+    if (!a_ev) { if ((rc = fwd(plan, dp, A, WA, rows, st)) != FHE_OK) return rc; A = WA; }
+    if (!b_ev) { if ((rc = fwd(plan, dp, B, WB, rows, st)) != FHE_OK) return rc; B = WB; }
+    u64 *C = out_ev ? (u64 *)d_c : WC;
     // T = k terms, nc = 1 output row, "G" = A per batch element
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * n)), dim3(256), 0, st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
-    return inv(plan, dp, C, (u64 *)d_c, batch, st);
+    return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_c, batch, st);
 }
 
 // out[b][i] = a[b][i] * p[b], i < rows;  a, out: [batch][rows][n];  p: [batch][n]
-extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_p, void *d_out, unsigned rows, size_t batch, void *stream) {
+extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_p, void *d_out, unsigned rows, size_t batch, unsigned flags, void *stream) {
     if (!plan) return fhe_fail(FHE_E_NULL, "fhe_tr_mul_r_dev: plan is NULL");
+    int rc = bad_flags("fhe_tr_mul_r_dev", flags, FHE_A_IS_EVALS | FHE_B_IS_EVALS | FHE_OUT_EVALS);
+    if (rc != FHE_OK) return rc;
     if (batch == 0 || rows == 0) return FHE_OK;
     if (!d_a || !d_p || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tr_mul_r_dev: NULL buffer");
     REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_p); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
-    int rc = fhe_device_plan(plan, &dp);
-    if (rc != FHE_OK) return rc;
+    if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n, total = batch * rows;
+    const bool a_ev = flags & FHE_A_IS_EVALS, p_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
     void *w = nullptr;
     if ((rc = fhe_workspace_get(1, (2 * total + batch) * n * 8, &w)) != FHE_OK) return rc;
-    u64 *A = (u64 *)w, *C = A + total * n, *P = C + total * n;
-    if ((rc = fwd(plan, dp, (const u64 *)d_a, A, total, st)) != FHE_OK) return rc;
-    if ((rc = fwd(plan, dp, (const u64 *)d_p, P, batch, st)) != FHE_OK) return rc;
+    u64 *WA = (u64 *)w, *WC = WA + total * n, *WP = WC + total * n;
+    const u64 *A = (const u64 *)d_a, *P = (const u64 *)d_p;
+    if (!a_ev) { if ((rc = fwd(plan, dp, A, WA, total, st)) != FHE_OK) return rc; A = WA; }
+    if (!p_ev) { if ((rc = fwd(plan, dp, P, WP, batch, st)) != FHE_OK) return rc; P = WP; }
+    u64 *C = out_ev ? (u64 *)d_out : WC;
     // T = 1, nc = rows: out[b][c] = A[b][c] * P[b]
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(total * n)), dim3(256), 0, st, (const u64 *)A, (const u64 *)P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(total * n)), dim3(256), 0, st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
-    return inv(plan, dp, C, (u64 *)d_out, total, st);
+    return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_out, total, st);
 }
 
 // shared worker: out[b][c] = sum_{t<T} key[t][c] * v[b][t]; key [T][nc][n] (one for the batch)
-static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *d_key, const u64 *d_v, u64 *d_out_evals_then_coeffs,
-                     u32 T, u32 nc, u64 batch, u64 *ws, hipStream_t st) {
+static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *d_key, bool key_is_evals, const u64 *d_v, bool v_is_evals,
+                     u64 *d_out, bool out_evals, u32 T, u32 nc, u64 batch, u64 *ws, hipStream_t st) {
     const u64 n = plan->n;
-    u64 *K = ws, *V = K + (u64)T * nc * n;
+    u64 *WK = ws, *WV = WK + (u64)T * nc * n;
+    const u64 *K = d_key, *V = d_v;
     int rc;
-    if ((rc = fwd(plan, dp, d_key, K, (u64)T * nc, st)) != FHE_OK) return rc;
-    if ((rc = fwd(plan, dp, d_v, V, batch * T, st)) != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * nc * n)), dim3(256), 0, st, (const u64 *)K, (const u64 *)V, d_out_evals_then_coeffs, batch, (u32)n, T, nc, (u64)0, plan->mod);
+    if (!key_is_evals) { if ((rc = fwd(plan, dp, d_key, WK, (u64)T * nc, st)) != FHE_OK) return rc; K = WK; }
+    if (!v_is_evals) { if ((rc = fwd(plan, dp, d_v, WV, batch * T, st)) != FHE_OK) return rc; V = WV; }
+    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * nc * n)), dim3(256), 0, st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
-    return inv(plan, dp, d_out_evals_then_coeffs, d_out_evals_then_coeffs, batch * nc, st);
+    return out_evals ? FHE_OK : inv(plan, dp, d_out, d_out, batch * nc, st);
 }
 
 // GLev x Vec<R> -> GLWE: glev [l][k+1][n] (a key, shared), v [batch][l][n], out [batch][k+1][n]
-extern "C" int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l, const void *d_glev, const void *d_v, void *d_out, size_t batch, void *stream) {
+extern "C" int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l, const void *d_glev, const void *d_v, void *d_out, size_t batch, unsigned flags, void *stream) {
     if (!plan) return fhe_fail(FHE_E_NULL, "fhe_glev_mul_dev: plan is NULL");
+    int rc = bad_flags("fhe_glev_mul_dev", flags, FHE_A_IS_EVALS | FHE_B_IS_EVALS | FHE_OUT_EVALS);
+    if (rc != FHE_OK) return rc;
     if (batch == 0) return FHE_OK;
     if (l == 0) return fhe_fail(FHE_E_INVALID, "fhe_glev_mul_dev: l = 0");
     if (!d_glev || !d_v || !d_out) return fhe_fail(FHE_E_NULL, "fhe_glev_mul_dev: NULL buffer");
     REQUIRE_ALIGNED(d_glev); REQUIRE_ALIGNED(d_v); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
-    int rc = fhe_device_plan(plan, &dp);
-    if (rc != FHE_OK) return rc;
+    if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
     const u64 n = plan->n;
     void *w = nullptr;
     if ((rc = fhe_workspace_get(1, ((u64)l * (k + 1) + batch * l) * n * 8, &w)) != FHE_OK) return rc;
-    return keyed_mac(plan, dp, (const u64 *)d_glev, (const u64 *)d_v, (u64 *)d_out, l, k + 1, batch, (u64 *)w, (hipStream_t)stream);
+    return keyed_mac(plan, dp, (const u64 *)d_glev, flags & FHE_A_IS_EVALS, (const u64 *)d_v, flags & FHE_B_IS_EVALS, (u64 *)d_out,
+                     flags & FHE_OUT_EVALS, l, k + 1, batch, (u64 *)w, (hipStream_t)stream);
 }
 
 // GLWE::key_switch: glwe [batch][k+1][n]; ksk [k][l][k+1][n] (shared); out [batch][k+1][n]
 extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const void *d_glwe, const void *d_ksk,
-                                       void *d_out, size_t batch, void *stream) {
+                                       void *d_out, size_t batch, unsigned flags, void *stream) {
     if (!plan) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch_dev: plan is NULL");
+    // only the key may be pre-transformed: the ciphertext is decomposed, and the tail subtracts, in coefficients
+    int rc = bad_flags("fhe_glwe_key_switch_dev", flags, FHE_A_IS_EVALS);
+    if (rc != FHE_OK) return rc;
     if (batch == 0) return FHE_OK;
     if (k == 0 || l == 0 || beta < 2) return fhe_fail(FHE_E_INVALID, "fhe_glwe_key_switch_dev: need k, l >= 1, beta >= 2");
     if (!d_glwe || !d_ksk || !d_out) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch_dev: NULL buffer");
     REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_ksk); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
-    int rc = fhe_device_plan(plan, &dp);
-    if (rc != FHE_OK) return rc;
+    if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n;
     const u32 k1 = k + 1, T = k * l;
@@ -318,7 +339,7 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     hipLaunchKernelGGL(fhe::decompose_kernel, dim3(fhe_ew_grid(batch * k * n)), dim3(256), 0, st, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)n, (u64)plan->q, (u32)beta, (u32)l, (u32)k, (u64)k1 * n);
     LAUNCH_OK("decompose_kernel");
     // ksk viewed as [T = k*l][k1][n]; DEC as [batch][T][n]
-    if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, DEC, RHS, T, k1, batch, WS, st)) != FHE_OK) return rc;
+    if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, flags & FHE_A_IS_EVALS, DEC, false, RHS, false, T, k1, batch, WS, st)) != FHE_OK) return rc;
     hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(fhe_ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
     LAUNCH_OK("ks_tail_kernel");
     return FHE_OK;

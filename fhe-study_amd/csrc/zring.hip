@@ -513,6 +513,7 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
 namespace {
 struct HostStage {
     std::vector<void *> bufs;
+    std::lock_guard<std::mutex> ws_lock{fhe_host_workspace_lock()};   // held until the destructor body has freed the buffers
     ~HostStage() { for (void *p : bufs) if (p) (void)hipFree(p); }
     int up(const void *h, size_t bytes, void **d) {
         *d = nullptr;

@@ -197,25 +197,34 @@ int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l, const voi
 
 /* ---- rows N3 / N4: batch surfaces and element-wise glue, device-resident ----
  * Sums of products are accumulated in the NTT domain and transformed back once; arithmetic
- * mod q is exact, so the words equal the reference's sum of canonical products. */
+ * mod q is exact, so the words equal the reference's sum of canonical products.
+ *
+ * `flags` generalise the cached `Rq.evals` (arith/src/ring_nq.rs:24-26,590-599) to the batch
+ * surfaces: an operand that is already in the NTT domain (fhe_ntt_forward_dev of it, e.g. a
+ * key transformed once) is not transformed again, and a result can be left there for the next
+ * product.  Output buffers must not overlap the inputs. */
+#define FHE_A_IS_EVALS 1u /* first operand (a / glev / ksk) holds NTT-domain values          */
+#define FHE_B_IS_EVALS 2u /* second operand (b / p / v) holds NTT-domain values              */
+#define FHE_OUT_EVALS  4u /* leave the result in the NTT domain (no inverse transform)       */
 
 /* TR<Rq> . TR<Rq>, arith/src/tuple_ring.rs:117-134: c[b] = sum_{i<k} a[b][i] * b[b][i].
  * a, b: [batch][k][n]; c: [batch][n]. */
 int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, unsigned k,
-                   size_t batch, void *hip_stream);
+                   size_t batch, unsigned flags, void *hip_stream);
 /* TR<Rq> x Rq (tuple_ring.rs:137-155) and GLWE<Rq> x Rq (gfhe/src/glwe.rs:263-280):
  * out[b][i] = a[b][i] * p[b], i < rows.  a, out: [batch][rows][n]; p: [batch][n]. */
 int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_p, void *d_out,
-                     unsigned rows, size_t batch, void *hip_stream);
+                     unsigned rows, size_t batch, unsigned flags, void *hip_stream);
 /* GLev<Rq> x Vec<Rq> -> GLWE, gfhe/src/glev.rs:68-80: out[b][c] = sum_{d<l} glev[d][c] * v[b][d].
  * glev: [l][k+1][n] (a key: shared by the batch); v: [batch][l][n]; out: [batch][k+1][n]. */
 int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l, const void *d_glev,
-                     const void *d_v, void *d_out, size_t batch, void *hip_stream);
+                     const void *d_v, void *d_out, size_t batch, unsigned flags, void *hip_stream);
 /* GLWE<Rq>::key_switch, gfhe/src/glwe.rs:126-137: (0, b) - sum_{i<k} ksk[i] * decompose(a_i, beta, l).
- * glwe, out: [batch][k+1][n] as (a_0..a_{k-1}, b); ksk: [k][l][k+1][n] (shared). */
+ * glwe, out: [batch][k+1][n] as (a_0..a_{k-1}, b); ksk: [k][l][k+1][n] (shared).
+ * flags: FHE_A_IS_EVALS only (the key; the ciphertext is decomposed in coefficients). */
 int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l,
                             const void *d_glwe, const void *d_ksk, void *d_out, size_t batch,
-                            void *hip_stream);
+                            unsigned flags, void *hip_stream);
 
 /* Rq + Rq, Rq - Rq, -Rq (ring_nq.rs:406-488,551-561), Rq::mul_by_u64 (ring_nq.rs:274-281). */
 int fhe_rq_add_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, size_t batch, void *hip_stream);

@@ -138,11 +138,13 @@ def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
     assert L.fhe_bfv_relinearize_dev(Q16, 16, Q16 - 1, d, d, d, 1, None) == B.FHE_E_BAD_Q  # pq < q
     assert L.fhe_tggsw_external_product_dev(64, 4, 65, d, d, d, 1, None) == B.FHE_E_INVALID
     assert L.fhe_rq_decompose_dev(Q16, 8, 1, 4, d, d, 1, None) == B.FHE_E_INVALID
-    assert L.fhe_glwe_key_switch_dev(plan.handle, 0, 2, 4, d, d, d, 1, None) == B.FHE_E_INVALID
-    assert L.fhe_tr_dot_dev(None, d, d, d, 2, 1, None) == B.FHE_E_NULL
+    assert L.fhe_glwe_key_switch_dev(plan.handle, 0, 2, 4, d, d, d, 1, 0, None) == B.FHE_E_INVALID
+    assert L.fhe_glwe_key_switch_dev(plan.handle, 1, 2, 4, d, d, d, 1, B.FHE_OUT_EVALS, None) == B.FHE_E_INVALID  # key flag only
+    assert L.fhe_glev_mul_dev(plan.handle, 1, 4, d, d, d, 1, 8, None) == B.FHE_E_INVALID                        # unknown flag bit
+    assert L.fhe_tr_dot_dev(None, d, d, d, 2, 1, 0, None) == B.FHE_E_NULL
     assert L.fhe_rq_add_dev(plan.handle, None, d, d, 1, None) == B.FHE_E_NULL
     assert L.fhe_mul_div_round_dev(Q16, 8, d, 1, 0, d, 1, None) == B.FHE_E_BAD_Q           # den = 0
     # empty batches are no-ops everywhere
     assert L.fhe_tn_mul_dev(8, None, None, None, 0, None) == 0
     assert L.fhe_bfv_mul_dev(Q16, 16, 2, Q16 * Q16 * Q16, None, None, None, 0, None) == 0
-    assert L.fhe_tr_dot_dev(plan.handle, None, None, None, 2, 0, None) == 0
+    assert L.fhe_tr_dot_dev(plan.handle, None, None, None, 2, 0, 0, None) == 0

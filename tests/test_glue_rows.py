@@ -171,9 +171,9 @@ def test_gpu_tr_dot_and_mul_r(pkg, oracle, q, n, k, batch):
     p = rng.integers(0, q, (batch, n), dtype=np.uint64)
     da, db, dp = _dev(a), _dev(b), _dev(p)
     dc = torch.empty((batch, n), dtype=torch.int64, device="cuda")
-    chk(L.fhe_tr_dot_dev(plan.handle, da.data_ptr(), db.data_ptr(), dc.data_ptr(), k, batch, None))
+    chk(L.fhe_tr_dot_dev(plan.handle, da.data_ptr(), db.data_ptr(), dc.data_ptr(), k, batch, 0, None))
     dout = torch.empty_like(da)
-    chk(L.fhe_tr_mul_r_dev(plan.handle, da.data_ptr(), dp.data_ptr(), dout.data_ptr(), k, batch, None))
+    chk(L.fhe_tr_mul_r_dev(plan.handle, da.data_ptr(), dp.data_ptr(), dout.data_ptr(), k, batch, 0, None))
     torch.cuda.synchronize()
     wc = np.empty((batch, n), dtype=np.uint64)
     wo = np.empty_like(a)
@@ -182,6 +182,25 @@ def test_gpu_tr_dot_and_mul_r(pkg, oracle, q, n, k, batch):
         oracle.glue("tr_mul_r", q, n, k, a[i], p[i], wo[i])
     assert np.array_equal(_host(dc), wc)
     assert np.array_equal(_host(dout), wo)
+
+    # operands kept in the NTT domain (the generalised Rq.evals): same words, and a result left
+    # there equals the forward transform of the coefficient result
+    B = pkg.binding
+    dA, dB, dP = (torch.empty_like(x) for x in (da, db, dp))
+    plan.forward_dev(da.data_ptr(), dA.data_ptr(), batch * k)
+    plan.forward_dev(db.data_ptr(), dB.data_ptr(), batch * k)
+    plan.forward_dev(dp.data_ptr(), dP.data_ptr(), batch)
+    dc2, dout2 = torch.empty_like(dc), torch.empty_like(dout)
+    chk(L.fhe_tr_dot_dev(plan.handle, dA.data_ptr(), db.data_ptr(), dc2.data_ptr(), k, batch, B.FHE_A_IS_EVALS, None))
+    assert np.array_equal(_host(dc2), wc)
+    chk(L.fhe_tr_dot_dev(plan.handle, dA.data_ptr(), dB.data_ptr(), dc2.data_ptr(), k, batch,
+                         B.FHE_A_IS_EVALS | B.FHE_B_IS_EVALS | B.FHE_OUT_EVALS, None))
+    assert np.array_equal(_host(dc2), oracle.ntt(q, n, wc))
+    chk(L.fhe_tr_mul_r_dev(plan.handle, da.data_ptr(), dP.data_ptr(), dout2.data_ptr(), k, batch, B.FHE_B_IS_EVALS, None))
+    assert np.array_equal(_host(dout2), wo)
+    chk(L.fhe_tr_mul_r_dev(plan.handle, dA.data_ptr(), dp.data_ptr(), dout2.data_ptr(), k, batch,
+                           B.FHE_A_IS_EVALS | B.FHE_OUT_EVALS, None))
+    assert np.array_equal(_host(dout2), oracle.ntt(q, n, wo.reshape(-1, n)).reshape(wo.shape))
 
 
 @pytest.mark.gpu
@@ -198,19 +217,35 @@ def test_gpu_glev_mul_and_key_switch(pkg, oracle, q, n, k, beta, l, batch):
     v = rng.integers(0, q, (batch, l, n), dtype=np.uint64)
     dout = torch.empty((batch, k + 1, n), dtype=torch.int64, device="cuda")
     dglev, dv = _dev(glev), _dev(v)      # keep the device copies alive across the asynchronous call
-    chk(L.fhe_glev_mul_dev(plan.handle, k, l, dglev.data_ptr(), dv.data_ptr(), dout.data_ptr(), batch, None))
+    chk(L.fhe_glev_mul_dev(plan.handle, k, l, dglev.data_ptr(), dv.data_ptr(), dout.data_ptr(), batch, 0, None))
     torch.cuda.synchronize()
     want = np.empty((batch, k + 1, n), dtype=np.uint64)
     for i in range(batch):
         oracle.glue("glev_mul", q, n, k, l, glev, v[i], want[i])
     assert np.array_equal(_host(dout), want)
+    # the key transformed once and reused (FHE_A_IS_EVALS), then both operands resident
+    B = pkg.binding
+    dGLEV, dV = torch.empty_like(dglev), torch.empty_like(dv)
+    plan.forward_dev(dglev.data_ptr(), dGLEV.data_ptr(), l * (k + 1))
+    plan.forward_dev(dv.data_ptr(), dV.data_ptr(), batch * l)
+    dout.zero_()
+    chk(L.fhe_glev_mul_dev(plan.handle, k, l, dGLEV.data_ptr(), dv.data_ptr(), dout.data_ptr(), batch, B.FHE_A_IS_EVALS, None))
+    assert np.array_equal(_host(dout), want)
+    chk(L.fhe_glev_mul_dev(plan.handle, k, l, dGLEV.data_ptr(), dV.data_ptr(), dout.data_ptr(), batch,
+                           B.FHE_A_IS_EVALS | B.FHE_B_IS_EVALS | B.FHE_OUT_EVALS, None))
+    assert np.array_equal(_host(dout), oracle.ntt(q, n, want.reshape(-1, n)).reshape(want.shape))
 
     glwe = rng.integers(0, q, (batch, k + 1, n), dtype=np.uint64)
     glwe[0, 0, :4] = [0, 1, (1 << min(l, 62)) % q, q - 1]           # both decompose branches
     ksk = rng.integers(0, q, (k, l, k + 1, n), dtype=np.uint64)
     dglwe, dksk = _dev(glwe), _dev(ksk)
-    chk(L.fhe_glwe_key_switch_dev(plan.handle, k, beta, l, dglwe.data_ptr(), dksk.data_ptr(), dout.data_ptr(), batch, None))
+    chk(L.fhe_glwe_key_switch_dev(plan.handle, k, beta, l, dglwe.data_ptr(), dksk.data_ptr(), dout.data_ptr(), batch, 0, None))
+    dKSK, dout_k = torch.empty_like(dksk), torch.empty_like(dout)
+    plan.forward_dev(dksk.data_ptr(), dKSK.data_ptr(), k * l * (k + 1))
+    chk(L.fhe_glwe_key_switch_dev(plan.handle, k, beta, l, dglwe.data_ptr(), dKSK.data_ptr(), dout_k.data_ptr(), batch,
+                                  B.FHE_A_IS_EVALS, None))
     torch.cuda.synchronize()
+    assert torch.equal(dout, dout_k)                     # pre-transformed key switching key: same words
     for i in range(batch):
         oracle.glue("key_switch", q, n, k, beta, l, glwe[i], ksk, want[i])
     assert np.array_equal(_host(dout), want)

@@ -355,3 +355,48 @@ def test_moduli_across_bit_lengths_and_lazy_range_boundaries(pkg, oracle, bits):
         assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (q, n)
         assert np.array_equal(plan.rq_mul(a, b, want_evals=False)[0].reshape(-1),
                               oracle.rq_mul(q, n, a, b)[0].reshape(-1)), (q, n)
+
+
+@pytest.mark.gpu
+def test_host_entry_points_are_reentrant(pkg, oracle):
+    """cargo runs the reference's tests on parallel threads, so a shim would enter the library
+    concurrently (SURVEY.md §8b "Threading").  Eight host threads mix transforms, products and the
+    N1/N2 host wrappers (which share one workspace) at different (q, n); every result is compared
+    with the oracle computed up front.  ctypes releases the GIL during the calls."""
+    import threading
+    B = pkg.binding
+    rng = np.random.default_rng(77)
+    U64 = 1 << 64
+    jobs = []
+    for i, (q, n) in enumerate([(Q16, 512), (Q61, 1024), (Q61, 4096), (Q16, 16)]):
+        a = rng.integers(0, q, (5 + i, n), dtype=np.uint64)
+        b = rng.integers(0, q, (5 + i, n), dtype=np.uint64)
+        plan = pkg.Plan(q, n)
+        jobs.append((lambda p=plan, x=a: p.forward(x), oracle.ntt(q, n, a)))
+        jobs.append((lambda p=plan, x=a, y=b: p.rq_mul(x, y)[0], oracle.rq_mul(q, n, a, b)[0]))
+    for n in (64, 1024):
+        a = rng.integers(0, U64, (3, n), dtype=np.uint64)
+        b = rng.integers(0, U64, (3, n), dtype=np.uint64)
+        jobs.append((lambda n=n, x=a, y=b: B.tn_mul(n, x, y), oracle.tn_mul(n, a, b)))
+        ia = rng.integers(0, Q16, (4, n), dtype=np.int64)
+        ib = rng.integers(0, Q16, (4, n), dtype=np.int64)
+        jobs.append((lambda n=n, x=ia, y=ib: B.r_naive_mul(n, x, y), oracle.r_naive_mul(n, ia, ib)))
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                for j in range(tid, len(jobs), 3):     # overlapping subsets: same plan on several threads
+                    fn, want = jobs[(j + rep) % len(jobs)]
+                    got = np.asarray(fn())
+                    if not np.array_equal(got.reshape(want.shape), want):
+                        errors.append((tid, rep, j))
+        except Exception as e:                           # noqa: BLE001 - reported below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]

@@ -18,6 +18,7 @@
 
 #include "capi_internal.hpp"
 #include "zq_device.hpp"
+#include "mac_kernel.hpp"
 
 using fhe::Mod;
 using fhe::u32;
@@ -115,27 +116,6 @@ __global__ __launch_bounds__(256) void decompose_kernel(const u64 *__restrict__ 
                 }
             }
         }
-    }
-}
-
-// out[b][c][j] = sum_{t<T} G[g_b][t][c][j] * D[b][t][j]  (mod q); G is shared by the batch
-// (gstride = 0) or per batch element (gstride = T*nc*n).  D may have a single shared row per
-// batch element broadcast over c (that is the shape of TR x R: T = 1, G per batch).
-__global__ __launch_bounds__(256) void mac_rows_kernel(const u64 *__restrict__ G, const u64 *__restrict__ D,
-                                                       u64 *__restrict__ out, u64 batch, u32 n, u32 T, u32 nc,
-                                                       u64 gstride, Mod m) {
-    const u64 total = batch * nc * n, stride = (u64)gridDim.x * 256;
-    for (u64 idx = (u64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
-        const u32 j = (u32)(idx % n);
-        const u64 bc = idx / n;
-        const u32 c = (u32)(bc % nc);
-        const u64 b = bc / nc;
-        const u64 *g = G + b * gstride + (u64)c * n + j;
-        const u64 *d = D + b * T * n + j;
-        u64 acc = 0;
-        for (u32 t = 0; t < T; t++)
-            acc = canon2(acc + mul_mod_var(g[(u64)t * nc * n], d[(u64)t * n], m), m);
-        out[idx] = acc;
     }
 }
 
@@ -252,7 +232,7 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     if (!b_ev) { if ((rc = fwd(plan, dp, B, WB, rows, st)) != FHE_OK) return rc; B = WB; }
     u64 *C = out_ev ? (u64 *)d_c : WC;
     // T = k terms, nc = 1 output row, "G" = A per batch element
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * n)), dim3(256), 0, st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
+    hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, 1, n))), dim3(256), 0, st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_c, batch, st);
 }
@@ -278,7 +258,7 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     if (!p_ev) { if ((rc = fwd(plan, dp, P, WP, batch, st)) != FHE_OK) return rc; P = WP; }
     u64 *C = out_ev ? (u64 *)d_out : WC;
     // T = 1, nc = rows: out[b][c] = A[b][c] * P[b]
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(total * n)), dim3(256), 0, st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
+    hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, rows, n))), dim3(256), 0, st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_out, total, st);
 }
@@ -292,7 +272,7 @@ static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const 
     int rc;
     if (!key_is_evals) { if ((rc = fwd(plan, dp, d_key, WK, (u64)T * nc, st)) != FHE_OK) return rc; K = WK; }
     if (!v_is_evals) { if ((rc = fwd(plan, dp, d_v, WV, batch * T, st)) != FHE_OK) return rc; V = WV; }
-    hipLaunchKernelGGL(fhe::mac_rows_kernel, dim3(fhe_ew_grid(batch * nc * n)), dim3(256), 0, st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
+    hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, nc, n))), dim3(256), 0, st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
     LAUNCH_OK("mac_rows_kernel");
     return out_evals ? FHE_OK : inv(plan, dp, d_out, d_out, batch * nc, st);
 }

@@ -192,7 +192,11 @@ __device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u
     for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
 }
 
-template <int LP, bool FINAL, bool WIDE>
+// DIGITS (single-pass sizes only): the input is `batch / digit_l` rows of 64-bit words and output
+// polynomial p is the transform of bit digit_l-1-(p % digit_l) of row p / digit_l — the gadget
+// decomposition of ring_torus.rs:67-77 / torus.rs:43-52 done in the load, so the 0/1 polynomials
+// never exist in memory.
+template <int LP, bool FINAL, bool WIDE, bool DIGITS = false>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -219,8 +223,18 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     };
 
     u64 v[16];
+    if constexpr (DIGITS) {
+        static_assert(FINAL, "digit loads exist for the single-pass kernels only");
+        const u64 p = pg * C::W + (w < live ? w : 0u);
+        const u64 row = p / a.digit_l;
+        const u32 sh = a.digit_l - 1u - (u32)(p - row * a.digit_l);
+        const u64 *__restrict__ src = a.in + row * n;
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, off + field_of<C::A0>(tf, k) * 8u);
+        for (int k = 0; k < 16; k++) v[k] = (src[field_of<C::A0>(tf, k)] >> sh) & 1ull;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, off + field_of<C::A0>(tf, k) * 8u);
+    }
     // Round 0's twiddles are the same for the whole workgroup (H = 0): read from the global
     // table at a wave-uniform address (scalar loads, SGPR operands).  The LDS copy is only
     // needed from round 1 on, so the barrier of the first exchange also publishes it.
@@ -758,7 +772,7 @@ static inline hipError_t allow_big_lds(const void *fn, size_t bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int LP, bool FINAL, bool WIDE>
+template <int LP, bool FINAL, bool WIDE, bool DIGITS = false>
 static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 nb = 1ull << (a.log_n - LP);
@@ -766,9 +780,9 @@ static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     const u64 grid = nb * groups;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE>, C::LDS_BYTES)) return e;
-    KernelTimer kt(FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig", LP, st);
-    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE>), dim3((unsigned)grid), dim3(C::TH),
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE, DIGITS>, C::LDS_BYTES)) return e;
+    KernelTimer kt(DIGITS ? "ntt_fwd_digits" : (FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig"), LP, st);
+    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE, DIGITS>), dim3((unsigned)grid), dim3(C::TH),
                        C::LDS_BYTES, st, a);
     return post_launch();
 }
@@ -935,6 +949,24 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
+                                     hipStream_t st) {
+    const int L = p.log_n;
+    if (L < 4 || L > kMaxSinglePassLog || !p.wide || l == 0 || l > 64) return hipErrorNotSupported;
+    if (rows == 0) return hipSuccess;
+    PassArgs a{};
+    a.tw = p.tw_fwd;
+    a.mod = p.mod;
+    a.log_n = p.log_n;
+    a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l;
+    switch (L) {
+#define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, true>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
 }
 
 // in2 != nullptr: transform the pointwise product in .* in2 (and write it to

@@ -35,6 +35,7 @@ struct PassArgs {
     Tw ninv, s_ninv;
     u64 batch;
     uint32_t log_n;
+    uint32_t digit_l;  // DIGITS kernels: output polynomial p is bit (digit_l-1 - p%digit_l) of input row p/digit_l
 };
 
 // Brackets one launch with HIP events when fhe_ntt_kernel_timing_enable(1).
@@ -47,6 +48,10 @@ struct KernelTimer {
 
 hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
                               u64 batch_tile, hipStream_t st);
+// out[r*l + d] = NTT(bit l-1-d of every word of in[r])  (Tn::decompose, beta = 2, fused into the
+// load).  Single-pass sizes and q < 2^61 only: returns hipErrorNotSupported otherwise.
+hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
+                                     hipStream_t st);
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st);
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,

@@ -141,17 +141,34 @@ __device__ __forceinline__ u64 canon4(u64 x, const Mod &m) { return canon2(csub_
 // [0,8q) -> [0,q)   (q < 2^61)
 __device__ __forceinline__ u64 canon8(u64 x, const Mod &m) { return canon4(csub_neg(x, m.neg4q), m); }
 
-// a * b mod q, canonical, for two VARIABLE canonical operands
-// (zip_eq(l,r).map(l*r), arith/src/ring_nq.rs:601-604).
-// a*b = hi*2^64 + lo  ==  hi*(2^64 mod q) + lo  (mod q); both terms are reduced
-// with the Shoup estimate against the fixed constants r64 and 1.
-__device__ __forceinline__ u64 mul_mod_var(u64 a, u64 b, const Mod &m) {
-    const u64 lo = a * b;
-    const u64 hi = __umul64hi(a, b);
+// (hi*2^64 + lo) mod q, canonical, for ANY 128-bit value:
+// hi*2^64 + lo  ==  hi*(2^64 mod q) + lo  (mod q); both terms are reduced with the Shoup
+// estimate against the fixed constants r64 and 1.
+__device__ __forceinline__ u64 reduce128(u64 hi, u64 lo, const Mod &m) {
     const u64 t2 = lo - __umul64hi(lo, m.onep) * m.q;          // lo mod q, in [0,2q)
     const u64 t = mul_shoup_acc(t2, hi, m.r64, m.r64p, m.nq);  // + hi*r64 mod q: [0,4q)
     return canon4(t, m);
 }
+// a * b mod q, canonical, for two VARIABLE operands
+// (zip_eq(l,r).map(l*r), arith/src/ring_nq.rs:601-604).
+__device__ __forceinline__ u64 mul_mod_var(u64 a, u64 b, const Mod &m) {
+    return reduce128(__umul64hi(a, b), a * b, m);
+}
+
+// Sum of products of canonical operands, reduced once per kMacChunk terms instead of once per
+// term: a term is < q^2 < 2^124, so 8 of them plus a canonical carry-over stay below 2^128.
+// One term costs 4 multiplies and a 128-bit add here, against ~18 multiplies for mul_mod_var.
+typedef unsigned __int128 u128;
+constexpr unsigned kMacChunk = 8;
+struct MacAcc {
+    u128 v = 0;
+    __device__ __forceinline__ void mac(u64 a, u64 b) { v += (u128)a * b; }
+    __device__ __forceinline__ u64 fold(const Mod &m) {   // -> canonical, and restart from it
+        const u64 r = reduce128((u64)(v >> 64), (u64)v, m);
+        v = r;
+        return r;
+    }
+};
 
 __device__ __forceinline__ u64 splitmix64(u64 x) {
     x += 0x9E3779B97F4A7C15ull;

@@ -20,6 +20,7 @@
 
 #include "capi_internal.hpp"
 #include "zq_device.hpp"
+#include "mac_kernel.hpp"
 
 using fhe::Mod;
 using fhe::Tw;
@@ -105,29 +106,6 @@ __global__ __launch_bounds__(256) void zr_mul_bcast_kernel(const u64 *__restrict
         const u64 r = i / per, bj = i - r * per;
         const u32 j = (u32)(bj % n2);
         c[i] = mul_mod_var(x[bj], y[r * n2 + j], m);
-    }
-}
-
-// External product accumulation in the NTT domain (tggsw.rs:57-59, 145):
-//   out[b][c][j] = sum_{i<k1} sum_{d<l} G[i][d][c][j] * D[b][i][d][j]      (mod p)
-__global__ __launch_bounds__(256) void zr_extprod_mac_kernel(const u64 *__restrict__ G,
-                                                             const u64 *__restrict__ D,
-                                                             u64 *__restrict__ out, u64 batch, u32 n,
-                                                             u32 k1, u32 l, Mod m) {
-    const u64 total = batch * k1 * n, stride = (u64)gridDim.x * 256;
-    for (u64 idx = (u64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
-        const u32 j = (u32)(idx % n);
-        const u64 bc = idx / n;
-        const u32 c = (u32)(bc % k1);
-        const u64 b = bc / k1;
-        u64 acc = 0;
-        for (u32 i = 0; i < k1; i++)
-            for (u32 d = 0; d < l; d++) {
-                const u64 g = G[(((u64)i * l + d) * k1 + c) * n + j];
-                const u64 x = D[((b * k1 + i) * l + d) * n + j];
-                acc = canon2(acc + mul_mod_var(g, x, m), m);
-            }
-        out[idx] = acc;
     }
 }
 
@@ -494,16 +472,28 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
     rc = fhe_workspace_get(1, (grows + 2 * drows + (size_t)z.K * orows) * n * 8, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *G = (u64 *)wsv, *Dg = G + grows * n, *D = Dg + drows * n, *R = D + drows * n;
-    hipLaunchKernelGGL(fhe::zr_digits_kernel, dim3(fhe_ew_grid(drows * n)), dim3(256), 0, st, (const u64 *)d_tglwe, Dg, (u64)orows, (u32)n, (u32)l);
-    LAUNCH_OK("zr_digits_kernel");
+    bool digits_done = false;
     for (int kk = 0; kk < z.K; kk++) {
         hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G, grows, (u32)n, (u32)n, z.cc.m[kk]);
         LAUNCH_OK("zr_reduce_pad_kernel");
         if ((rc = z_forward(z, kk, G, G, grows, st)) != FHE_OK) return rc;
-        if ((rc = z_forward(z, kk, Dg, D, drows, st)) != FHE_OK) return rc;   // digits are < every prime
+        // D = NTT of the 0/1 digit polynomials (digits are < every prime).  Single-pass sizes
+        // extract the bit in the transform's load; larger n materialises the digits once.
+        hipError_t e = fhe::launch_ntt_forward_digits(z.dp[kk], (const u64 *)d_tglwe, D, orows, (u32)l, st);
+        if (e == hipErrorNotSupported) {
+            if (!digits_done) {
+                hipLaunchKernelGGL(fhe::zr_digits_kernel, dim3(fhe_ew_grid(drows * n)), dim3(256), 0, st, (const u64 *)d_tglwe, Dg, (u64)orows, (u32)n, (u32)l);
+                LAUNCH_OK("zr_digits_kernel");
+                digits_done = true;
+            }
+            if ((rc = z_forward(z, kk, Dg, D, drows, st)) != FHE_OK) return rc;
+        } else if (e != hipSuccess) {
+            return fhe_hip_fail(e, "digit forward NTT");
+        }
         u64 *Rk = R + (u64)kk * orows * n;
-        hipLaunchKernelGGL(fhe::zr_extprod_mac_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)G, (const u64 *)D, Rk, (u64)batch, (u32)n, k1, (u32)l, z.cc.m[kk]);
-        LAUNCH_OK("zr_extprod_mac_kernel");
+        // out[b][c] = sum_{i<k1,d<l} G[i][d][c] * D[b][i][d]  (tggsw.rs:57-59,145): T = k1*l terms, k1 rows
+        hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, k1, n))), dim3(256), 0, st, (const u64 *)G, (const u64 *)D, Rk, (u64)batch, (u32)n, (u32)(k1 * l), (u32)k1, (u64)0, z.cc.m[kk]);
+        LAUNCH_OK("mac_rows_kernel");
         if ((rc = z_inverse(z, kk, Rk, Rk, orows, st)) != FHE_OK) return rc;
     }
     return z_crt(z, true, R, R + orows * n, R + 2 * orows * n, (u64 *)d_out, orows * n, st);

@@ -299,7 +299,9 @@ def test_gpu_tn_mul(pkg, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,k,l,batch", [(64, 4, 64, 3),      # tfhe/src/tggsw.rs:157-196 test shape
                                          (1024, 1, 64, 2),     # BASELINE.json configs[3] shape
-                                         (16, 2, 8, 5)])
+                                         (16, 2, 8, 5),
+                                         (8, 1, 64, 2),        # n < 16: no single-pass digit kernel
+                                         (16384, 1, 2, 1)])    # two-pass size: digits materialised once
 def test_gpu_external_product(pkg, oracle, n, k, l, batch):
     rng = np.random.default_rng(n + k)
     tggsw = rng.integers(0, U64, (k + 1, l, k + 1, n), dtype=np.uint64)

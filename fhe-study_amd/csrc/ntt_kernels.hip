@@ -123,12 +123,28 @@ __device__ __forceinline__ void stage_twiddles(Tw *ltw, const Tw *__restrict__ t
 
 // Global access as (wave-uniform 64-bit base) + (32-bit per-lane BYTE offset): the form the
 // saddr/voffset addressing mode takes, so an access costs one v_add_u32, not 64-bit arithmetic.
+// Coefficient data is touched once per pass, so accesses in which a wave instruction covers whole
+// cache lines carry the non-temporal hint (plain copy: 5.41 -> 5.71 TB/s with it,
+// tools/ubench_mem.hip; forward 2^16 transform 7.40 -> 7.25 ms).  The inverse contiguous pass reads
+// and writes a line in pieces spread over several instructions and needs the cache to merge them:
+// with the hint it ran 3.69 -> 5.5 ms, so it uses the plain forms (ld_c / st_c).
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 template <typename T>
-__device__ __forceinline__ T ld_at(const u64 *ubase, u32 byte_off) {
+__device__ __forceinline__ T ld_at(const u64 *ubase, u32 byte_off);
+template <>
+__device__ __forceinline__ u64 ld_at<u64>(const u64 *ubase, u32 byte_off) {
+    return __builtin_nontemporal_load(
+        reinterpret_cast<const u64 *>(reinterpret_cast<const unsigned char *>(ubase) + byte_off));
+}
+__device__ __forceinline__ void st_at(u64 *ubase, u32 byte_off, u64 x) {
+    __builtin_nontemporal_store(x, reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ubase) + byte_off));
+}
+template <typename T>
+__device__ __forceinline__ T ld_c(const u64 *ubase, u32 byte_off) {
     return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(ubase) + byte_off);
 }
 template <typename T>
-__device__ __forceinline__ void st_at(u64 *ubase, u32 byte_off, T x) {
+__device__ __forceinline__ void st_c(u64 *ubase, u32 byte_off, T x) {
     *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ubase) + byte_off) = x;
 }
 
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     for (int i = 0; i < 16; i++) {
         const u32 e = i * C::TH + tid;
         const u32 wu = e >> LP, f = e & (C::M - 1);
-        if (wu < live) st_at<u64>(pout, ((wu << a.log_n) + f) * 8u, lds[pad16(e)]);
+        if (wu < live) st_at(pout, ((wu << a.log_n) + f) * 8u, lds[pad16(e)]);
     }
 }
 
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
         const u64 *__restrict__ pin = a.in + ubase;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const ulonglong2 x = ld_at<ulonglong2>(pin, g0 + j * 16u);
+            const ulonglong2 x = ld_c<ulonglong2>(pin, g0 + j * 16u);
             v[2 * j] = x.x;
             v[2 * j + 1] = x.y;
         }
@@ -323,13 +339,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
             u64 *__restrict__ pout2 = a.out2 + ubase;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const ulonglong2 y = ld_at<ulonglong2>(pin2, g0 + j * 16u);
+                const ulonglong2 y = ld_c<ulonglong2>(pin2, g0 + j * 16u);
                 ulonglong2 p;
                 p.x = mul_mod_var(v[2 * j], y.x, a.mod);
                 p.y = mul_mod_var(v[2 * j + 1], y.y, a.mod);
                 v[2 * j] = p.x;
                 v[2 * j + 1] = p.y;
-                if (a.out2 && active) st_at<ulonglong2>(pout2, g0 + j * 16u, p);
+                if (a.out2 && active) st_c<ulonglong2>(pout2, g0 + j * 16u, p);
             }
         }
     }
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     if (active) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            st_at<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, FINAL ? canon2(v[k], m) : v[k]);
+            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, FINAL ? canon2(v[k], m) : v[k]);
     }
 }
 
@@ -430,7 +446,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
-    for (int k = 0; k < 16; k++) st_at<u64>(pout, ((field_of<ALAST>(tf, k) << lb) + c) * 8u, v[k]);  // lazy: < 4q, or < 6q (WIDE)
+    for (int k = 0; k < 16; k++) st_at(pout, ((field_of<ALAST>(tf, k) << lb) + c) * 8u, v[k]);  // lazy: < 4q, or < 6q (WIDE)
 }
 
 template <int LA, int CW>
@@ -469,7 +485,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     }
     round_inv<C::R0, true>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
-    for (int k = 0; k < 16; k++) st_at<u64>(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, canon2(v[k], m));
+    for (int k = 0; k < 16; k++) st_at(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, canon2(v[k], m));
 }
 
 // ---------------------------------------------------------------------------

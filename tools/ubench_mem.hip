@@ -68,6 +68,44 @@ __global__ __launch_bounds__(256) void copy_ldsdma(const char* __restrict__ a, c
   }
 }
 
+// (f) 16 B per lane with non-temporal loads and stores (streaming hint: no reuse expected)
+__global__ __launch_bounds__(256) void copy_b128_nt(const ulonglong2* __restrict__ a, ulonglong2* __restrict__ b, u64 n) {
+  u64 base = (u64)blockIdx.x * 2048 + threadIdx.x;
+  u64 x[8], y[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const u64* p = (const u64*)(a + base + k * 256);
+    x[k] = __builtin_nontemporal_load(p); y[k] = __builtin_nontemporal_load(p + 1);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    u64* p = (u64*)(b + base + k * 256);
+    __builtin_nontemporal_store(x[k], p); __builtin_nontemporal_store(y[k], p + 1);
+  }
+}
+// (g) non-temporal stores only
+__global__ __launch_bounds__(256) void copy_b64_nts(const u64* __restrict__ a, u64* __restrict__ b, u64 n) {
+  u64 base = (u64)blockIdx.x * 4096 + threadIdx.x;
+  u64 v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) v[k] = a[base + k * 256];
+#pragma unroll
+  for (int k = 0; k < 16; k++) __builtin_nontemporal_store(v[k], b + base + k * 256);
+}
+// (h) read only (xor-reduce, one store per workgroup), (i) write only
+__global__ __launch_bounds__(256) void read_only(const ulonglong2* __restrict__ a, u64* __restrict__ b, u64 n) {
+  u64 base = (u64)blockIdx.x * 2048 + threadIdx.x;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { ulonglong2 v = a[base + k * 256]; acc ^= v.x ^ v.y; }
+  if (acc == 0x123456789abcdefull) b[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void write_only(ulonglong2* __restrict__ b, u64 n) {
+  u64 base = (u64)blockIdx.x * 2048 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; k++) b[base + k * 256] = ulonglong2{base, (u64)k};
+}
+
 template <typename F> static float timeit(F f) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   f(); hipDeviceSynchronize();
@@ -84,5 +122,13 @@ int main() {
   rep("strided tile 8B/lane", timeit([&] { copy_strided_b64<<<n / 8192, 512>>>((const u64*)a, (u64*)b, n); }));
   rep("strided tile 16B/lane", timeit([&] { copy_strided_b128<<<n / 8192, 256>>>((const ulonglong2*)a, (ulonglong2*)b, n); }));
   rep("LDS-DMA in, b128 out", timeit([&] { copy_ldsdma<<<bytes / 32768, 256, 32768>>>(a, b, n); }));
+  rep("contiguous 16B/lane, nt ld+st", timeit([&] { copy_b128_nt<<<n / 4096, 256>>>((const ulonglong2*)a, (ulonglong2*)b, n); }));
+  rep("contiguous 8B/lane, nt st", timeit([&] { copy_b64_nts<<<n / 4096, 256>>>((const u64*)a, (u64*)b, n); }));
+  { float ms = timeit([&] { read_only<<<n / 4096, 256>>>((const ulonglong2*)a, (u64*)b, n); });
+    printf("%-28s %8.3f ms  %6.2f TB/s (read only)\n", "read only 16B/lane", ms, 1.0 * bytes / ms * 1e-9); }
+  { float ms = timeit([&] { write_only<<<n / 4096, 256>>>((ulonglong2*)b, n); });
+    printf("%-28s %8.3f ms  %6.2f TB/s (write only)\n", "write only 16B/lane", ms, 1.0 * bytes / ms * 1e-9); }
+  { float ms = timeit([&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); });
+    rep("hipMemcpyAsync D2D", ms); }
   return 0;
 }

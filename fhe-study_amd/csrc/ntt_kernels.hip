@@ -208,11 +208,13 @@ __device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u
     for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
 }
 
-// DIGITS (single-pass sizes only): the input is `batch / digit_l` rows of 64-bit words and output
-// polynomial p is the transform of bit digit_l-1-(p % digit_l) of row p / digit_l — the gadget
-// decomposition of ring_torus.rs:67-77 / torus.rs:43-52 done in the load, so the 0/1 polynomials
-// never exist in memory.
-template <int LP, bool FINAL, bool WIDE, bool DIGITS = false>
+// SRC_DIGITS (single-pass sizes only): the input is `batch / digit_l` rows of 64-bit words and
+// output polynomial p is the transform of bit digit_l-1-(p % digit_l) of row p / digit_l — the
+// gadget decomposition of ring_torus.rs:67-77 / torus.rs:43-52 done in the load, so the 0/1
+// polynomials never exist in memory.
+// SRC_REDUCE (single-pass sizes only; the two-pass sizes do it in the strided pass): the input
+// rows are 2^src_log_n arbitrary 64-bit words, reduced mod q and zero-padded to n in the load.
+template <int LP, bool FINAL, bool WIDE, int SRC = SRC_PLAIN>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     };
 
     u64 v[16];
-    if constexpr (DIGITS) {
+    if constexpr (SRC == SRC_DIGITS) {
         static_assert(FINAL, "digit loads exist for the single-pass kernels only");
         const u64 p = pg * C::W + (w < live ? w : 0u);
         const u64 row = p / a.digit_l;
@@ -247,6 +249,16 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
         const u64 *__restrict__ src = a.in + row * n;
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = (src[field_of<C::A0>(tf, k)] >> sh) & 1ull;
+    } else if constexpr (SRC == SRC_REDUCE) {
+        static_assert(FINAL, "reducing loads exist for the single-pass kernels only");
+        const u64 p = pg * C::W + (w < live ? w : 0u);
+        const u64 *__restrict__ src = a.in + (p << a.src_log_n);
+        const u32 nsrc = 1u << a.src_log_n;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 f = field_of<C::A0>(tf, k);
+            v[k] = f < nsrc ? reduce_any(src[f], a.mod) : 0ull;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, off + field_of<C::A0>(tf, k) * 8u);
@@ -409,7 +421,9 @@ __device__ __forceinline__ void exchange_strided(u64 (&v)[16], u64 *lds, u32 c, 
     for (int k = 0; k < 16; k++) v[k] = lds[field_of<AT>(tf, k) * CW + c];
 }
 
-template <int LA, int CW, bool WIDE>
+// RSRC: the input rows are 2^src_log_n arbitrary words, reduced mod q and zero-padded in the load
+// (see SRC_REDUCE above).
+template <int LA, int CW, bool WIDE, bool RSRC = false>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kernel(PassArgs a) {
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -429,8 +443,18 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     const Tw *tw = ltw;
 
     u64 v[16];
+    if constexpr (RSRC) {
+        const u64 *__restrict__ src = a.in + (poly << a.src_log_n) + (u64)cg * CW;
+        const u32 nsrc = 1u << a.src_log_n, col = cg * CW + c;
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<C::A0>(tf, k) << lb) + c) * 8u);
+        for (int k = 0; k < 16; k++) {
+            const u32 e = field_of<C::A0>(tf, k) << lb;          // row start; element e + col
+            v[k] = e + col < nsrc ? reduce_any(ld_at<u64>(src, (e + c) * 8u), m) : 0ull;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<C::A0>(tf, k) << lb) + c) * 8u);
+    }
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];   // first pass: s0 = 0, blk = 0
 
     round_fwd<C::R0, WIDE>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
@@ -788,7 +812,7 @@ static inline hipError_t allow_big_lds(const void *fn, size_t bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int LP, bool FINAL, bool WIDE, bool DIGITS = false>
+template <int LP, bool FINAL, bool WIDE, int SRC = SRC_PLAIN>
 static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 nb = 1ull << (a.log_n - LP);
@@ -796,9 +820,9 @@ static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     const u64 grid = nb * groups;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE, DIGITS>, C::LDS_BYTES)) return e;
-    KernelTimer kt(DIGITS ? "ntt_fwd_digits" : (FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig"), LP, st);
-    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE, DIGITS>), dim3((unsigned)grid), dim3(C::TH),
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>, C::LDS_BYTES)) return e;
+    KernelTimer kt(SRC == SRC_DIGITS ? "ntt_fwd_digits" : SRC == SRC_REDUCE ? "ntt_fwd_reduce" : (FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig"), LP, st);
+    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>), dim3((unsigned)grid), dim3(C::TH),
                        C::LDS_BYTES, st, a);
     return post_launch();
 }
@@ -818,19 +842,19 @@ static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
     return post_launch();
 }
 
-template <int LA, int CW, bool INV, bool WIDE>
+template <int LA, int CW, bool INV, bool WIDE, bool RSRC = false>
 static hipError_t launch_strided(const PassArgs &a, hipStream_t st) {
     using C = StridedCfg<LA, CW>;
     const u64 ncg = (1ull << (a.log_n - LA)) / CW;
     const u64 grid = ncg * a.batch;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    KernelTimer kt(INV ? "ntt_inv_strided" : "ntt_fwd_strided", LA, st);
+    KernelTimer kt(INV ? "ntt_inv_strided" : (RSRC ? "ntt_fwd_strided_reduce" : "ntt_fwd_strided"), LA, st);
     if (INV)
         hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW>), dim3((unsigned)grid), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     else
-        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, WIDE>), dim3((unsigned)grid), dim3(C::TH),
+        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, WIDE, RSRC>), dim3((unsigned)grid), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     return post_launch();
 }
@@ -978,11 +1002,49 @@ hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *ou
     a.log_n = p.log_n;
     a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l;
     switch (L) {
-#define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, true>(a, st);
+#define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, SRC_DIGITS>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *out, u64 rows,
+                                     uint32_t src_log_n, u64 batch_tile, hipStream_t st) {
+    const int L = p.log_n;
+    if (L < 4 || !p.wide || src_log_n > (uint32_t)L) return hipErrorNotSupported;
+    if (rows == 0) return hipSuccess;
+    PassArgs a{};
+    a.tw = p.tw_fwd;
+    a.mod = p.mod;
+    a.log_n = p.log_n;
+    a.src_log_n = src_log_n;
+    if (L <= kMaxSinglePassLog) {
+        a.in = in; a.out = out; a.batch = rows;
+        switch (L) {
+#define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, SRC_REDUCE>(a, st);
+            CONTIG_CASES(X)
+#undef X
+        }
+        return hipErrorInvalidValue;
+    }
+    const int LB = contig_bits(L), LA = L - LB;
+    const u64 n = 1ull << L, nsrc = 1ull << src_log_n;
+    if (batch_tile == 0) batch_tile = rows;
+    for (u64 b0 = 0; b0 < rows; b0 += batch_tile) {
+        const u64 nb = rows - b0 < batch_tile ? rows - b0 : batch_tile;
+        a.in = in + b0 * nsrc; a.out = out + b0 * n; a.batch = nb;
+        hipError_t e = hipErrorInvalidValue;
+        switch (LA) {
+            case 6: e = launch_strided<6, 128, false, true, true>(a, st); break;
+            case 7: e = launch_strided<7, 64, false, true, true>(a, st); break;
+            case 8: e = launch_strided<8, 32, false, true, true>(a, st); break;
+        }
+        if (e != hipSuccess) return e;
+        a.in = out + b0 * n;
+        if ((e = fwd_contig_dispatch(LB, true, true, a, st)) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // in2 != nullptr: transform the pointwise product in .* in2 (and write it to

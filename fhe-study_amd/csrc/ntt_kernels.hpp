@@ -35,8 +35,12 @@ struct PassArgs {
     Tw ninv, s_ninv;
     u64 batch;
     uint32_t log_n;
-    uint32_t digit_l;  // DIGITS kernels: output polynomial p is bit (digit_l-1 - p%digit_l) of input row p/digit_l
+    uint32_t digit_l;    // SRC_DIGITS: output polynomial p is bit (digit_l-1 - p%digit_l) of input row p/digit_l
+    uint32_t src_log_n;  // SRC_REDUCE: input rows have 2^src_log_n arbitrary 64-bit words (<= n); the rest is 0
 };
+
+// what a forward kernel's load does besides loading
+enum : int { SRC_PLAIN = 0, SRC_DIGITS = 1, SRC_REDUCE = 2 };
 
 // Brackets one launch with HIP events when fhe_ntt_kernel_timing_enable(1).
 struct KernelTimer {
@@ -52,6 +56,11 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
 // load).  Single-pass sizes and q < 2^61 only: returns hipErrorNotSupported otherwise.
 hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
                                      hipStream_t st);
+// out[r] = NTT(in[r] reduced mod q and zero-padded from 2^src_log_n to n words): the operand
+// preparation of the exact products over Z (zring.hip) fused into the load.  q < 2^61 and
+// n >= 16 only: returns hipErrorNotSupported otherwise.
+hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *out, u64 rows,
+                                     uint32_t src_log_n, u64 batch_tile, hipStream_t st);
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st);
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,

@@ -141,6 +141,12 @@ __device__ __forceinline__ u64 canon4(u64 x, const Mod &m) { return canon2(csub_
 // [0,8q) -> [0,q)   (q < 2^61)
 __device__ __forceinline__ u64 canon8(u64 x, const Mod &m) { return canon4(csub_neg(x, m.neg4q), m); }
 
+// x mod q for any 64-bit x (Shoup with w = 1), canonical
+__device__ __forceinline__ u64 reduce_any(u64 x, const Mod &m) {
+    const u64 r = x - __umul64hi(x, m.onep) * m.q;  // [0, 2q)
+    return canon2(r, m);
+}
+
 // (hi*2^64 + lo) mod q, canonical, for ANY 128-bit value:
 // hi*2^64 + lo  ==  hi*(2^64 mod q) + lo  (mod q); both terms are reduced with the Shoup
 // estimate against the fixed constants r64 and 1.

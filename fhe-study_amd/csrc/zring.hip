@@ -52,12 +52,6 @@ struct CrtConsts {
     u64 half3;       // (P3 - 1) / 2
 };
 
-// x mod p for any 64-bit x (Shoup with w = 1), canonical
-__device__ __forceinline__ u64 reduce_any(u64 x, const Mod &m) {
-    const u64 r = x - __umul64hi(x, m.onep) * m.q;  // [0, 2p)
-    return canon2(r, m);
-}
-
 __global__ __launch_bounds__(256) void zr_reduce_pad_kernel(const u64 *__restrict__ in,
                                                             u64 *__restrict__ out, u64 rows, u32 n,
                                                             u32 n2, Mod m) {
@@ -257,6 +251,18 @@ static int z_forward(const ZCtx &z, int k, const u64 *in, u64 *out, u64 rows, hi
     hipError_t e = fhe::launch_ntt_forward(z.dp[k], in, out, rows, fhe_batch_tile_for(z.plan[k]), st);
     return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "zring forward NTT");
 }
+// out[r] = NTT_k(src[r] mod P_k, zero-padded from n_src to the plan's n): the reduction and the
+// padding happen in the transform's load; sizes without such a kernel (n < 16) stage through `out`.
+static int z_forward_src(const ZCtx &z, int k, const u64 *src, u64 *out, u64 rows, u64 n_src, hipStream_t st) {
+    const u64 n = z.plan[k]->n;
+    hipError_t e = fhe::launch_ntt_forward_reduce(z.dp[k], src, out, rows, (uint32_t)__builtin_ctzll(n_src),
+                                                  fhe_batch_tile_for(z.plan[k]), st);
+    if (e == hipSuccess) return FHE_OK;
+    if (e != hipErrorNotSupported) return fhe_hip_fail(e, "zring reducing forward NTT");
+    hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(rows * n)), dim3(256), 0, st, src, out, rows, (u32)n_src, (u32)n, z.cc.m[k]);
+    LAUNCH_OK("zr_reduce_pad_kernel");
+    return z_forward(z, k, out, out, rows, st);
+}
 static int z_inverse(const ZCtx &z, int k, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
     hipError_t e = fhe::launch_ntt_inverse(z.dp[k], in, nullptr, nullptr, out, rows,
                                            fhe_batch_tile_for(z.plan[k]), st);
@@ -304,11 +310,8 @@ extern "C" int fhe_r_naive_mul_dev(uint64_t n, const void *d_a, const void *d_b,
     if (rc != FHE_OK) return rc;
     u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;   // R: K residue arrays
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
-        LAUNCH_OK("zr_reduce_pad_kernel");
-        if ((rc = z_forward(z, k, A, A, batch, st)) != FHE_OK) return rc;
-        if ((rc = z_forward(z, k, B, B, batch, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, (const u64 *)d_a, A, batch, n, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, (const u64 *)d_b, B, batch, n, st)) != FHE_OK) return rc;
         hipError_t e = fhe::launch_ntt_inverse(z.dp[k], A, B, nullptr, R + (u64)k * words, batch,
                                                fhe_batch_tile_for(z.plan[k]), st);
         if (e != hipSuccess) return fhe_hip_fail(e, "zring inverse(A.*B)");
@@ -354,9 +357,7 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
     if (rc != FHE_OK) return rc;
     u64 *AB = (u64 *)wsv, *R = AB + 4 * words, *V = R + 3 * (u64)z.K * words;
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(4 * words)), dim3(256), 0, st, (const u64 *)d_ab, AB, (u64)(4 * batch), (u32)n, (u32)n2, z.cc.m[k]);
-        LAUNCH_OK("zr_reduce_pad_kernel");
-        if ((rc = z_forward(z, k, AB, AB, 4 * batch, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, (const u64 *)d_ab, AB, 4 * batch, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 3 * (u64)k * words;
         hipLaunchKernelGGL(fhe::zr_tensor_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)AB, Rk, words, z.cc.m[k]);
         LAUNCH_OK("zr_tensor_kernel");
@@ -389,11 +390,8 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
     u64 *X = (u64 *)wsv, *R = X + words, *V = R + 2 * (u64)z.K * words, *Rr = V + 2 * words, *Y = Rr + words;
     const u64 *c2 = (const u64 *)d_c + 2 * bn;
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, c2, X, (u64)batch, (u32)n, (u32)n2, z.cc.m[k]);
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(2 * n2)), dim3(256), 0, st, (const u64 *)d_rlk, Y, (u64)2, (u32)n, (u32)n2, z.cc.m[k]);
-        LAUNCH_OK("zr_reduce_pad_kernel");
-        if ((rc = z_forward(z, k, X, X, batch, st)) != FHE_OK) return rc;
-        if ((rc = z_forward(z, k, Y, Y, 2, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, c2, X, batch, n, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, (const u64 *)d_rlk, Y, 2, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 2 * (u64)k * words;
         hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, (const u64 *)Y, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
         LAUNCH_OK("zr_mul_bcast_kernel");
@@ -439,11 +437,8 @@ extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void
     if (rc != FHE_OK) return rc;
     u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;
     for (int k = 0; k < z.K; k++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_a, A, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)d_b, B, (u64)batch, (u32)n, (u32)n, z.cc.m[k]);
-        LAUNCH_OK("zr_reduce_pad_kernel");
-        if ((rc = z_forward(z, k, A, A, batch, st)) != FHE_OK) return rc;
-        if ((rc = z_forward(z, k, B, B, batch, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, (const u64 *)d_a, A, batch, n, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, (const u64 *)d_b, B, batch, n, st)) != FHE_OK) return rc;
         hipError_t e = fhe::launch_ntt_inverse(z.dp[k], A, B, nullptr, R + (u64)k * words, batch,
                                                fhe_batch_tile_for(z.plan[k]), st);
         if (e != hipSuccess) return fhe_hip_fail(e, "zring inverse(A.*B)");
@@ -474,9 +469,7 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
     u64 *G = (u64 *)wsv, *Dg = G + grows * n, *D = Dg + drows * n, *R = D + drows * n;
     bool digits_done = false;
     for (int kk = 0; kk < z.K; kk++) {
-        hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G, grows, (u32)n, (u32)n, z.cc.m[kk]);
-        LAUNCH_OK("zr_reduce_pad_kernel");
-        if ((rc = z_forward(z, kk, G, G, grows, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, kk, (const u64 *)d_tggsw, G, grows, n, st)) != FHE_OK) return rc;
         // D = NTT of the 0/1 digit polynomials (digits are < every prime).  Single-pass sizes
         // extract the bit in the transform's load; larger n materialises the digits once.
         hipError_t e = fhe::launch_ntt_forward_digits(z.dp[kk], (const u64 *)d_tglwe, D, orows, (u32)l, st);

@@ -57,6 +57,7 @@ def extprod(n=1024, k=1, l=64, batch=630):
 
 if __name__ == "__main__":
     bfv()
+    bfv(batch=2048)          # same work per ciphertext; launch gaps amortised
     extprod()
     B.kernel_timing_reset(); B.kernel_timing_enable(True)
     extprod(batch=630)

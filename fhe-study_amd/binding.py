@@ -52,6 +52,7 @@ EXPORTS = [
     "fhe_tn_mul", "fhe_tn_mul_dev", "fhe_tggsw_external_product", "fhe_tggsw_external_product_dev",
     # rows N3/N4: batch surfaces and element-wise glue
     "fhe_tr_dot_dev", "fhe_tr_mul_r_dev", "fhe_glev_mul_dev", "fhe_glwe_key_switch_dev",
+    "fhe_tr_dot", "fhe_tr_mul_r", "fhe_glev_mul", "fhe_glwe_key_switch",
     "fhe_rq_add_dev", "fhe_rq_sub_dev", "fhe_rq_neg_dev", "fhe_rq_mul_by_u64_dev",
     "fhe_rq_mod_switch_dev", "fhe_rq_mul_div_round_dev", "fhe_rq_decompose_dev",
 ]
@@ -183,6 +184,10 @@ def load_library():
     L.fhe_tr_mul_r_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
     L.fhe_glev_mul_dev.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]
     L.fhe_glwe_key_switch_dev.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]
+    L.fhe_tr_dot.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz]
+    L.fhe_tr_mul_r.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz]
+    L.fhe_glev_mul.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz]
+    L.fhe_glwe_key_switch.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp, _sz]
     L.fhe_rq_add_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
     L.fhe_rq_sub_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
     L.fhe_rq_neg_dev.argtypes = [_vp, _vp, _vp, _sz, _vp]

@@ -64,3 +64,28 @@ static inline unsigned fhe_ew_grid(fhe::u64 count) {
         hipError_t e_ = hipGetLastError();                   \
         if (e_ != hipSuccess) return fhe_hip_fail(e_, what); \
     } while (0)
+
+// Staging of HOST buffers around a *_dev entry point that uses the shared workspace: uploads on
+// the calling thread's stream, holds fhe_host_workspace_lock() until its destructor body has
+// freed the device buffers (hipFree drains the stream on error paths).
+struct FheHostStage {
+    std::vector<void *> bufs;
+    std::lock_guard<std::mutex> ws_lock{fhe_host_workspace_lock()};
+    ~FheHostStage() { for (void *p : bufs) if (p) (void)hipFree(p); }
+    int up(const void *h, size_t bytes, void **d) {
+        *d = nullptr;
+        hipError_t e = hipMalloc(d, bytes ? bytes : 16);
+        if (e != hipSuccess) return fhe_hip_fail(e, "hipMalloc");
+        bufs.push_back(*d);
+        if (h && bytes) {
+            e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, hipStreamPerThread);
+            if (e != hipSuccess) return fhe_hip_fail(e, "hipMemcpyAsync H2D");
+        }
+        return FHE_OK;
+    }
+    int down(void *h, const void *d, size_t bytes) {
+        HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, hipStreamPerThread));
+        HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+        return FHE_OK;
+    }
+};

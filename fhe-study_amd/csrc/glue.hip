@@ -324,3 +324,71 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     LAUNCH_OK("ks_tail_kernel");
     return FHE_OK;
 }
+
+// ---- host-buffer forms of the N3 surfaces (what a shim of gfhe binds: its data are host Vecs) ----
+extern "C" int fhe_tr_dot(const fhe_ntt_plan *plan, const uint64_t *a, const uint64_t *b, uint64_t *c, unsigned k, size_t batch) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_tr_dot: plan is NULL");
+    if (batch == 0 || k == 0) return FHE_OK;
+    if (!a || !b || !c) return fhe_fail(FHE_E_NULL, "fhe_tr_dot: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t row = plan->n * 8;
+    FheHostStage hs;
+    void *da, *db, *dc;
+    if ((rc = hs.up(a, batch * k * row, &da)) != FHE_OK) return rc;
+    if ((rc = hs.up(b, batch * k * row, &db)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * row, &dc)) != FHE_OK) return rc;
+    if ((rc = fhe_tr_dot_dev(plan, da, db, dc, k, batch, 0, hipStreamPerThread)) != FHE_OK) return rc;
+    return hs.down(c, dc, batch * row);
+}
+
+extern "C" int fhe_tr_mul_r(const fhe_ntt_plan *plan, const uint64_t *a, const uint64_t *p, uint64_t *out, unsigned rows, size_t batch) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_tr_mul_r: plan is NULL");
+    if (batch == 0 || rows == 0) return FHE_OK;
+    if (!a || !p || !out) return fhe_fail(FHE_E_NULL, "fhe_tr_mul_r: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t row = plan->n * 8;
+    FheHostStage hs;
+    void *da, *dp, *dout;
+    if ((rc = hs.up(a, batch * rows * row, &da)) != FHE_OK) return rc;
+    if ((rc = hs.up(p, batch * row, &dp)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * rows * row, &dout)) != FHE_OK) return rc;
+    if ((rc = fhe_tr_mul_r_dev(plan, da, dp, dout, rows, batch, 0, hipStreamPerThread)) != FHE_OK) return rc;
+    return hs.down(out, dout, batch * rows * row);
+}
+
+extern "C" int fhe_glev_mul(const fhe_ntt_plan *plan, unsigned k, unsigned l, const uint64_t *glev, const uint64_t *v, uint64_t *out, size_t batch) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_glev_mul: plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (l == 0) return fhe_fail(FHE_E_INVALID, "fhe_glev_mul: l = 0");
+    if (!glev || !v || !out) return fhe_fail(FHE_E_NULL, "fhe_glev_mul: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t row = plan->n * 8, k1 = (size_t)k + 1;
+    FheHostStage hs;
+    void *dg, *dv, *dout;
+    if ((rc = hs.up(glev, l * k1 * row, &dg)) != FHE_OK) return rc;
+    if ((rc = hs.up(v, batch * l * row, &dv)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * k1 * row, &dout)) != FHE_OK) return rc;
+    if ((rc = fhe_glev_mul_dev(plan, k, l, dg, dv, dout, batch, 0, hipStreamPerThread)) != FHE_OK) return rc;
+    return hs.down(out, dout, batch * k1 * row);
+}
+
+extern "C" int fhe_glwe_key_switch(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const uint64_t *glwe, const uint64_t *ksk,
+                                   uint64_t *out, size_t batch) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch: plan is NULL");
+    if (batch == 0) return FHE_OK;
+    if (k == 0 || l == 0 || beta < 2) return fhe_fail(FHE_E_INVALID, "fhe_glwe_key_switch: need k, l >= 1, beta >= 2");
+    if (!glwe || !ksk || !out) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const size_t row = plan->n * 8, k1 = (size_t)k + 1;
+    FheHostStage hs;
+    void *dg, *dk, *dout;
+    if ((rc = hs.up(glwe, batch * k1 * row, &dg)) != FHE_OK) return rc;
+    if ((rc = hs.up(ksk, (size_t)k * l * k1 * row, &dk)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * k1 * row, &dout)) != FHE_OK) return rc;
+    if ((rc = fhe_glwe_key_switch_dev(plan, k, beta, l, dg, dk, dout, batch, 0, hipStreamPerThread)) != FHE_OK) return rc;
+    return hs.down(out, dout, batch * k1 * row);
+}

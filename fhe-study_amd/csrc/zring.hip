@@ -493,29 +493,7 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
 }
 
 // ---- host-buffer wrappers (what a Rust shim binds) ------------------------------------------------
-namespace {
-struct HostStage {
-    std::vector<void *> bufs;
-    std::lock_guard<std::mutex> ws_lock{fhe_host_workspace_lock()};   // held until the destructor body has freed the buffers
-    ~HostStage() { for (void *p : bufs) if (p) (void)hipFree(p); }
-    int up(const void *h, size_t bytes, void **d) {
-        *d = nullptr;
-        hipError_t e = hipMalloc(d, bytes ? bytes : 16);
-        if (e != hipSuccess) return fhe_hip_fail(e, "hipMalloc");
-        bufs.push_back(*d);
-        if (h && bytes) {
-            e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, hipStreamPerThread);
-            if (e != hipSuccess) return fhe_hip_fail(e, "hipMemcpyAsync H2D");
-        }
-        return FHE_OK;
-    }
-};
-int down(void *h, const void *d, size_t bytes) {
-    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, hipStreamPerThread));
-    HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
-    return FHE_OK;
-}
-}  // namespace
+using HostStage = FheHostStage;
 
 extern "C" int fhe_bfv_mul(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const uint64_t *rlk, const uint64_t *ab,
                            uint64_t *out, size_t batch) {
@@ -530,7 +508,7 @@ extern "C" int fhe_bfv_mul(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, cons
     if ((rc = hs.up(nullptr, 2 * batch * n * 8, &dout)) != FHE_OK) return rc;
     rc = fhe_bfv_mul_dev(q, n, t, pq, drlk, dab, dout, batch, hipStreamPerThread);
     if (rc != FHE_OK) return rc;
-    return down(out, dout, 2 * batch * n * 8);
+    return hs.down(out, dout, 2 * batch * n * 8);
 }
 
 extern "C" int fhe_bfv_tensor(uint64_t q, uint64_t n, uint64_t t, const uint64_t *ab, uint64_t *c, size_t batch) {
@@ -544,7 +522,7 @@ extern "C" int fhe_bfv_tensor(uint64_t q, uint64_t n, uint64_t t, const uint64_t
     if ((rc = hs.up(nullptr, 3 * batch * n * 8, &dc)) != FHE_OK) return rc;
     rc = fhe_bfv_tensor_dev(q, n, t, dab, dc, batch, hipStreamPerThread);
     if (rc != FHE_OK) return rc;
-    return down(c, dc, 3 * batch * n * 8);
+    return hs.down(c, dc, 3 * batch * n * 8);
 }
 
 extern "C" int fhe_r_naive_mul(uint64_t n, const int64_t *a, const int64_t *b, int64_t *out, size_t batch) {
@@ -560,7 +538,7 @@ extern "C" int fhe_r_naive_mul(uint64_t n, const int64_t *a, const int64_t *b, i
     // operands are read as NON-NEGATIVE 64-bit integers (Rq::to_r gives values in [0,q), ring_n.rs:72-79)
     rc = fhe_r_naive_mul_dev(n, da, db, dout, batch, 64, 64, hipStreamPerThread);
     if (rc != FHE_OK) return rc;
-    return down(out, dout, 2 * batch * n * 8);
+    return hs.down(out, dout, 2 * batch * n * 8);
 }
 
 extern "C" int fhe_tn_mul(uint64_t n, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t batch) {
@@ -575,7 +553,7 @@ extern "C" int fhe_tn_mul(uint64_t n, const uint64_t *a, const uint64_t *b, uint
     if ((rc = hs.up(nullptr, batch * n * 8, &dout)) != FHE_OK) return rc;
     rc = fhe_tn_mul_dev(n, da, db, dout, batch, hipStreamPerThread);
     if (rc != FHE_OK) return rc;
-    return down(out, dout, batch * n * 8);
+    return hs.down(out, dout, batch * n * 8);
 }
 
 extern "C" int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, const uint64_t *tggsw,
@@ -592,5 +570,5 @@ extern "C" int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, co
     if ((rc = hs.up(nullptr, batch * k1 * n * 8, &dout)) != FHE_OK) return rc;
     rc = fhe_tggsw_external_product_dev(n, k, l, dg, dt, dout, batch, hipStreamPerThread);
     if (rc != FHE_OK) return rc;
-    return down(out, dout, batch * k1 * n * 8);
+    return hs.down(out, dout, batch * k1 * n * 8);
 }

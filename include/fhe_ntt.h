@@ -226,6 +226,16 @@ int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta,
                             const void *d_glwe, const void *d_ksk, void *d_out, size_t batch,
                             unsigned flags, void *hip_stream);
 
+/* Host-buffer forms of the four surfaces above (same layouts, no flags): what a shim of `gfhe`,
+ * whose ciphertexts are host `Vec`s, binds.  They stage through device memory on the calling
+ * thread's stream and return when `out` is complete. */
+int fhe_tr_dot(const fhe_ntt_plan *plan, const uint64_t *a, const uint64_t *b, uint64_t *c, unsigned k, size_t batch);
+int fhe_tr_mul_r(const fhe_ntt_plan *plan, const uint64_t *a, const uint64_t *p, uint64_t *out, unsigned rows, size_t batch);
+int fhe_glev_mul(const fhe_ntt_plan *plan, unsigned k, unsigned l, const uint64_t *glev, const uint64_t *v,
+                 uint64_t *out, size_t batch);
+int fhe_glwe_key_switch(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const uint64_t *glwe,
+                        const uint64_t *ksk, uint64_t *out, size_t batch);
+
 /* Rq + Rq, Rq - Rq, -Rq (ring_nq.rs:406-488,551-561), Rq::mul_by_u64 (ring_nq.rs:274-281). */
 int fhe_rq_add_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, size_t batch, void *hip_stream);
 int fhe_rq_sub_dev(const fhe_ntt_plan *plan, const void *d_a, const void *d_b, void *d_c, size_t batch, void *hip_stream);

@@ -249,3 +249,40 @@ def test_gpu_glev_mul_and_key_switch(pkg, oracle, q, n, k, beta, l, batch):
     for i in range(batch):
         oracle.glue("key_switch", q, n, k, beta, l, glwe[i], ksk, want[i])
     assert np.array_equal(_host(dout), want)
+
+
+@pytest.mark.gpu
+def test_gpu_host_buffer_forms_of_the_batch_surfaces(pkg, oracle):
+    """fhe_tr_dot / fhe_tr_mul_r / fhe_glev_mul / fhe_glwe_key_switch take host buffers (what a
+    shim of gfhe binds); same words as the oracle, batch > 1"""
+    import ctypes
+    L, chk = pkg.load_library(), pkg.binding._check
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    q, n, k, beta, l, batch = Q16, 64, 3, 2, 16, 2
+    plan = pkg.Plan(q, n)
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, q, (batch, k, n), dtype=np.uint64)
+    b = rng.integers(0, q, (batch, k, n), dtype=np.uint64)
+    p = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    c, wc = np.empty((batch, n), dtype=np.uint64), np.empty((batch, n), dtype=np.uint64)
+    out, wo = np.empty_like(a), np.empty_like(a)
+    chk(L.fhe_tr_dot(plan.handle, vp(a), vp(b), vp(c), k, batch))
+    chk(L.fhe_tr_mul_r(plan.handle, vp(a), vp(p), vp(out), k, batch))
+    for i in range(batch):
+        oracle.glue("tr_dot", q, n, k, a[i], b[i], wc[i])
+        oracle.glue("tr_mul_r", q, n, k, a[i], p[i], wo[i])
+    assert np.array_equal(c, wc) and np.array_equal(out, wo)
+
+    glev = rng.integers(0, q, (l, k + 1, n), dtype=np.uint64)
+    v = rng.integers(0, q, (batch, l, n), dtype=np.uint64)
+    glwe = rng.integers(0, q, (batch, k + 1, n), dtype=np.uint64)
+    ksk = rng.integers(0, q, (k, l, k + 1, n), dtype=np.uint64)
+    got, want = np.empty((batch, k + 1, n), dtype=np.uint64), np.empty((batch, k + 1, n), dtype=np.uint64)
+    chk(L.fhe_glev_mul(plan.handle, k, l, vp(glev), vp(v), vp(got), batch))
+    for i in range(batch):
+        oracle.glue("glev_mul", q, n, k, l, glev, v[i], want[i])
+    assert np.array_equal(got, want)
+    chk(L.fhe_glwe_key_switch(plan.handle, k, beta, l, vp(glwe), vp(ksk), vp(got), batch))
+    for i in range(batch):
+        oracle.glue("key_switch", q, n, k, beta, l, glwe[i], ksk, want[i])
+    assert np.array_equal(got, want)

@@ -11,9 +11,9 @@ from conftest import ROOT
 HOST = os.path.join(ROOT, "fhe-study_amd", "host")
 
 
-def _build(pkg):
+def _build(pkg, exe="test_arith"):
     subprocess.check_call(["make", "-s", "-C", HOST])
-    return os.path.join(HOST, "test_arith")
+    return os.path.join(HOST, exe)
 
 
 def test_host_mirror_builds_against_the_c_abi(pkg):
@@ -27,3 +27,17 @@ def test_host_mirror_reference_tests(pkg):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all host C++ tests passed" in r.stdout
+
+
+def test_gfhe_mirror_builds_against_the_c_abi(pkg):
+    assert os.path.exists(_build(pkg, "test_gfhe"))
+
+
+@pytest.mark.gpu
+def test_gfhe_mirror_reference_tests(pkg):
+    """gfhe.hpp: TR / GLWE / GLev / key_switch over the host-buffer N3 entry points; restates
+    gfhe/src/glwe.rs:582-626 (test_key_switch) and checks every surface against its definition"""
+    exe = _build(pkg, "test_gfhe")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all host C++ gfhe tests passed" in r.stdout

@@ -33,6 +33,7 @@ int fhe_fail(int code, const char *fmt, ...) {
     return code;
 }
 int fhe_hip_fail(hipError_t e, const char *what) {
+    (void)hipGetLastError();   // the error is reported through the return code: leave no sticky state behind
     return fhe_fail(FHE_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 #define fail fhe_fail
@@ -264,11 +265,19 @@ int fhe_workspace_get(int slot, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lk(g_ws_lock);
     Workspace &w = g_ws[slot][dev];
     if (w.bytes < bytes) {
+        // grow geometrically so that the buffers retired on the way sum to less than the live one
+        size_t want = w.bytes + w.bytes / 2;
+        if (want < bytes) want = bytes;
         void *p = nullptr;
-        HIP_TRY(hipMalloc(&p, bytes));
+        if (want != bytes && hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            want = bytes;
+        }
+        if (!p) HIP_TRY(hipMalloc(&p, want));
         if (w.ptr) g_ws_retired.push_back(w.ptr);
         w.ptr = p;
-        w.bytes = bytes;
+        w.bytes = want;
     }
     *out = w.ptr;
     return FHE_OK;

@@ -400,3 +400,20 @@ def test_host_entry_points_are_reentrant(pkg, oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
+def test_allocation_failure_is_reported_and_the_library_stays_usable(pkg, oracle):
+    """a workspace the device cannot hold (64 TiB) must come back as FHE_E_HIP before anything is
+    launched, leave no sticky HIP error behind, and the next call must work"""
+    import torch
+    B, L = pkg.binding, pkg.load_library()
+    n = 65536
+    plan = pkg.Plan(Q61, n)
+    d = torch.zeros(2 * n, dtype=torch.int64, device="cuda")
+    rc = L.fhe_rq_mul_dev(plan.handle, d.data_ptr(), 0, d.data_ptr(), 0, d.data_ptr(), None, None, None,
+                          1 << 26, None, None)
+    assert rc == B.FHE_E_HIP, rc
+    assert b"hipMalloc" in L.fhe_last_error() or b"memory" in L.fhe_last_error().lower()
+    a = oracle.fill_synthetic(Q61, 9, 0, 2 * n)
+    assert np.array_equal(plan.forward(a), oracle.ntt(Q61, n, a))

@@ -282,7 +282,74 @@ int fhe_workspace_get(int slot, size_t bytes, void **out) {
     *out = w.ptr;
     return FHE_OK;
 }
+// ---- staging pool for the host-buffer entry points -------------------------------------------
+// A shim that swaps the bodies of NTT::ntt / Rq mul calls in once per polynomial; hipMalloc +
+// hipFree (which drains the device) per call cost more than the transform.  Idle staging buffers
+// are kept per device — at most kStageSlots of them, kStageCapBytes in total, none above
+// kStageMaxOne — and handed out best-fit.  A buffer is released only after the stream that used
+// it has been synchronised, so reuse needs no further ordering.
+namespace {
+struct StageBuf { void *ptr; size_t bytes; int dev; };
+constexpr size_t kStageSlots = 16, kStageCapBytes = 1ull << 30, kStageMaxOne = 256ull << 20;
+std::mutex g_stage_lock;
+std::vector<StageBuf> g_stage_idle;
+size_t g_stage_idle_bytes = 0;
+}  // namespace
+
+int fhe_stage_acquire(size_t bytes, void **out, size_t *got) {
+    int dev = 0;
+    int rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    if (bytes == 0) bytes = 16;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_lock);
+        size_t best = g_stage_idle.size();
+        for (size_t i = 0; i < g_stage_idle.size(); i++) {
+            const StageBuf &b = g_stage_idle[i];
+            if (b.dev == dev && b.bytes >= bytes && b.bytes <= 4 * bytes + 4096 &&
+                (best == g_stage_idle.size() || b.bytes < g_stage_idle[best].bytes))
+                best = i;
+        }
+        if (best != g_stage_idle.size()) {
+            *out = g_stage_idle[best].ptr;
+            *got = g_stage_idle[best].bytes;
+            g_stage_idle_bytes -= g_stage_idle[best].bytes;
+            g_stage_idle.erase(g_stage_idle.begin() + best);
+            return FHE_OK;
+        }
+    }
+    // round small requests up so that nearby sizes share buffers
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, want));
+    *out = p;
+    *got = want;
+    return FHE_OK;
+}
+
+void fhe_stage_release(void *ptr, size_t bytes) {
+    if (!ptr) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && bytes <= kStageMaxOne) {
+        std::lock_guard<std::mutex> lk(g_stage_lock);
+        if (g_stage_idle.size() < kStageSlots && g_stage_idle_bytes + bytes <= kStageCapBytes) {
+            g_stage_idle.push_back(StageBuf{ptr, bytes, dev});
+            g_stage_idle_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(ptr);
+}
+
+static void stage_free_all() {
+    std::lock_guard<std::mutex> lk(g_stage_lock);
+    for (auto &b : g_stage_idle) (void)hipFree(b.ptr);
+    g_stage_idle.clear();
+    g_stage_idle_bytes = 0;
+}
+
 void fhe_workspace_free_all() {
+    stage_free_all();
     std::lock_guard<std::mutex> lk(g_ws_lock);
     for (auto &slot : g_ws)
         for (auto &w : slot) {
@@ -499,14 +566,18 @@ extern "C" int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_
 // ---------------------------------------------------------------------------
 // host-buffer entry points: stage through device memory around the same kernels
 // ---------------------------------------------------------------------------
+// Every host entry point synchronises its stream before it returns; on an error path the
+// buffer may still be in use, so it is drained before going back to the pool.
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
-        return FHE_OK;
+    size_t cap = 0;
+    bool clean = false;   // set once the stream has been synchronised after the last use
+    ~DevBuf() {
+        if (!p) return;
+        if (!clean) (void)hipStreamSynchronize(hipStreamPerThread);
+        fhe_stage_release(p, cap);
     }
+    int alloc(size_t bytes) { return fhe_stage_acquire(bytes, &p, &cap); }
 };
 
 static int host_transform(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t *out, size_t batch,
@@ -527,6 +598,7 @@ static int host_transform(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t
     if (rc != FHE_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out, d.p, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    d.clean = true;
     return FHE_OK;
 }
 
@@ -566,6 +638,7 @@ extern "C" int fhe_rq_mul(const fhe_ntt_plan *plan, const uint64_t *a, int a_is_
     if (a_evals_out) HIP_TRY(hipMemcpyAsync(a_evals_out, da.p, bytes, hipMemcpyDeviceToHost, st));
     if (b_evals_out) HIP_TRY(hipMemcpyAsync(b_evals_out, db.p, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    da.clean = db.clean = dc.clean = dce.clean = true;
     return FHE_OK;
 }
 
@@ -601,6 +674,7 @@ extern "C" int fhe_rq_pointwise_mul(const fhe_ntt_plan *plan, const uint64_t *a,
     if (rc != FHE_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c, da.p, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    da.clean = db.clean = true;
     return FHE_OK;
 }
 
@@ -623,6 +697,7 @@ extern "C" int fhe_rq_check_canonical(const fhe_ntt_plan *plan, const uint64_t *
     int flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, df.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    dx.clean = df.clean = true;
     if (flag) return fail(FHE_E_NOT_CANONICAL, "a coefficient >= q=%llu was found", (unsigned long long)plan->q);
     return FHE_OK;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/fhe_ntt.h"
@@ -45,6 +46,9 @@ int fhe_workspace_get(int slot, size_t bytes, void **out);
 // launch until the results are back on the host.
 std::mutex &fhe_host_workspace_lock();
 void fhe_workspace_free_all();
+// pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
+int fhe_stage_acquire(size_t bytes, void **out, size_t *got);
+void fhe_stage_release(void *ptr, size_t bytes);
 
 static inline bool fhe_misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 #define REQUIRE_ALIGNED(p)                                                                          \
@@ -69,16 +73,21 @@ static inline unsigned fhe_ew_grid(fhe::u64 count) {
 // the calling thread's stream, holds fhe_host_workspace_lock() until its destructor body has
 // freed the device buffers (hipFree drains the stream on error paths).
 struct FheHostStage {
-    std::vector<void *> bufs;
+    std::vector<std::pair<void *, size_t>> bufs;
+    bool clean = false;   // the stream has been synchronised after the last use of the buffers
     std::lock_guard<std::mutex> ws_lock{fhe_host_workspace_lock()};
-    ~FheHostStage() { for (void *p : bufs) if (p) (void)hipFree(p); }
+    ~FheHostStage() {
+        if (!clean) (void)hipStreamSynchronize(hipStreamPerThread);   // error path: drain before reuse
+        for (auto &b : bufs) fhe_stage_release(b.first, b.second);
+    }
     int up(const void *h, size_t bytes, void **d) {
         *d = nullptr;
-        hipError_t e = hipMalloc(d, bytes ? bytes : 16);
-        if (e != hipSuccess) return fhe_hip_fail(e, "hipMalloc");
-        bufs.push_back(*d);
+        size_t got = 0;
+        int rc = fhe_stage_acquire(bytes, d, &got);
+        if (rc != FHE_OK) return rc;
+        bufs.emplace_back(*d, got);
         if (h && bytes) {
-            e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, hipStreamPerThread);
+            hipError_t e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, hipStreamPerThread);
             if (e != hipSuccess) return fhe_hip_fail(e, "hipMemcpyAsync H2D");
         }
         return FHE_OK;
@@ -86,6 +95,7 @@ struct FheHostStage {
     int down(void *h, const void *d, size_t bytes) {
         HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, hipStreamPerThread));
         HIP_TRY(hipStreamSynchronize(hipStreamPerThread));
+        clean = true;
         return FHE_OK;
     }
 };

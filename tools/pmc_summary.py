@@ -5,14 +5,22 @@ profiles/<round>_pmc_traffic.json, the file bench.py reads `roofline.traffic` fr
 usage: python tools/pmc_summary.py <fetch_dir> <write_dir> <polys_per_launch> <out.json>
 Counter units are KiB; on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes and is doubled
 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 
-NAMES = {  # rocprofv3 kernel name prefix -> name used by the library's kernel timer
-    "ntt_fwd_strided_kernel<8, 32, true>": "ntt_fwd_strided_8",
-    "ntt_fwd_contig_kernel<8, true, true>": "ntt_fwd_contig_final_8",
-    "ntt_inv_contig_kernel<8, false, false>": "ntt_inv_contig_8",
-    "ntt_inv_strided_kernel<8, 32>": "ntt_inv_strided_8",
-}
+NAMES = [  # (regex on the rocprofv3 kernel name, name used by the library's kernel timer)
+    (r"ntt_fwd_strided_kernel<8, 32, true(, false)?>", "ntt_fwd_strided_8"),
+    (r"ntt_fwd_contig_kernel<8, true, true(, 0)?>", "ntt_fwd_contig_final_8"),
+    (r"ntt_inv_contig_kernel<8, false, false>", "ntt_inv_contig_8"),
+    (r"ntt_inv_strided_kernel<8, 32>", "ntt_inv_strided_8"),
+]
+
+
+def short_name(rname):
+    for pat, short in NAMES:
+        m = re.search(pat, rname)
+        if m:
+            return short, m.group(0)
+    return None, None
 
 
 def per_kernel(d, counter):
@@ -40,13 +48,13 @@ def main():
                      "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM",
            "polynomials_per_launch": polys, "kernels": {}}
     for rname, f_kb in fetch.items():
-        short = next((s for p, s in NAMES.items() if p in rname), None)
+        short, matched = short_name(rname)
         if short is None or rname not in write:
             continue
         w_kb = write[rname]
         hbm = (2.0 * f_kb + w_kb) * 1024.0
         res["kernels"][short] = {
-            "rocprof_name": next(p for p in NAMES if p in rname),
+            "rocprof_name": matched,
             "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
             "hbm_bytes_per_launch": hbm, "hbm_bytes_per_polynomial": hbm / polys,
             "algorithmic_bytes_per_polynomial": n * 16,
@@ -54,6 +62,8 @@ def main():
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res["kernels"], indent=1))
+    if not res["kernels"]:
+        sys.exit("pmc_summary: no kernel matched — update NAMES")
 
 
 if __name__ == "__main__":

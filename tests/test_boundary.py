@@ -148,3 +148,17 @@ def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
     assert L.fhe_tn_mul_dev(8, None, None, None, 0, None) == 0
     assert L.fhe_bfv_mul_dev(Q16, 16, 2, Q16 * Q16 * Q16, None, None, None, 0, None) == 0
     assert L.fhe_tr_dot_dev(plan.handle, None, None, None, 2, 0, 0, None) == 0
+
+
+def test_header_is_plain_c_and_the_c_example_links(pkg, tmp_path):
+    """include/fhe_ntt.h must be consumable from C99 (the FFI of any language binds C), and
+    examples/rq_mul.c must link against the library using nothing else"""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "fhe_ntt.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    exe = str(tmp_path / "rq_mul")
+    libdir = os.path.dirname(pkg.binding.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-O1", "-o", exe,
+                           os.path.join(ROOT, "examples", "rq_mul.c"), "-L" + libdir, "-lfhe_ntt",
+                           "-Wl,-rpath," + libdir])
+    assert os.path.exists(exe)

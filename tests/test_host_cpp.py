@@ -41,3 +41,16 @@ def test_gfhe_mirror_reference_tests(pkg):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all host C++ gfhe tests passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_example_runs(pkg, tmp_path):
+    """examples/rq_mul.c: the boundary from C99 — the reference's product KAT and a 1000-polynomial
+    round trip through the host-buffer entry points"""
+    exe = str(tmp_path / "rq_mul")
+    libdir = os.path.join(ROOT, "fhe-study_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-o", exe, os.path.join(ROOT, "examples", "rq_mul.c"),
+                           "-L" + libdir, "-lfhe_ntt", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bit-exact" in r.stdout

@@ -54,3 +54,31 @@ def test_plain_c_example_runs(pkg, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-exact" in r.stdout
+
+
+def test_bfv_mirror_builds_against_the_c_abi(pkg):
+    assert os.path.exists(_build(pkg, "test_bfv"))
+
+
+@pytest.mark.gpu
+def test_bfv_mirror_reference_tests(pkg):
+    """bfv.hpp: RLWE::tensor / RLWE::mul / tmp_naive_mul over the C ABI; restates
+    bfv/src/lib.rs:504-601 (test_tensor, test_mul_relin: decrypt(c1*c2) == m1*m2)"""
+    exe = _build(pkg, "test_bfv")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all host C++ bfv tests passed" in r.stdout
+
+
+def test_tfhe_mirror_builds_against_the_c_abi(pkg):
+    assert os.path.exists(_build(pkg, "test_tfhe"))
+
+
+@pytest.mark.gpu
+def test_tfhe_mirror_reference_tests(pkg):
+    """tfhe.hpp: Tn * Tn and TGGSW * TGLWE over the C ABI; restates tfhe/src/tggsw.rs:157-196
+    (test_external_product: decode(decrypt(TGGSW(m1) * TGLWE(m2))) == m1*m2)"""
+    exe = _build(pkg, "test_tfhe")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all host C++ tfhe tests passed" in r.stdout

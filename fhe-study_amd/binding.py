@@ -55,6 +55,7 @@ EXPORTS = [
     "fhe_tr_dot", "fhe_tr_mul_r", "fhe_glev_mul", "fhe_glwe_key_switch",
     "fhe_rq_add_dev", "fhe_rq_sub_dev", "fhe_rq_neg_dev", "fhe_rq_mul_by_u64_dev",
     "fhe_rq_mod_switch_dev", "fhe_rq_mul_div_round_dev", "fhe_rq_decompose_dev",
+    "fhe_rq_remodule_dev", "fhe_rq_mul_by_f64_dev", "fhe_rq_div_round_dev",
 ]
 
 
@@ -195,6 +196,9 @@ def load_library():
     L.fhe_rq_mod_switch_dev.argtypes = [_u64, _u64, _vp, _vp, _sz, _vp]
     L.fhe_rq_mul_div_round_dev.argtypes = [_u64, _u64, _u64, _vp, _vp, _sz, _vp]
     L.fhe_rq_decompose_dev.argtypes = [_u64, _u64, _uint, _uint, _vp, _vp, _sz, _vp]
+    L.fhe_rq_remodule_dev.argtypes = [_u64, _vp, _vp, _sz, _vp]
+    L.fhe_rq_mul_by_f64_dev.argtypes = [_u64, ctypes.c_double, _vp, _vp, _sz, _vp]
+    L.fhe_rq_div_round_dev.argtypes = [_u64, _u64, _vp, _vp, _sz, _vp]
     L.fhe_ntt_device_count.argtypes = []
     L.fhe_last_error.restype = ctypes.c_char_p
     L.fhe_ntt_version.restype = ctypes.c_char_p

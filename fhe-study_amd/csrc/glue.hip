@@ -78,6 +78,26 @@ __global__ __launch_bounds__(256) void rq_mul_div_round_kernel(const u64 *__rest
     }
 }
 
+__device__ __forceinline__ u64 zq_from_f64(u64 q, double x) {   // Zq::from_f64, zq.rs:32-39
+    const long long e = f64_as_i64_sat(round(x)), qi = (long long)q;
+    return (e < 0 || e >= qi) ? (u64)(((e % qi) + qi) % qi) : (u64)e;
+}
+
+// Rq::remodule(p) ring_nq.rs:82-88 (Zq::from_u64 per coefficient), Rq::mul_by_f64 :282-292,
+// Rq::div_round :299-306 (+ Rq::from_vec_f64 -> Zq::from_f64)
+enum class EwF { Remodule, MulF64, DivRound };
+template <EwF OP>
+__global__ __launch_bounds__(256) void ewf_kernel(const u64 *__restrict__ a, u64 *__restrict__ c, u64 count,
+                                                  u64 q, u64 su, double sf) {
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const u64 v = a[i];
+        if (OP == EwF::Remodule) c[i] = v >= q ? v % q : v;                       // q = the new modulus p
+        else if (OP == EwF::MulF64) c[i] = zq_from_f64(q, (double)v * sf);
+        else c[i] = zq_from_f64(q, round((double)v / (double)su));
+    }
+}
+
 // Rq::decompose(beta, l), ring_nq.rs:67-78 with Zq::decompose zq.rs:141-207.
 // input row r = (group r / grp, member r % grp) lives at a + group*gstride + member*n (so the k
 // mask rows of each (k+1)-row ciphertext can be picked without a gather); out [rows][l][n]
@@ -189,6 +209,37 @@ extern "C" int fhe_rq_mul_div_round_dev(uint64_t q, uint64_t num, uint64_t den, 
     if (rc != FHE_OK) return rc;
     hipLaunchKernelGGL(fhe::rq_mul_div_round_kernel, dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)num, (u64)den);
     LAUNCH_OK("rq_mul_div_round_kernel");
+    return FHE_OK;
+}
+extern "C" int fhe_rq_remodule_dev(uint64_t p, const void *d_a, void *d_c, size_t count, void *st) {
+    if (p == 0) return fhe_fail(FHE_E_BAD_Q, "fhe_rq_remodule_dev: p = 0");
+    if (count == 0) return FHE_OK;
+    if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_remodule_dev: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL((fhe::ewf_kernel<fhe::EwF::Remodule>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)p, (u64)0, 0.0);
+    LAUNCH_OK("ewf_kernel<Remodule>");
+    return FHE_OK;
+}
+extern "C" int fhe_rq_mul_by_f64_dev(uint64_t q, double s, const void *d_a, void *d_c, size_t count, void *st) {
+    if (q == 0 || (q >> 63)) return fhe_fail(FHE_E_BAD_Q, "fhe_rq_mul_by_f64_dev: need 0 < q < 2^63");
+    if (count == 0) return FHE_OK;
+    if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mul_by_f64_dev: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL((fhe::ewf_kernel<fhe::EwF::MulF64>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)0, s);
+    LAUNCH_OK("ewf_kernel<MulF64>");
+    return FHE_OK;
+}
+extern "C" int fhe_rq_div_round_dev(uint64_t q, uint64_t s, const void *d_a, void *d_c, size_t count, void *st) {
+    if (q == 0 || (q >> 63)) return fhe_fail(FHE_E_BAD_Q, "fhe_rq_div_round_dev: need 0 < q < 2^63");
+    if (s == 0) return fhe_fail(FHE_E_INVALID, "fhe_rq_div_round_dev: s = 0");
+    if (count == 0) return FHE_OK;
+    if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_div_round_dev: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipLaunchKernelGGL((fhe::ewf_kernel<fhe::EwF::DivRound>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)s, 0.0);
+    LAUNCH_OK("ewf_kernel<DivRound>");
     return FHE_OK;
 }
 extern "C" int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, const void *d_a, void *d_out, size_t rows, void *st) {

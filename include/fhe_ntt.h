@@ -245,6 +245,13 @@ int fhe_rq_mul_by_u64_dev(const fhe_ntt_plan *plan, const void *d_a, uint64_t s,
 int fhe_rq_mod_switch_dev(uint64_t q, uint64_t p, const void *d_a, void *d_c, size_t count, void *hip_stream);
 /* Ring::mul_div_round for Rq, ring_nq.rs:100-113: Zq::from_f64(round(num * v / den)). */
 int fhe_rq_mul_div_round_dev(uint64_t q, uint64_t num, uint64_t den, const void *d_a, void *d_c, size_t count, void *hip_stream);
+/* Rq::remodule(p), ring_nq.rs:82-88: every coefficient through Zq::from_u64(p, v) (v mod p).
+ * Rq::mul_by_f64(s), ring_nq.rs:282-292: Zq::from_f64(q, v as f64 * s).
+ * Rq::div_round(s), ring_nq.rs:299-306: Zq::from_f64(q, round(v as f64 / s as f64)).
+ * f64 steps are single IEEE operations, `round` is half away from zero, `as i64` saturates. */
+int fhe_rq_remodule_dev(uint64_t p, const void *d_a, void *d_c, size_t count, void *hip_stream);
+int fhe_rq_mul_by_f64_dev(uint64_t q, double s, const void *d_a, void *d_c, size_t count, void *hip_stream);
+int fhe_rq_div_round_dev(uint64_t q, uint64_t s, const void *d_a, void *d_c, size_t count, void *hip_stream);
 /* Rq::decompose(beta, l), ring_nq.rs:67-78 with Zq::decompose zq.rs:141-207 (base 2 and
  * base beta, including their saturation branch).  a: [rows][n] -> out: [rows][l][n]. */
 int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, const void *d_a, void *d_out, size_t rows, void *hip_stream);

@@ -58,6 +58,18 @@ void oracle_rq_mul_div_round(uint64_t q, uint64_t n, const uint64_t *a, uint64_t
     for (uint64_t i = 0; i < n; i++)
         c[i] = oracle_zq_from_f64(q, round(((double)num * (double)a[i]) / (double)den));
 }
+/* Rq::remodule(p), ring_nq.rs:82-88 -> Rq::from_vec_u64 -> Zq::from_u64 */
+void oracle_rq_remodule(uint64_t n, const uint64_t *a, uint64_t p, uint64_t *c) {
+    for (uint64_t i = 0; i < n; i++) c[i] = zfrom_u64(p, a[i]);
+}
+/* Rq::mul_by_f64, ring_nq.rs:282-292 */
+void oracle_rq_mul_by_f64(uint64_t q, uint64_t n, const uint64_t *a, double s, uint64_t *c) {
+    for (uint64_t i = 0; i < n; i++) c[i] = oracle_zq_from_f64(q, (double)a[i] * s);
+}
+/* Rq::div_round, ring_nq.rs:299-306 (-> from_vec_f64 -> Zq::from_f64; length n: no fold) */
+void oracle_rq_div_round(uint64_t q, uint64_t n, const uint64_t *a, uint64_t s, uint64_t *c) {
+    for (uint64_t i = 0; i < n; i++) c[i] = oracle_zq_from_f64(q, round((double)a[i] / (double)s));
+}
 /* Zq::decompose, zq.rs:141-207 (base 2 and base beta), applied per coefficient and transposed:
  * Rq::decompose, ring_nq.rs:67-78.  out[d][j], d < l. */
 void oracle_rq_decompose(uint64_t q, uint64_t n, const uint64_t *a, uint32_t beta, uint32_t l,

@@ -94,7 +94,10 @@ class Oracle:
                          ("oracle_rq_neg", [_u64, _u64, _p64, _p64]), ("oracle_rq_mul_by_u64", [_u64, _u64, _p64, _u64, _p64]),
                          ("oracle_rq_mod_switch", [_u64, _u64, _p64, _u64, _p64]),
                          ("oracle_rq_mul_div_round", [_u64, _u64, _p64, _u64, _u64, _p64]),
-                         ("oracle_rq_decompose", [_u64, _u64, _p64, ctypes.c_uint32, ctypes.c_uint32, _p64])):
+                         ("oracle_rq_decompose", [_u64, _u64, _p64, ctypes.c_uint32, ctypes.c_uint32, _p64]),
+                         ("oracle_rq_remodule", [_u64, _p64, _u64, _p64]),
+                         ("oracle_rq_mul_by_f64", [_u64, _u64, _p64, ctypes.c_double, _p64]),
+                         ("oracle_rq_div_round", [_u64, _u64, _p64, _u64, _p64])):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = at
         u32 = ctypes.c_uint32

@@ -138,6 +138,8 @@ def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
     assert L.fhe_bfv_relinearize_dev(Q16, 16, Q16 - 1, d, d, d, 1, None) == B.FHE_E_BAD_Q  # pq < q
     assert L.fhe_tggsw_external_product_dev(64, 4, 65, d, d, d, 1, None) == B.FHE_E_INVALID
     assert L.fhe_rq_decompose_dev(Q16, 8, 1, 4, d, d, 1, None) == B.FHE_E_INVALID
+    assert L.fhe_rq_div_round_dev(Q16, 0, d, d, 1, None) == B.FHE_E_INVALID
+    assert L.fhe_rq_remodule_dev(0, d, d, 1, None) == B.FHE_E_BAD_Q
     assert L.fhe_glwe_key_switch_dev(plan.handle, 0, 2, 4, d, d, d, 1, 0, None) == B.FHE_E_INVALID
     assert L.fhe_glwe_key_switch_dev(plan.handle, 1, 2, 4, d, d, d, 1, B.FHE_OUT_EVALS, None) == B.FHE_E_INVALID  # key flag only
     assert L.fhe_glev_mul_dev(plan.handle, 1, 4, d, d, d, 1, 8, None) == B.FHE_E_INVALID                        # unknown flag bit

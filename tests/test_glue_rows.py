@@ -67,6 +67,14 @@ def test_oracle_elementwise_against_python(oracle):
     oracle.glue("rq_mod_switch", q, n, a, p, out)
     rr = lambda x: math.floor(x + 0.5)
     assert out.tolist() == [int(rr((float(int(x)) * float(p)) / float(q))) % p for x in a]
+    # remodule / mul_by_f64 / div_round (ring_nq.rs:82-88,282-292,299-306) against Python floats
+    oracle.glue("rq_remodule", n, a, 65537, out); assert out.tolist() == [int(x) % 65537 for x in a]
+    small = (a % np.uint64(1 << 40)).astype(np.uint64)         # keeps v*s inside i64: no saturation
+    rnd = lambda x: math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+    oracle.glue("rq_mul_by_f64", q, n, small, -2.5, out)
+    assert out.tolist() == [int(rnd(float(int(x)) * -2.5)) % q for x in small]
+    oracle.glue("rq_div_round", q, n, a, 1000, out)
+    assert out.tolist() == [int(rnd(float(int(x)) / 1000.0)) % q for x in a]
 
 
 def test_oracle_batch_surfaces_against_python(oracle):
@@ -135,6 +143,12 @@ def test_gpu_elementwise(pkg, oracle, q, n):
         chk(L.fhe_rq_mod_switch_dev(q, p, da.data_ptr(), dc.data_ptr(), batch * n, None)); cmp("rq_mod_switch", q, n, a, p, None)
     for num, den in ((2, q), (16, q), (1, 3)):
         chk(L.fhe_rq_mul_div_round_dev(q, num, den, da.data_ptr(), dc.data_ptr(), batch * n, None)); cmp("rq_mul_div_round", q, n, a, num, den, None)
+    for p in (2, 65537, q, (1 << 63) - 25):
+        chk(L.fhe_rq_remodule_dev(p, da.data_ptr(), dc.data_ptr(), batch * n, None)); cmp("rq_remodule", n, a, p, None)
+    for s in (0.0, 1.0, -2.5, 0.333, 1e6, -1e30):                 # the last saturates `as i64`
+        chk(L.fhe_rq_mul_by_f64_dev(q, s, da.data_ptr(), dc.data_ptr(), batch * n, None)); cmp("rq_mul_by_f64", q, n, a, s, None)
+    for s in (1, 2, 1000, q - 1, (1 << 64) - 1):
+        chk(L.fhe_rq_div_round_dev(q, s, da.data_ptr(), dc.data_ptr(), batch * n, None)); cmp("rq_div_round", q, n, a, s, None)
 
 
 @pytest.mark.gpu

@@ -53,6 +53,7 @@ EXPORTS = [
     # rows N3/N4: batch surfaces and element-wise glue
     "fhe_tr_dot_dev", "fhe_tr_mul_r_dev", "fhe_glev_mul_dev", "fhe_glwe_key_switch_dev",
     "fhe_tr_dot", "fhe_tr_mul_r", "fhe_glev_mul", "fhe_glwe_key_switch",
+    "fhe_tglwe_mul_tn", "fhe_tglwe_mul_tn_dev", "fhe_tglev_mul", "fhe_tglev_mul_dev",
     "fhe_rq_add_dev", "fhe_rq_sub_dev", "fhe_rq_neg_dev", "fhe_rq_mul_by_u64_dev",
     "fhe_rq_mod_switch_dev", "fhe_rq_mul_div_round_dev", "fhe_rq_decompose_dev",
     "fhe_rq_remodule_dev", "fhe_rq_mul_by_f64_dev", "fhe_rq_div_round_dev",
@@ -185,6 +186,10 @@ def load_library():
     L.fhe_tr_mul_r_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
     L.fhe_glev_mul_dev.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]
     L.fhe_glwe_key_switch_dev.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]
+    L.fhe_tglwe_mul_tn.argtypes = [_u64, _uint, _vp, _vp, _vp, _sz]
+    L.fhe_tglwe_mul_tn_dev.argtypes = [_u64, _uint, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_tglev_mul.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz]
+    L.fhe_tglev_mul_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
     L.fhe_tr_dot.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz]
     L.fhe_tr_mul_r.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz]
     L.fhe_glev_mul.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz]
@@ -355,6 +360,25 @@ def tn_mul(n, a, b):
     out = np.empty_like(a)
     _check(load_library().fhe_tn_mul(n, pa, pb, out.ctypes.data_as(_vp), a.size // n))
     return out
+
+
+def tglwe_mul_tn(n, k, tglwe, p):
+    """TGLWE x Tn (tfhe/src/tglwe.rs:182-194); tglwe [batch][(k+1)][n], p [batch][n]"""
+    c, pc = _host(tglwe)
+    t, pt = _host(p)
+    out = np.empty_like(c)
+    _check(load_library().fhe_tglwe_mul_tn(n, k, pc, pt, out.ctypes.data_as(_vp), t.size // n))
+    return out
+
+
+def tglev_mul(n, k, l, tglev, v):
+    """TGLev x Vec<Tn> (tfhe/src/tggsw.rs:139-149); tglev [l][(k+1)][n], v [batch][l][n] -> [batch][(k+1)][n]"""
+    g, pg = _host(tglev)
+    d, pd = _host(v)
+    batch = d.size // (l * n)
+    out = np.empty(batch * (k + 1) * n, dtype=np.uint64)
+    _check(load_library().fhe_tglev_mul(n, k, l, pg, pd, out.ctypes.data_as(_vp), batch))
+    return out.reshape(batch, k + 1, n)
 
 
 def tggsw_external_product(n, k, l, tggsw, tglwe):

@@ -492,6 +492,70 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
     return z_crt(z, true, R, R + orows * n, R + 2 * orows * n, (u64 *)d_out, orows * n, st);
 }
 
+// ---- TFHE: TGLWE x Tn (plaintext product) and TGLev x Vec<Tn> -------------------------------------
+// tfhe/src/tglwe.rs:182-194: every component of the ciphertext times one torus polynomial.
+// d_tglwe, d_out [batch][(k+1)][n]; d_p [batch][n].  Full 64 x 64-bit operands: 3 primes.
+extern "C" int fhe_tglwe_mul_tn_dev(uint64_t n, unsigned k, const void *d_tglwe, const void *d_p, void *d_out,
+                                    size_t batch, void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_tglwe_mul_tn_dev");
+    if (rc != FHE_OK) return rc;
+    if (k < 1 || k > 64) return fhe_fail(FHE_E_INVALID, "fhe_tglwe_mul_tn_dev: need 1 <= k <= 64");
+    if (batch == 0) return FHE_OK;
+    if (!d_tglwe || !d_p || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tglwe_mul_tn_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_tglwe); REQUIRE_ALIGNED(d_p); REQUIRE_ALIGNED(d_out);
+    const u32 k1 = k + 1;
+    ZCtx z;
+    rc = zctx_init(&z, n, primes_for_bits(128 + ceil_log2(n), true));   // |c_j| < n * 2^128
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 rows = batch * k1;
+    void *wsv = nullptr;
+    rc = fhe_workspace_get(1, (rows + batch + (size_t)z.K * rows) * n * 8, &wsv);
+    if (rc != FHE_OK) return rc;
+    u64 *A = (u64 *)wsv, *P = A + rows * n, *R = P + batch * n;
+    for (int kk = 0; kk < z.K; kk++) {
+        if ((rc = z_forward_src(z, kk, (const u64 *)d_tglwe, A, rows, n, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, kk, (const u64 *)d_p, P, batch, n, st)) != FHE_OK) return rc;
+        u64 *Rk = R + (u64)kk * rows * n;
+        // T = 1 term, nc = k+1 rows, "key" = the ciphertext itself (per batch element)
+        hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, k1, n))), dim3(256), 0, st, (const u64 *)A, (const u64 *)P, Rk, (u64)batch, (u32)n, (u32)1, k1, (u64)k1 * n, z.cc.m[kk]);
+        LAUNCH_OK("mac_rows_kernel");
+        if ((rc = z_inverse(z, kk, Rk, Rk, rows, st)) != FHE_OK) return rc;
+    }
+    return z_crt(z, true, R, R + rows * n, R + 2 * rows * n, (u64 *)d_out, rows * n, st);
+}
+
+// tfhe/src/tggsw.rs:139-149: out[b] = sum_{d<l} tglev[d] * v[b][d]  (TGLWE x Tn summed over the levels).
+// d_tglev [l][(k+1)][n] (one for the batch); d_v [batch][l][n] (any 64-bit words); d_out [batch][(k+1)][n].
+extern "C" int fhe_tglev_mul_dev(uint64_t n, unsigned k, unsigned l, const void *d_tglev, const void *d_v, void *d_out,
+                                 size_t batch, void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_tglev_mul_dev");
+    if (rc != FHE_OK) return rc;
+    if (l < 1 || l > 64 || k < 1 || k > 64) return fhe_fail(FHE_E_INVALID, "fhe_tglev_mul_dev: need 1 <= l <= 64, 1 <= k <= 64");
+    if (batch == 0) return FHE_OK;
+    if (!d_tglev || !d_v || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tglev_mul_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_tglev); REQUIRE_ALIGNED(d_v); REQUIRE_ALIGNED(d_out);
+    const u32 k1 = k + 1;
+    ZCtx z;
+    rc = zctx_init(&z, n, primes_for_bits(128 + ceil_log2(n) + ceil_log2(l), true));   // |sum| < l * n * 2^128
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 grows = (u64)l * k1, vrows = batch * l, orows = batch * k1;
+    void *wsv = nullptr;
+    rc = fhe_workspace_get(1, (grows + vrows + (size_t)z.K * orows) * n * 8, &wsv);
+    if (rc != FHE_OK) return rc;
+    u64 *G = (u64 *)wsv, *V = G + grows * n, *R = V + vrows * n;
+    for (int kk = 0; kk < z.K; kk++) {
+        if ((rc = z_forward_src(z, kk, (const u64 *)d_tglev, G, grows, n, st)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, kk, (const u64 *)d_v, V, vrows, n, st)) != FHE_OK) return rc;
+        u64 *Rk = R + (u64)kk * orows * n;
+        hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, k1, n))), dim3(256), 0, st, (const u64 *)G, (const u64 *)V, Rk, (u64)batch, (u32)n, (u32)l, k1, (u64)0, z.cc.m[kk]);
+        LAUNCH_OK("mac_rows_kernel");
+        if ((rc = z_inverse(z, kk, Rk, Rk, orows, st)) != FHE_OK) return rc;
+    }
+    return z_crt(z, true, R, R + orows * n, R + 2 * orows * n, (u64 *)d_out, orows * n, st);
+}
+
 // ---- host-buffer wrappers (what a Rust shim binds) ------------------------------------------------
 using HostStage = FheHostStage;
 
@@ -569,6 +633,38 @@ extern "C" int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, co
     if ((rc = hs.up(tglwe, batch * k1 * n * 8, &dt)) != FHE_OK) return rc;
     if ((rc = hs.up(nullptr, batch * k1 * n * 8, &dout)) != FHE_OK) return rc;
     rc = fhe_tggsw_external_product_dev(n, k, l, dg, dt, dout, batch, hipStreamPerThread);
+    if (rc != FHE_OK) return rc;
+    return hs.down(out, dout, batch * k1 * n * 8);
+}
+
+extern "C" int fhe_tglwe_mul_tn(uint64_t n, unsigned k, const uint64_t *tglwe, const uint64_t *p, uint64_t *out, size_t batch) {
+    if (batch == 0) return FHE_OK;
+    if (!tglwe || !p || !out) return fhe_fail(FHE_E_NULL, "fhe_tglwe_mul_tn: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    HostStage hs;
+    void *dc, *dp, *dout;
+    const size_t k1 = (size_t)k + 1;
+    if ((rc = hs.up(tglwe, batch * k1 * n * 8, &dc)) != FHE_OK) return rc;
+    if ((rc = hs.up(p, batch * n * 8, &dp)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * k1 * n * 8, &dout)) != FHE_OK) return rc;
+    rc = fhe_tglwe_mul_tn_dev(n, k, dc, dp, dout, batch, hipStreamPerThread);
+    if (rc != FHE_OK) return rc;
+    return hs.down(out, dout, batch * k1 * n * 8);
+}
+
+extern "C" int fhe_tglev_mul(uint64_t n, unsigned k, unsigned l, const uint64_t *tglev, const uint64_t *v, uint64_t *out, size_t batch) {
+    if (batch == 0) return FHE_OK;
+    if (!tglev || !v || !out) return fhe_fail(FHE_E_NULL, "fhe_tglev_mul: NULL buffer");
+    int dev, rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    HostStage hs;
+    void *dg, *dv, *dout;
+    const size_t k1 = (size_t)k + 1;
+    if ((rc = hs.up(tglev, (size_t)l * k1 * n * 8, &dg)) != FHE_OK) return rc;
+    if ((rc = hs.up(v, batch * l * n * 8, &dv)) != FHE_OK) return rc;
+    if ((rc = hs.up(nullptr, batch * k1 * n * 8, &dout)) != FHE_OK) return rc;
+    rc = fhe_tglev_mul_dev(n, k, l, dg, dv, dout, batch, hipStreamPerThread);
     if (rc != FHE_OK) return rc;
     return hs.down(out, dout, batch * k1 * n * 8);
 }

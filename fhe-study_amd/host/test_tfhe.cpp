@@ -127,9 +127,35 @@ static void test_tn_mul() {
     }
 }
 
+// TGLWE * Tn and TGLev * Vec<Tn> against the compositions the reference writes
+// (tglwe.rs:182-194: r_i * plaintext; tggsw.rs:139-149: zip(v, tlwes).map(glwe_i * a_d_i).sum())
+static void test_tglwe_and_tglev_products() {
+    const size_t n = 64, k = 3, l = 5;
+    auto rand_tglwe = [&] { TGLWE c; for (size_t i = 0; i < k; i++) c.a.push_back(rand_uniform(n)); c.b = rand_uniform(n); return c; };
+    TGLWE c = rand_tglwe();
+    Tn p = rand_uniform(n);
+    TGLWE cp = c * p;
+    EXPECT(cp.b == c.b * p);
+    for (size_t i = 0; i < k; i++) EXPECT(cp.a[i] == c.a[i] * p);
+
+    TGLev g;
+    std::vector<Tn> v;
+    for (size_t d = 0; d < l; d++) { g.rows.push_back(rand_tglwe()); v.push_back(rand_uniform(n)); }
+    TGLWE sum = g.rows[0] * v[0];
+    for (size_t d = 1; d < l; d++) {
+        TGLWE term = g.rows[d] * v[d];
+        for (size_t i = 0; i < k; i++) sum.a[i] = sum.a[i] + term.a[i];
+        sum.b = sum.b + term.b;
+    }
+    TGLWE gv = g * v;
+    EXPECT(gv.b == sum.b);
+    for (size_t i = 0; i < k; i++) EXPECT(gv.a[i] == sum.a[i]);
+}
+
 int main() {
     if (fhe_ntt_device_count() < 1) { printf("no HIP device\n"); return 2; }
     test_tn_mul();
+    test_tglwe_and_tglev_products();
     test_external_product();
     printf(failures ? "%d FAILURES\n" : "all host C++ tfhe tests passed%.0d\n", failures);
     return failures ? 1 : 0;

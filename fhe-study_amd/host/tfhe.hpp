@@ -7,6 +7,8 @@
 //   TGLWE(GLWE<Tn>)                     tfhe/src/tglwe.rs:33   tfhe::TGLWE{a, b}
 //   TGLev(Vec<TGLWE>)                   tfhe/src/tggsw.rs:65   tfhe::TGLev
 //   TGGSW(Vec<TGLev>, TGLev)            tggsw.rs:12-14         tfhe::TGGSW
+//   TGLWE * Tn (plaintext product)      tglwe.rs:182-194       operator*(TGLWE, Tn)    fhe_tglwe_mul_tn
+//   TGLev * Vec<Tn> -> TGLWE            tggsw.rs:139-149       operator*(TGLev, vector<Tn>)  fhe_tglev_mul
 //   TGGSW * TGLWE (external product)    tggsw.rs:45-62         operator*(TGGSW, TGLWE) fhe_tggsw_external_product
 //
 // Additions are the reference's wrapping u64 adds (torus.rs:80-104) and stay on the host.
@@ -68,6 +70,35 @@ struct TGLWE {   // (a_0 .. a_{k-1}, b)
 struct TGLev { std::vector<TGLWE> rows; };          // l TGLWEs
 struct TGGSW { std::vector<TGLev> a; TGLev b; };    // k TGLevs for the mask, one for the body
 
+namespace detail {
+inline TGLWE unpack(const std::vector<uint64_t> &w, size_t k, size_t n) {
+    TGLWE r;
+    for (size_t i = 0; i < k; i++) r.a.push_back(Tn{std::vector<uint64_t>(w.begin() + i * n, w.begin() + (i + 1) * n)});
+    r.b = Tn{std::vector<uint64_t>(w.begin() + k * n, w.end())};
+    return r;
+}
+}  // namespace detail
+
+// tglwe.rs:182-194: plaintext multiplication, every component times the Tn
+inline TGLWE operator*(const TGLWE &c, const Tn &p) {
+    if (c.b.n() != p.n()) throw Panic(FHE_E_PARAM_MISMATCH, "TGLWE * Tn: different n");   // debug_assert_eq!(param)
+    std::vector<uint64_t> w = c.packed(), out(w.size());
+    arith::check(fhe_tglwe_mul_tn(p.n(), (unsigned)c.k(), w.data(), p.coeffs.data(), out.data(), 1));
+    return detail::unpack(out, c.k(), p.n());
+}
+
+// tggsw.rs:139-149: sum_d tglev[d] * v[d]
+inline TGLWE operator*(const TGLev &g, const std::vector<Tn> &v) {
+    if (g.rows.size() != v.size()) throw Panic(FHE_E_INVALID, "TGLev * Vec<Tn>: lengths differ");   // assert_eq!, :143
+    const size_t k = g.rows.at(0).k(), n = v.at(0).n(), l = v.size();
+    std::vector<uint64_t> pg, pv;
+    for (const TGLWE &row : g.rows) { std::vector<uint64_t> w = row.packed(); pg.insert(pg.end(), w.begin(), w.end()); }
+    for (const Tn &t : v) pv.insert(pv.end(), t.coeffs.begin(), t.coeffs.end());
+    std::vector<uint64_t> out((k + 1) * n);
+    arith::check(fhe_tglev_mul(n, (unsigned)k, (unsigned)l, pg.data(), pv.data(), out.data(), 1));
+    return detail::unpack(out, k, n);
+}
+
 // tggsw.rs:45-62, with beta = 2 and l = 64 as hard-coded there
 inline TGLWE operator*(const TGGSW &g, const TGLWE &c) {
     const size_t k = c.k(), n = c.b.n(), l = g.b.rows.size();
@@ -84,10 +115,7 @@ inline TGLWE operator*(const TGGSW &g, const TGLWE &c) {
     push_lev(g.b);
     std::vector<uint64_t> pc = c.packed(), out(pc.size());
     arith::check(fhe_tggsw_external_product(n, (unsigned)k, (unsigned)l, pg.data(), pc.data(), out.data(), 1));
-    TGLWE r;
-    for (size_t i = 0; i < k; i++) r.a.push_back(Tn{std::vector<uint64_t>(out.begin() + i * n, out.begin() + (i + 1) * n)});
-    r.b = Tn{std::vector<uint64_t>(out.begin() + k * n, out.end())};
-    return r;
+    return detail::unpack(out, k, n);
 }
 
 }  // namespace tfhe

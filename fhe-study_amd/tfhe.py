@@ -5,6 +5,8 @@ over the C ABI.
     Tn * Tn           ring_torus.rs:251-298            Tn.__mul__
     Tn::decompose     ring_torus.rs:67-77              (inside the external product, on the GPU)
     TGLWE(GLWE<Tn>)   tfhe/src/tglwe.rs:33             TGLWE(a [k][n], b [n])
+    TGLWE * Tn        tfhe/src/tglwe.rs:182-194        TGLWE.__mul__
+    TGLev * Vec<Tn>   tfhe/src/tggsw.rs:139-149        TGLev.__mul__
     TGGSW * TGLWE     tfhe/src/tggsw.rs:45-62          TGGSW.__mul__   (beta = 2, l = 64 as there)
 """
 import numpy as np
@@ -41,6 +43,29 @@ class TGLWE:
 
     def packed(self):
         return np.concatenate([self.a, self.b[..., None, :]], axis=-2)   # [.., k+1, n]
+
+    def __mul__(self, plaintext):
+        """plaintext multiplication, tglwe.rs:182-194: every component times the Tn"""
+        x = self.packed()
+        k = x.shape[-2] - 1
+        out = binding.tglwe_mul_tn(plaintext.n, k, x, plaintext.coeffs).reshape(x.shape)
+        return TGLWE(out[..., :k, :], out[..., k, :])
+
+
+class TGLev:
+    """l TGLWEs (tggsw.rs:65): rows [l][(k+1)][n]"""
+
+    def __init__(self, rows):
+        self.rows = np.ascontiguousarray(rows, dtype=np.uint64)
+
+    def __mul__(self, v):
+        """dot product with a Vec<Tn> (usually a decomposition), tggsw.rs:139-149"""
+        l, k1, n = self.rows.shape
+        if len(v) != l:
+            raise binding.FheError(binding.FHE_E_INVALID, "TGLev * Vec<Tn>: lengths differ")   # assert_eq!, :143
+        vv = np.stack([t.coeffs for t in v])
+        out = binding.tglev_mul(n, k1 - 1, l, self.rows, vv)[0]
+        return TGLWE(out[: k1 - 1], out[k1 - 1])
 
 
 class TGGSW:

@@ -195,6 +195,19 @@ int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, const uint64_
 int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw,
                                    const void *d_tglwe, void *d_out, size_t batch, void *hip_stream);
 
+/* TGLWE x Tn (plaintext product), tfhe/src/tglwe.rs:182-194: out[b][i] = tglwe[b][i] * p[b] mod
+ * (2^64, X^n+1), i <= k.  tglwe, out: [batch][(k+1)][n]; p: [batch][n]. */
+int fhe_tglwe_mul_tn(uint64_t n, unsigned k, const uint64_t *tglwe, const uint64_t *p, uint64_t *out, size_t batch);
+int fhe_tglwe_mul_tn_dev(uint64_t n, unsigned k, const void *d_tglwe, const void *d_p, void *d_out,
+                         size_t batch, void *hip_stream);
+/* TGLev x Vec<Tn> -> TGLWE, tfhe/src/tggsw.rs:139-149: out[b] = sum_{d<l} tglev[d] * v[b][d].
+ * tglev: [l][(k+1)][n] (one for the batch); v: [batch][l][n] (any 64-bit words, e.g. a decomposition);
+ * out: [batch][(k+1)][n]. */
+int fhe_tglev_mul(uint64_t n, unsigned k, unsigned l, const uint64_t *tglev, const uint64_t *v, uint64_t *out,
+                  size_t batch);
+int fhe_tglev_mul_dev(uint64_t n, unsigned k, unsigned l, const void *d_tglev, const void *d_v, void *d_out,
+                      size_t batch, void *hip_stream);
+
 /* ---- rows N3 / N4: batch surfaces and element-wise glue, device-resident ----
  * Sums of products are accumulated in the NTT domain and transformed back once; arithmetic
  * mod q is exact, so the words equal the reference's sum of canonical products.

@@ -297,6 +297,37 @@ def test_gpu_tn_mul(pkg, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,k,l,batch", [(64, 4, 64, 3), (1024, 1, 8, 2), (8, 2, 3, 5)])
+def test_gpu_tglwe_times_tn_and_tglev_times_vec(pkg, oracle, n, k, l, batch):
+    """TGLWE x Tn (tglwe.rs:182-194) and TGLev x Vec<Tn> (tggsw.rs:139-149) against their definitions:
+    single Tn products (the oracle's schoolbook mod 2^64) and wrapping sums"""
+    rng = np.random.default_rng(n * 7 + l)
+    c = rng.integers(0, U64, (batch, k + 1, n), dtype=np.uint64)
+    p = rng.integers(0, U64, (batch, n), dtype=np.uint64)
+    c[0] = U64 - 1
+    p[0] = U64 - 1
+    got = pkg.binding.tglwe_mul_tn(n, k, c, p)
+    want = np.stack([oracle.tn_mul(n, c[b], np.broadcast_to(p[b], (k + 1, n))) for b in range(batch)])
+    assert np.array_equal(got, want)
+
+    tglev = rng.integers(0, U64, (l, k + 1, n), dtype=np.uint64)
+    v = rng.integers(0, U64, (batch, l, n), dtype=np.uint64)
+    v[0] = U64 - 1
+    got = pkg.binding.tglev_mul(n, k, l, tglev, v)
+    want = np.zeros((batch, k + 1, n), dtype=np.uint64)
+    for b in range(batch):
+        for d in range(l):
+            want[b] += oracle.tn_mul(n, tglev[d], np.broadcast_to(v[b, d], (k + 1, n)))      # u64 add wraps
+    assert np.array_equal(got, want)
+    # the host mirror reads like the reference: TGLev * Vec<Tn>, TGLWE * Tn
+    T = pkg.tfhe
+    r = T.TGLev(tglev) * [T.Tn(v[1, d]) for d in range(l)]
+    assert np.array_equal(r.packed(), want[1])
+    r = T.TGLWE(c[1, :k], c[1, k]) * T.Tn(p[1])
+    assert np.array_equal(r.packed(), pkg.binding.tglwe_mul_tn(n, k, c[1:2], p[1:2])[0])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,k,l,batch", [(64, 4, 64, 3),      # tfhe/src/tggsw.rs:157-196 test shape
                                          (1024, 1, 64, 2),     # BASELINE.json configs[3] shape
                                          (16, 2, 8, 5),

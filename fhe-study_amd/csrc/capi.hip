@@ -296,10 +296,11 @@ std::vector<StageBuf> g_stage_idle;
 size_t g_stage_idle_bytes = 0;
 }  // namespace
 
-int fhe_stage_acquire(size_t bytes, void **out, size_t *got) {
+int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev_out) {
     int dev = 0;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    *dev_out = dev;
     if (bytes == 0) bytes = 16;
     {
         std::lock_guard<std::mutex> lk(g_stage_lock);
@@ -327,10 +328,9 @@ int fhe_stage_acquire(size_t bytes, void **out, size_t *got) {
     return FHE_OK;
 }
 
-void fhe_stage_release(void *ptr, size_t bytes) {
+void fhe_stage_release(void *ptr, size_t bytes, int dev) {
     if (!ptr) return;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && bytes <= kStageMaxOne) {
+    if (bytes <= kStageMaxOne) {
         std::lock_guard<std::mutex> lk(g_stage_lock);
         if (g_stage_idle.size() < kStageSlots && g_stage_idle_bytes + bytes <= kStageCapBytes) {
             g_stage_idle.push_back(StageBuf{ptr, bytes, dev});
@@ -571,13 +571,14 @@ extern "C" int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    int dev = 0;          // the device the buffer lives on (the caller's current device at alloc)
     bool clean = false;   // set once the stream has been synchronised after the last use
     ~DevBuf() {
         if (!p) return;
         if (!clean) (void)hipStreamSynchronize(hipStreamPerThread);
-        fhe_stage_release(p, cap);
+        fhe_stage_release(p, cap, dev);
     }
-    int alloc(size_t bytes) { return fhe_stage_acquire(bytes, &p, &cap); }
+    int alloc(size_t bytes) { return fhe_stage_acquire(bytes, &p, &cap, &dev); }
 };
 
 static int host_transform(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t *out, size_t batch,

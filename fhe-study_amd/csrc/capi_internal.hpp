@@ -47,8 +47,8 @@ int fhe_workspace_get(int slot, size_t bytes, void **out);
 std::mutex &fhe_host_workspace_lock();
 void fhe_workspace_free_all();
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
-int fhe_stage_acquire(size_t bytes, void **out, size_t *got);
-void fhe_stage_release(void *ptr, size_t bytes);
+int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);
+void fhe_stage_release(void *ptr, size_t bytes, int dev);
 
 static inline bool fhe_misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 #define REQUIRE_ALIGNED(p)                                                                          \
@@ -73,19 +73,21 @@ static inline unsigned fhe_ew_grid(fhe::u64 count) {
 // the calling thread's stream, holds fhe_host_workspace_lock() until its destructor body has
 // freed the device buffers (hipFree drains the stream on error paths).
 struct FheHostStage {
-    std::vector<std::pair<void *, size_t>> bufs;
+    struct Buf { void *p; size_t cap; int dev; };
+    std::vector<Buf> bufs;
     bool clean = false;   // the stream has been synchronised after the last use of the buffers
     std::lock_guard<std::mutex> ws_lock{fhe_host_workspace_lock()};
     ~FheHostStage() {
         if (!clean) (void)hipStreamSynchronize(hipStreamPerThread);   // error path: drain before reuse
-        for (auto &b : bufs) fhe_stage_release(b.first, b.second);
+        for (auto &b : bufs) fhe_stage_release(b.p, b.cap, b.dev);
     }
     int up(const void *h, size_t bytes, void **d) {
         *d = nullptr;
         size_t got = 0;
-        int rc = fhe_stage_acquire(bytes, d, &got);
+        int dev = 0;
+        int rc = fhe_stage_acquire(bytes, d, &got, &dev);
         if (rc != FHE_OK) return rc;
-        bufs.emplace_back(*d, got);
+        bufs.push_back(Buf{*d, got, dev});
         if (h && bytes) {
             hipError_t e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, hipStreamPerThread);
             if (e != hipSuccess) return fhe_hip_fail(e, "hipMemcpyAsync H2D");

@@ -417,3 +417,43 @@ def test_allocation_failure_is_reported_and_the_library_stays_usable(pkg, oracle
     assert b"hipMalloc" in L.fhe_last_error() or b"memory" in L.fhe_last_error().lower()
     a = oracle.fill_synthetic(Q61, 9, 0, 2 * n)
     assert np.array_equal(plan.forward(a), oracle.ntt(Q61, n, a))
+
+
+@pytest.mark.gpu
+def test_device_entry_points_can_be_captured_in_a_hip_graph(pkg, oracle):
+    """the *_dev entry points only enqueue on the caller's stream (no allocation or synchronisation
+    once the plan's tables and the workspace exist), so a launch-bound chain — here an Rq product
+    followed by a second one on its result — can be captured once and replayed"""
+    import torch
+    q, n, batch = Q61, 1024, 3
+    plan = pkg.Plan(q, n)
+    a = oracle.fill_synthetic(q, 41, 0, batch * n)
+    b = oracle.fill_synthetic(q, 42, 0, batch * n)
+    as_dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
+    da, db = as_dev(a), as_dev(b)
+    dc, dd = torch.empty_like(da), torch.empty_like(da)
+    work = torch.empty(plan.workspace_bytes(batch) // 8, dtype=torch.int64, device="cuda")
+
+    def chain(st):
+        plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, d_work=work.data_ptr(), stream=st)
+        plan.rq_mul_dev(dc.data_ptr(), db.data_ptr(), dd.data_ptr(), batch, d_work=work.data_ptr(), stream=st)
+
+    chain(torch.cuda.current_stream().cuda_stream)      # warm-up: device tables are uploaded here
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chain(torch.cuda.current_stream().cuda_stream)
+    dc.zero_(); dd.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    c = oracle.rq_mul(q, n, a, b)[0]
+    d = oracle.rq_mul(q, n, c, b)[0]
+    assert np.array_equal(dc.cpu().numpy().view(np.uint64), c.reshape(-1))
+    assert np.array_equal(dd.cpu().numpy().view(np.uint64), d.reshape(-1))
+    # new inputs, same graph
+    a2 = oracle.fill_synthetic(q, 43, 0, batch * n)
+    da.copy_(as_dev(a2))
+    g.replay()
+    torch.cuda.synchronize()
+    c2 = oracle.rq_mul(q, n, a2, b)[0]
+    assert np.array_equal(dc.cpu().numpy().view(np.uint64), c2.reshape(-1))

@@ -106,43 +106,46 @@ __global__ __launch_bounds__(256) void zr_mul_bcast_kernel(const u64 *__restrict
 // Garner: residues r1 (mod P1), r2 (mod P2), r3 (mod P3) of an integer V with |V| < P/2
 // (SIGNED) or 0 <= V < P  ->  V mod 2^64.
 template <int K, bool SIGNED>
+__device__ __forceinline__ u64 crt_value(u64 x1, u64 x2, u64 x3, const CrtConsts &cc) {
+    u64 v = x1;
+    bool neg = false;
+    if (K == 1) {
+        neg = x1 >= cc.half1;
+    } else {
+        const Mod &m2 = cc.m[1];
+        // d2 = (r2 - r1) * P1^-1 mod P2      (r1 < P1 may exceed P2: reduce first)
+        const u64 x1m2 = canon2(x1, m2);                       // P1 < 2*P2
+        const u64 diff = canon2(x2 + m2.q - x1m2, m2);
+        const u64 d2 = canon2(mul_shoup_lazy(diff, cc.inv1_mod2.w, cc.inv1_mod2.wp, m2), m2);
+        v = x1 + cc.p1 * d2;                                    // mod 2^64
+        if (K == 2) {
+            neg = d2 > cc.half2 || (d2 == cc.half2 && x1 >= cc.half1);
+        } else {
+            const Mod &m3 = cc.m[2];
+            // d3 = (r3 - r1 - P1*d2) * (P1*P2)^-1 mod P3
+            const u64 x1m3 = canon2(x1, m3);
+            const u64 d2m3 = canon2(d2, m3);
+            const u64 t = canon2(mul_shoup_lazy(d2m3, cc.p1_mod3.w, cc.p1_mod3.wp, m3), m3);
+            u64 diff3 = canon2(x3 + m3.q - x1m3, m3);
+            diff3 = canon2(diff3 + m3.q - t, m3);
+            const u64 d3 = canon2(mul_shoup_lazy(diff3, cc.inv12_mod3.w, cc.inv12_mod3.wp, m3), m3);
+            v += cc.p12_lo * d3;
+            neg = d3 > cc.half3 ||
+                  (d3 == cc.half3 && (d2 > cc.half2 || (d2 == cc.half2 && x1 >= cc.half1)));
+        }
+    }
+    if (SIGNED && neg) v -= cc.prod_lo[K - 1];
+    return v;
+}
+
+template <int K, bool SIGNED>
 __global__ __launch_bounds__(256) void zr_crt_kernel(const u64 *__restrict__ r1,
                                                      const u64 *__restrict__ r2,
                                                      const u64 *__restrict__ r3, u64 *__restrict__ out,
                                                      u64 count, CrtConsts cc) {
     const u64 stride = (u64)gridDim.x * 256;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
-        const u64 x1 = r1[i];
-        u64 v = x1;
-        bool neg = false;
-        if (K == 1) {
-            neg = x1 >= cc.half1;
-        } else {
-            const Mod &m2 = cc.m[1];
-            // d2 = (r2 - r1) * P1^-1 mod P2      (r1 < P1 may exceed P2: reduce first)
-            const u64 x1m2 = canon2(x1, m2);                       // P1 < 2*P2
-            const u64 diff = canon2(r2[i] + m2.q - x1m2, m2);
-            const u64 d2 = canon2(mul_shoup_lazy(diff, cc.inv1_mod2.w, cc.inv1_mod2.wp, m2), m2);
-            v = x1 + cc.p1 * d2;                                    // mod 2^64
-            if (K == 2) {
-                neg = d2 > cc.half2 || (d2 == cc.half2 && x1 >= cc.half1);
-            } else {
-                const Mod &m3 = cc.m[2];
-                // d3 = (r3 - r1 - P1*d2) * (P1*P2)^-1 mod P3
-                const u64 x1m3 = canon2(x1, m3);
-                const u64 d2m3 = canon2(d2, m3);
-                const u64 t = canon2(mul_shoup_lazy(d2m3, cc.p1_mod3.w, cc.p1_mod3.wp, m3), m3);
-                u64 diff3 = canon2(r3[i] + m3.q - x1m3, m3);
-                diff3 = canon2(diff3 + m3.q - t, m3);
-                const u64 d3 = canon2(mul_shoup_lazy(diff3, cc.inv12_mod3.w, cc.inv12_mod3.wp, m3), m3);
-                v += cc.p12_lo * d3;
-                neg = d3 > cc.half3 ||
-                      (d3 == cc.half3 && (d2 > cc.half2 || (d2 == cc.half2 && x1 >= cc.half1)));
-            }
-        }
-        if (SIGNED && neg) v -= cc.prod_lo[K - 1];
-        out[i] = v;
-    }
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+        out[i] = crt_value<K, SIGNED>(r1[i], K > 1 ? r2[i] : 0ull, K > 2 ? r3[i] : 0ull, cc);
 }
 
 // Rust `f64 as i64` (saturating, NaN -> 0)
@@ -175,6 +178,36 @@ __global__ __launch_bounds__(256) void zr_mul_div_round_kernel(const u64 *__rest
         const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
         const u64 zh = (j == n - 1) ? 0ull : zq_from_f64(q, round((numf * (double)hi) / denf));
         out[i] = zl >= zh ? zl - zh : (q + zl) - zh;   // Zq::sub, zq.rs:259-276
+    }
+}
+
+// The same with the Garner recombination in front and an optional Zq addend behind
+// (c0 + &r0, bfv/src/lib.rs:269): residue arrays of `rows` x 2n words in, `rows` x n words out,
+// so the recombined integers are never written.  Unsigned lift (operands are non-negative).
+template <int K>
+__global__ __launch_bounds__(256) void zr_crt_mdr_kernel(const u64 *__restrict__ r1, const u64 *__restrict__ r2,
+                                                         const u64 *__restrict__ r3, const u64 *__restrict__ addend,
+                                                         u64 *__restrict__ out, u64 rows, u32 n, u64 q, u64 num,
+                                                         u64 den, CrtConsts cc) {
+    const u64 total = rows * n, stride = (u64)gridDim.x * 256;
+    const double numf = (double)num, denf = (double)den;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 r = i / n;
+        const u32 j = (u32)(i - r * n);
+        const u64 il = r * 2 * n + j, ih = il + n;
+        const long long lo = (long long)crt_value<K, false>(r1[il], K > 1 ? r2[il] : 0ull, K > 2 ? r3[il] : 0ull, cc);
+        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
+        u64 zh = 0;
+        if (j != n - 1) {
+            const long long hi = (long long)crt_value<K, false>(r1[ih], K > 1 ? r2[ih] : 0ull, K > 2 ? r3[ih] : 0ull, cc);
+            zh = zq_from_f64(q, round((numf * (double)hi) / denf));
+        }
+        u64 v = zl >= zh ? zl - zh : (q + zl) - zh;   // Zq::sub, zq.rs:259-276
+        if (addend) {
+            v += addend[i];
+            if (v >= q) v -= q;                        // Zq::add, zq.rs:219-231
+        }
+        out[i] = v;
     }
 }
 
@@ -280,6 +313,17 @@ static int z_crt(const ZCtx &z, bool is_signed, const u64 *r1, const u64 *r2, co
     return FHE_OK;
 }
 
+// out[row][j] = (addend[row][j] +) fold(from_f64(round(num * crt(residues)[.] / den))): rows x 2n residues in
+static int z_crt_mdr(const ZCtx &z, const u64 *r1, const u64 *r2, const u64 *r3, const u64 *addend, u64 *out,
+                     u64 rows, u64 n, u64 q, u64 num, u64 den, hipStream_t st) {
+    const unsigned g = fhe_ew_grid(rows * n);
+#define MDR_CASE(K_) hipLaunchKernelGGL((fhe::zr_crt_mdr_kernel<K_>), dim3(g), dim3(256), 0, st, r1, r2, r3, addend, out, rows, (u32)n, q, num, den, z.cc)
+    if (z.K == 1) MDR_CASE(1); else if (z.K == 2) MDR_CASE(2); else MDR_CASE(3);
+#undef MDR_CASE
+    LAUNCH_OK("zr_crt_mdr_kernel");
+    return FHE_OK;
+}
+
 static unsigned bits_of(u64 x) { unsigned b = 0; while (x) { b++; x >>= 1; } return b; }
 static unsigned ceil_log2(u64 x) { return x <= 1 ? 0 : bits_of(x - 1); }
 
@@ -363,9 +407,9 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
         LAUNCH_OK("zr_tensor_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 3 * batch, st)) != FHE_OK) return rc;
     }
-    rc = z_crt(z, false, R, R + 3 * words, R + 6 * words, V, 3 * words, st);
-    if (rc != FHE_OK) return rc;
-    return fhe_mul_div_round_dev(q, n, V, t, q, d_c, 3 * batch, st);
+    // recombine, scale by t/q, round, reduce, fold — in one kernel (the integers are never stored)
+    (void)V;
+    return z_crt_mdr(z, R, R + 3 * words, R + 6 * words, nullptr, (u64 *)d_c, 3 * batch, n, q, t, q, st);
 }
 
 // d_rlk: [rlk0 | rlk1], each n words mod pq (one key for the whole batch).
@@ -397,25 +441,21 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
         LAUNCH_OK("zr_mul_bcast_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 2 * batch, st)) != FHE_OK) return rc;
     }
-    rc = z_crt(z, false, R, R + 2 * words, R + 4 * words, V, 2 * words, st);
-    if (rc != FHE_OK) return rc;
-    // r0, r1 = mul_div_round(.., 1, p); reuse Rr (2*bn <= words) for them
-    rc = fhe_mul_div_round_dev(q, n, V, 1, p, Rr, 2 * batch, st);
-    if (rc != FHE_OK) return rc;
-    hipLaunchKernelGGL(fhe::zr_rq_add_kernel, dim3(fhe_ew_grid(2 * bn)), dim3(256), 0, st, (const u64 *)d_c, (const u64 *)Rr, (u64 *)d_out, 2 * bn, (u64)q);
-    LAUNCH_OK("zr_rq_add_kernel");
-    return FHE_OK;
+    // (c0, c1) + mul_div_round(crt(..), 1, p): recombination, scaling, fold and the final add in one kernel
+    (void)V; (void)Rr; (void)bn;
+    return z_crt_mdr(z, R, R + 2 * words, R + 4 * words, (const u64 *)d_c, (u64 *)d_out, 2 * batch, n, q, 1, p, st);
 }
 
 extern "C" int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, const void *d_ab,
                                void *d_out, size_t batch, void *hip_stream) {
     if (batch == 0) return FHE_OK;
-    // the tensor result lives in its own allocation: both stages use the shared workspace
+    // the tensor result lives in workspace slot 0 (both stages use slot 1); a stream-ordered
+    // allocation per call cost up to 2 ms at 2048 ciphertexts whenever the pool had trimmed itself
     void *c = nullptr;
-    HIP_TRY(hipMallocAsync(&c, 3 * batch * n * 8, (hipStream_t)hip_stream));
-    int rc = fhe_bfv_tensor_dev(q, n, t, d_ab, c, batch, hip_stream);
+    int rc = fhe_workspace_get(0, 3 * batch * n * 8, &c);
+    if (rc != FHE_OK) return rc;
+    rc = fhe_bfv_tensor_dev(q, n, t, d_ab, c, batch, hip_stream);
     if (rc == FHE_OK) rc = fhe_bfv_relinearize_dev(q, n, pq, d_rlk, c, d_out, batch, hip_stream);
-    (void)hipFreeAsync(c, (hipStream_t)hip_stream);
     return rc;
 }
 

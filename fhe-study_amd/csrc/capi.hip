@@ -501,6 +501,21 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
     const size_t elems = batch * plan->n, bytes = elems * sizeof(u64);
     const u64 tile = fhe_batch_tile_for(plan);
 
+    // single-pass sizes: the whole product in one kernel (both forward transforms, the pointwise
+    // product and the inverse transform stay on chip); FHE_RQ_MUL_FUSED=0 selects the three-kernel path
+    static const bool fused_on = [] {
+        const char *e = getenv("FHE_RQ_MUL_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (fused_on) {
+        hipError_t fe = fhe::launch_rq_mul_fused(dp, (const u64 *)d_a, a_is_evals != 0, (const u64 *)d_b, b_is_evals != 0,
+                                                 (u64 *)d_c, (u64 *)d_c_evals, (u64 *)d_a_evals_out,
+                                                 (u64 *)d_b_evals_out, batch, st);
+        if (fe == hipSuccess) return FHE_OK;
+        if (fe != hipErrorNotSupported) return hip_fail(fe, "launch_rq_mul_fused");
+        (void)hipGetLastError();
+    }
+
     const bool need_wa = !a_is_evals && !d_a_evals_out;
     const bool need_wb = !b_is_evals && !d_b_evals_out;
     u64 *work = (u64 *)d_work;

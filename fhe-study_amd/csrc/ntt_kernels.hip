@@ -22,6 +22,8 @@
 //   A round holds field bits [a, a+4) in registers (k = those 4 bits) and runs
 //   the stages for bits a+3, a+2, ... ; with H = f >> (a+4) the index of stage i
 //   of the round is (T0 << i) + (k >> (4-i)),  T0 = (1<<(s0+ls0)) + (blk<<ls0) + H.
+#include <type_traits>
+
 #include "ntt_kernels.hpp"
 #include "zq_device.hpp"
 
@@ -388,6 +390,121 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
 #pragma unroll
         for (int k = 0; k < 16; k++)
             st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, FINAL ? canon2(v[k], m) : v[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// FUSED PRODUCT for single-pass sizes: c = intt(ntt(a) .* ntt(b)) (ring_nq.rs:586-607) with the
+// polynomial resident in registers / LDS from the first load to the last store — one launch
+// instead of three and 3 (+ evals) instead of 7 passes over memory.  The forward rounds end in the
+// register window (field bits [0,4)) the inverse rounds start from, so nothing is rearranged
+// between the transforms.  Operands flagged as evals skip their forward transform.
+// ---------------------------------------------------------------------------
+template <int LP, bool WIDE, bool TILE_FRESH>
+__device__ __forceinline__ void fwd_rounds_single(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 w,
+                                                  u32 tf, const Mod &m) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
+    round_fwd<C::R0, WIDE>(v, gtw, 1u, m);
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        exchange_contig<LP, C::A0, A, TILE_FRESH>(v, lds, w, tf);
+        round_fwd<4, WIDE>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), m);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
+        round_fwd<4, WIDE>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), m);
+    }
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
+        round_fwd<4, WIDE>(v, TW(C::in_lds(3)), (1u << LS) + (tf >> A), m);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = WIDE ? canon8(v[k], m) : canon4(v[k], m);
+}
+
+template <int LP>
+__device__ __forceinline__ void inv_rounds_single(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 w,
+                                                  u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
+    // the tile was last gathered by a forward exchange: every scatter here is preceded by a barrier
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        round_inv<4, false>(v, TW(C::in_lds(3)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::a_of(2), false>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        round_inv<4, false>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::a_of(1), false>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        round_inv<4, false>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::A0, false>(v, lds, w, tf);
+    }
+    round_inv<C::R0, true>(v, TW(C::in_lds(0)), 1u, m, ninv, s_ninv);
+}
+
+template <int LP, bool WIDE>
+__global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    Tw *ltw_f = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    Tw *ltw_i = ltw_f + C::LTW_N;
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u64 pg = (u64)blockIdx.x;
+    const u32 live = (u32)min((u64)C::W, a.batch - pg * C::W);
+    const bool active = w < live;
+    const u64 ubase = pg * C::W * (u64)C::M;                 // single pass: n = M
+    const u32 off = ((active ? w : 0u) << LP) * 8u;
+    const Mod &m = a.mod;
+    stage_twiddles<C::LTW_N, C::TH>(ltw_f, a.tw, 0u, 0u, tid);       // both published by the barrier(s)
+    stage_twiddles<C::LTW_N, C::TH>(ltw_i, a.tw_inv, 0u, 0u, tid);   // that precede their first LDS use
+    if constexpr (C::NR == 1) __syncthreads();   // LP = 4: no exchange would publish them
+
+    // an operand: coefficients -> forward transform (natural-order load, window A0), or evals ->
+    // the 16 consecutive values of this thread; canonical in the [0,4) register window either way
+    auto operand = [&](const u64 *__restrict__ src, bool is_evals, u64 (&v)[16], auto fresh) {
+        const u64 *__restrict__ p = src + ubase;
+        if (is_evals) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const ulonglong2 x = ld_c<ulonglong2>(p, off + tf * 128u + j * 16u);
+                v[2 * j] = x.x;
+                v[2 * j + 1] = x.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = ld_c<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
+            fwd_rounds_single<LP, WIDE, decltype(fresh)::value>(v, lds, ltw_f, a.tw, w, tf, m);
+        }
+    };
+    auto store_evals = [&](u64 *dst, const u64 (&v)[16]) {
+        if (!dst || !active) return;
+        u64 *__restrict__ p = dst + ubase;
+#pragma unroll
+        for (int j = 0; j < 8; j++) st_c<ulonglong2>(p, off + tf * 128u + j * 16u, ulonglong2{v[2 * j], v[2 * j + 1]});
+    };
+
+    u64 va[16], vb[16];
+    operand(a.in, a.flags & 1u, va, std::true_type{});
+    store_evals(a.out3, va);
+    operand(a.in2, a.flags & 2u, vb, std::false_type{});   // the tile may have been used by the first operand
+    store_evals(a.out4, vb);
+#pragma unroll
+    for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);   // zip_eq(l,r).map(l*r), ring_nq.rs:601-604
+    store_evals(a.out2, va);
+    if constexpr (C::NR == 1) { /* twiddles published above */ } else if (a.flags == 3u) __syncthreads();   // no forward exchange ran
+    inv_rounds_single<LP>(va, lds, ltw_i, a.tw_inv, w, tf, m, a.ninv, a.s_ninv);
+    if (active) {
+        u64 *__restrict__ pout = a.out + ubase;
+#pragma unroll
+        for (int k = 0; k < 16; k++) st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, canon2(va[k], m));
     }
 }
 
@@ -989,6 +1106,42 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+template <int LP, bool WIDE>
+static hipError_t launch_rq_mul_fused_lp(const PassArgs &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    const u64 grid = (a.batch + C::W - 1) / C::W;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = C::LDS_BYTES + (size_t)C::LTW_N * sizeof(Tw);   // a second twiddle tile
+    if (hipError_t e = allow_big_lds((const void *)rq_mul_fused_kernel<LP, WIDE>, lds_bytes)) return e;
+    KernelTimer kt("rq_mul_fused", LP, st);
+    hipLaunchKernelGGL((rq_mul_fused_kernel<LP, WIDE>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
+    return post_launch();
+}
+
+hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_evals, const u64 *b_, bool b_is_evals,
+                               u64 *c, u64 *c_evals, u64 *a_evals, u64 *b_evals, u64 batch, hipStream_t st) {
+    const int L = p.log_n;
+    if (L < 4 || L > kMaxSinglePassLog) return hipErrorNotSupported;
+    if (batch == 0) return hipSuccess;
+    PassArgs a{};
+    a.tw = p.tw_fwd;
+    a.tw_inv = p.tw_inv;
+    a.mod = p.mod;
+    a.ninv = p.ninv;
+    a.s_ninv = p.s_ninv;
+    a.log_n = p.log_n;
+    a.in = a_; a.in2 = b_; a.out = c; a.out2 = c_evals; a.out3 = a_evals; a.out4 = b_evals;
+    a.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
+    a.batch = batch;
+    switch (L) {
+#define X(LP_) case LP_: return p.wide ? launch_rq_mul_fused_lp<LP_, true>(a, st) : launch_rq_mul_fused_lp<LP_, false>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,

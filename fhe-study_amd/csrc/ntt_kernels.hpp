@@ -37,6 +37,10 @@ struct PassArgs {
     uint32_t log_n;
     uint32_t digit_l;    // SRC_DIGITS: output polynomial p is bit (digit_l-1 - p%digit_l) of input row p/digit_l
     uint32_t src_log_n;  // SRC_REDUCE: input rows have 2^src_log_n arbitrary 64-bit words (<= n); the rest is 0
+    // fused product kernel (rq_mul_fused_kernel) only:
+    const Tw *tw_inv;    // inverse table (tw holds the forward one)
+    u64 *out3, *out4;    // evals of the two operands, or nullptr
+    uint32_t flags;      // bit 0 / 1: operand in / in2 already holds NTT-domain values
 };
 
 // what a forward kernel's load does besides loading
@@ -63,6 +67,11 @@ hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *ou
                                      uint32_t src_log_n, u64 batch_tile, hipStream_t st);
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st);
+// c = a * b in Z_q[X]/(X^n+1) for single-pass sizes (16 <= n <= 2^13) in ONE kernel: both forward
+// transforms, the pointwise product and the inverse transform of a polynomial stay in registers /
+// LDS.  evals_* may be nullptr.  Returns hipErrorNotSupported for other sizes.
+hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a, bool a_is_evals, const u64 *b, bool b_is_evals,
+                               u64 *c, u64 *c_evals, u64 *a_evals, u64 *b_evals, u64 batch, hipStream_t st);
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
                                 hipStream_t st);
 hipError_t launch_fill_synthetic(u64 *out, u64 count, u64 q, u64 seed, u64 first, hipStream_t st);

@@ -457,3 +457,31 @@ def test_device_entry_points_can_be_captured_in_a_hip_graph(pkg, oracle):
     torch.cuda.synchronize()
     c2 = oracle.rq_mul(q, n, a2, b)[0]
     assert np.array_equal(dc.cpu().numpy().view(np.uint64), c2.reshape(-1))
+
+
+@pytest.mark.gpu
+def test_three_kernel_product_path_for_single_pass_sizes(pkg, oracle):
+    """For 16 <= n <= 2^13 the product runs as ONE kernel (rq_mul_fused_kernel); FHE_RQ_MUL_FUSED=0
+    selects forward + forward + fused-pointwise inverse as for the larger sizes.  Both must give the
+    reference's words, with every combination of cached evals and every optional output."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import fhe_study_amd as pkg\n"
+        "from oracle import load_oracle\n"
+        "O = load_oracle()\n"
+        "for q, n, batch in ((65537, 16, 300), (65537, 512, 7), (pkg.Q61, 1024, 5), (pkg.Q61, 8192, 3)):\n"
+        "    a = O.fill_synthetic(q, 5, 0, batch * n); b = O.fill_synthetic(q, 6, 0, batch * n)\n"
+        "    c, ce, ae, be = O.rq_mul(q, n, a, b)\n"
+        "    P = pkg.Plan(q, n)\n"
+        "    for got in (P.rq_mul(a, b), P.rq_mul(ae, b, a_is_evals=True), P.rq_mul(ae, be, a_is_evals=True, b_is_evals=True)):\n"
+        "        assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, (c, ce, ae, be))), (q, n)\n"
+        "    assert np.array_equal(P.rq_mul(a, b, want_evals=False)[0].reshape(-1), c.reshape(-1))\n"
+        "print('product parity ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for fused in ("0", "1"):
+        env = dict(os.environ, FHE_RQ_MUL_FUSED=fused)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "product parity ok" in r.stdout, fused + r.stdout + r.stderr

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""tools/mulbench.py — throughput of the device-resident Rq product (fhe_rq_mul_dev) per size;
+FHE_RQ_MUL_FUSED=0 selects the three-kernel path for single-pass sizes (diagnostic)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import fhe_study_amd as pkg
+
+B = pkg.binding
+st = torch.cuda.current_stream().cuda_stream
+for log_n, batch in [(4, 1 << 20), (8, 1 << 18), (10, 1 << 17), (12, 1 << 15), (13, 1 << 14), (16, 4096)] + [(10, 1), (12, 1), (13, 1)]:
+    q, n = pkg.Q61, 1 << log_n
+    plan = pkg.Plan(q, n)
+    a = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
+    b = torch.empty_like(a); c = torch.empty_like(a); ce = torch.empty_like(a)
+    B.fill_synthetic_dev(q, 1, 0, batch * n, a.data_ptr(), st)
+    B.fill_synthetic_dev(q, 2, 0, batch * n, b.data_ptr(), st)
+    work = torch.empty(max(16, plan.workspace_bytes(batch) // 8), dtype=torch.int64, device="cuda:0")
+    f = lambda: plan.rq_mul_dev(a.data_ptr(), b.data_ptr(), c.data_ptr(), batch, d_c_evals=ce.data_ptr(), d_work=work.data_ptr(), stream=st)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    reps = 20 if batch > 1 else 200
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"rq_mul n=2^{log_n} batch={batch}: {dt*1e6:10.1f} us  {batch/dt/1e6:8.3f} M products/s", flush=True)

@@ -35,19 +35,34 @@ namespace fhe {
 // one round: R stages on the 16 register-resident coefficients
 // ---------------------------------------------------------------------------
 // Lazy ranges of the forward rounds:
-//   WIDE (q < 2^61, 8q < 2^64): a stage without correction takes x < 6q to x,y < 8q, a
-//   stage that first subtracts 4q from x >= 4q takes x < 8q to x,y < 6q; corrections sit
-//   on stages R-1, R-3, .. of a round, so every round ends below 6q: one conditional
-//   subtraction per TWO butterflies.
+//   WIDE (q < 2^61, 8q < 2^64): values are tracked as multiples of q at compile time.  A stage
+//   takes x < B*q to x' = u + t, y' = u - t + 2q < (B+2)*q, so it needs B <= 6; when B > 6 the
+//   stage first subtracts 4q from x >= 4q (B <= 8 -> 4).  BIN is the bound of the round's inputs
+//   (2 for the first round of a transform — canonical inputs, with slack —, 6 after a round),
+//   fwd_bound_out the bound of its outputs: one conditional subtraction per TWO butterflies in
+//   steady state, one per FOUR in a first round.  TIGHT_LAST: the round's last stage brings x
+//   below 2q first, so the outputs are below 4q (cheaper to canonicalise than < 6q or < 8q).
+//   END6: the round's last stage also corrects when its inputs exceed 4q, so the round (the last
+//   of a strided pass) ends below 6q whatever its length — the bound the next pass starts from.
 //   otherwise (q < 2^62): Harvey's [0,4q) with a 2q correction in every butterfly.
-template <int R, bool WIDE>
+constexpr int fwd_stage_needs_csub(int bound_in) { return bound_in > 6; }
+constexpr int fwd_bound_out(int R, int bin) {
+    int b = bin;
+    for (int i = 0; i < R; i++) b = (fwd_stage_needs_csub(b) ? 4 : b) + 2;
+    return b;
+}
+constexpr int kPassBound = 6;   // bound (in q) of what a forward strided pass hands to the contiguous pass
+template <int R, bool WIDE, int BIN = 6, bool TIGHT_LAST = false, bool END6 = false>
 __device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
                                           const Mod &m) {
+    static_assert(BIN >= 1 && BIN <= 8, "input bound out of range");
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int span = 8 >> i;
         constexpr int kNone = 0;
-        const bool corr = ((R - 1 - i) & 1) == 0;
+        const int bin_i = fwd_bound_out(i, BIN);                 // bound of this stage's inputs
+        const bool corr = fwd_stage_needs_csub(bin_i) || (END6 && i == R - 1 && bin_i > 4);
+        const bool tight = TIGHT_LAST && i == R - 1;             // bring x below 2q: x' and y' < 4q
 #ifdef FHE_ABLATE_NO_BUTTERFLIES   // timing-only build: memory pattern without the arithmetic
         if (i >= 0) continue;
 #endif
@@ -58,6 +73,9 @@ __device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ t
             for (int l = 0; l < span; l++) {
                 const int k = g * 2 * span + l;
                 if (!WIDE) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
+                else if (tight && bin_i > 4) ct_bfly<6>(v[k], v[k + span], t.w, t.wp, m);
+                else if (tight && bin_i > 2) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
+                else if (tight) ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
                 else if (corr) ct_bfly<4>(v[k], v[k + span], t.w, t.wp, m);
                 else ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
             }
@@ -270,24 +288,27 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     // needed from round 1 on, so the barrier of the first exchange also publishes it.
     stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, s0, blk, tid);
 
-    round_fwd<C::R0, WIDE>(v, a.tw, (1u << s0) + blk, m);
+    // bounds (in q) entering each round; inputs are canonical or come from a strided pass (< 6q).
+    // The transform's very last stage (FINAL) brings x below 2q: outputs < 4q.
+    constexpr int B0 = kPassBound, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1), B3 = fwd_bound_out(4, B2);
+    round_fwd<C::R0, WIDE, B0, FINAL && C::NR == 1>(v, a.tw, (1u << s0) + blk, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         constexpr bool L = C::in_lds(1);
         exchange_contig<LP, C::A0, A, true>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, TW(L), T0(L, LS, tf >> A), m);
+        round_fwd<4, WIDE, B1, FINAL && C::NR == 2>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         constexpr bool L = C::in_lds(2);
         exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, TW(L), T0(L, LS, tf >> A), m);
+        round_fwd<4, WIDE, B2, FINAL && C::NR == 3>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
         constexpr bool L = C::in_lds(3);
         exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, TW(L), T0(L, LS, tf >> A), m);
+        round_fwd<4, WIDE, B3, FINAL && C::NR == 4>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     // transpose through LDS so the store is one contiguous slab per wave.  (Storing the 128
     // contiguous bytes a thread owns after the last round as 8 x 16 B straight from registers
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u64 x = FINAL ? (WIDE ? canon8(v[k], m) : canon4(v[k], m)) : v[k];
+        const u64 x = FINAL ? canon4(v[k], m) : v[k];   // FINAL: < 4q in both modes
         lds[pad16(w * C::M + field_of<ALAST>(tf, k))] = x;
     }
     __syncthreads();
@@ -405,24 +426,25 @@ __device__ __forceinline__ void fwd_rounds_single(u64 (&v)[16], u64 *lds, const 
                                                   u32 tf, const Mod &m) {
     using C = ContigCfg<LP>;
     auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
-    round_fwd<C::R0, WIDE>(v, gtw, 1u, m);
+    constexpr int B0 = 2, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1), B3 = fwd_bound_out(4, B2);   // canonical inputs
+    round_fwd<C::R0, WIDE, B0, C::NR == 1>(v, gtw, 1u, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         exchange_contig<LP, C::A0, A, TILE_FRESH>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), m);
+        round_fwd<4, WIDE, B1, C::NR == 2>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), m);
+        round_fwd<4, WIDE, B2, C::NR == 3>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
         exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE>(v, TW(C::in_lds(3)), (1u << LS) + (tf >> A), m);
+        round_fwd<4, WIDE, B3, C::NR == 4>(v, TW(C::in_lds(3)), (1u << LS) + (tf >> A), m);
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = WIDE ? canon8(v[k], m) : canon4(v[k], m);
+    for (int k = 0; k < 16; k++) v[k] = canon4(v[k], m);   // the last stage left x', y' < 4q
 }
 
 template <int LP>
@@ -574,16 +596,19 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     }
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];   // first pass: s0 = 0, blk = 0
 
-    round_fwd<C::R0, WIDE>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
+    // inputs are canonical (bound 2 leaves slack); the pass ends below kPassBound*q (END6)
+    constexpr int B0 = 2, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1);
+    static_assert(kPassBound == 6, "END6 ends a pass below 6q");
+    round_fwd<C::R0, WIDE, B0, false, C::NR == 1>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         exchange_strided<CW, C::A0, A, true>(v, lds, c, tf);   // its barrier also publishes ltw
-        round_fwd<4, WIDE>(v, tw, (1u << LS) + (tf >> A), m);
+        round_fwd<4, WIDE, B1, false, C::NR == 2>(v, tw, (1u << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         exchange_strided<CW, C::a_of(1), A, false>(v, lds, c, tf);
-        round_fwd<4, WIDE>(v, tw, (1u << LS) + (tf >> A), m);
+        round_fwd<4, WIDE, B2, false, C::NR == 3>(v, tw, (1u << LS) + (tf >> A), m);
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll

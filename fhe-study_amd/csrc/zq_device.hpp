@@ -113,13 +113,15 @@ __device__ __forceinline__ u64 mul_shoup_lazy(u64 y, u64 w, u64 wp, const Mod &m
 
 // Forward (Cooley-Tukey) butterfly, arith/src/ntt.rs:57-62:
 //   U = r[j]; V = r[j+t]*S; r[j] = U+V; r[j+t] = U-V
-// CSUB = 0: none (caller guarantees headroom), 2: x -= 2q if x >= 2q, 4: x -= 4q if x >= 4q.
+// CSUB = 0: none (caller guarantees headroom), 2: x -= 2q if x >= 2q, 4: x -= 4q if x >= 4q,
+// 6: both (x < 8q -> x < 2q).
 //   x' = u + t,  y' = u - t + 2q = (2u + 2q + 1) + ~x'
 template <int CSUB>
 __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, u64 wp, const Mod &m) {
     u64 u = x;
     if (CSUB == 2) u = csub_neg(x, m.neg2q);
     if (CSUB == 4) u = csub_neg(x, m.neg4q);
+    if (CSUB == 6) u = csub_neg(csub_neg(x, m.neg4q), m.neg2q);
     const u64 s = mul_shoup_acc(u, y, w, wp, m.nq);
     y = add64(dbl_add64(u, m.q2p1), ~s);
     x = s;

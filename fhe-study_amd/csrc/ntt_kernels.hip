@@ -115,6 +115,99 @@ __device__ __forceinline__ void round_inv(u64 (&v)[16], const Tw *__restrict__ t
     }
 }
 
+// ---- inverse rounds for q < 2^61 (8q < 2^64): per-register value bounds -----------------------
+// A Gentleman-Sande butterfly only needs x + y < 2^64 and x - y + K*q > 0: with bounds (in q) bx, by
+// of its inputs, bx + by <= 8 is enough, the sum leaves with bound bx + by and the product with 2.
+// So instead of one conditional subtraction per butterfly the round follows the bounds of its 16
+// registers at compile time and subtracts 4q only where a pair would exceed 8: 12 instead of 32
+// per round from canonical inputs, 20 instead of 32 in steady state.  A round starts from a uniform
+// bound BIN (after the LDS transpose a register may come from any register of another thread) and
+// ends by bringing every register below BOUT*q.
+struct InvSched {
+    unsigned char cx[4][8];   // stage (in execution order), butterfly: x -= 4q if x >= 4q first
+    unsigned char cy[4][8];   // same for y
+    unsigned char ky[4][8];   // bound of y entering the subtraction: d = x - y + ky*q
+    unsigned char fin[16];    // register: final conditional subtraction of 4q
+};
+constexpr InvSched inv_sched(int R, int bin, bool fold, int bout) {
+    InvSched s{};
+    int B[16] = {};
+    for (int k = 0; k < 16; k++) B[k] = bin;
+    int st = 0;
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+        int j = 0;
+        for (int g = 0; g < (1 << i); g++)
+            for (int l = 0; l < span; l++, j++) {
+                const int k = g * 2 * span + l, k2 = k + span;
+                int bx = B[k], by = B[k2];
+                bool cx = false, cy = false;
+                if (bx + by > 8) {
+                    if (bx >= by) { cx = true; bx = bx > 4 ? 4 : bx; }
+                    else { cy = true; by = by > 4 ? 4 : by; }
+                }
+                if (bx + by > 8) {
+                    if (!cx) { cx = true; bx = bx > 4 ? 4 : bx; }
+                    else { cy = true; by = by > 4 ? 4 : by; }
+                }
+                s.cx[st][j] = cx;
+                s.cy[st][j] = cy;
+                s.ky[st][j] = (unsigned char)by;
+                B[k] = (fold && i == 0) ? 2 : bx + by;
+                B[k2] = 2;
+            }
+    }
+    for (int k = 0; k < 16; k++) s.fin[k] = B[k] > bout;
+    return s;
+}
+
+template <int R, bool FOLD, int BIN, int BOUT>
+__device__ __forceinline__ void round_inv_w(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
+                                            const Tw ninv, const Tw s_ninv) {
+    static_assert(BIN == 2 || BIN == 4, "rounds start from canonical (2) or normalised (4) inputs");
+    static_assert(BOUT == 4, "rounds end below 4q");
+    constexpr InvSched S = inv_sched(R, BIN, FOLD, BOUT);
+    const u64 q4 = 0ull - m.neg4q;
+    const u64 K[5] = {0ull, m.q2p1, q4 + 1ull, q4 + m.q2p1, 2ull * q4 + 1ull};   // (2j)*q + 1
+    int st = 0;
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            Tw t{};
+            if (!(FOLD && i == 0)) t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l, j = g * span + l;
+                u64 x = v[k], y = v[k + span];
+                if (S.cx[st][j]) x = csub_neg(x, m.neg4q);
+                if (S.cy[st][j]) y = csub_neg(y, m.neg4q);
+                const u64 d = add64(add64(x, K[S.ky[st][j] / 2]), ~y);        // x - y + ky*q  in (0, 8q)
+                const u64 s = add64(x, y);                                      // < 8q
+                if (FOLD && i == 0) {
+                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, m);
+                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, m);
+                } else {
+                    v[k] = s;
+                    v[k + span] = mul_shoup_acc(0, d, t.w, t.wp, m.nq);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (S.fin[k]) v[k] = csub_neg(v[k], m.neg4q);
+}
+
+// WIDE: the bound-tracking rounds above (values below 4q between rounds); otherwise [0,2q) throughout
+template <int R, bool FOLD, bool WIDE, int BIN>
+__device__ __forceinline__ void round_inv_sel(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
+                                              const Tw ninv, const Tw s_ninv) {
+    if constexpr (WIDE) round_inv_w<R, FOLD, BIN, 4>(v, tw, T0, m, ninv, s_ninv);
+    else round_inv<R, FOLD>(v, tw, T0, m, ninv, s_ninv);
+}
+
 // field value of register k for a thread whose non-register field bits are tf,
 // register window = field bits [A, A+4)
 template <int A>
@@ -332,7 +425,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
 // MUL_IN: the input is the pointwise product in .* in2 (fused
 // zip_eq(l,r).map(l*r), ring_nq.rs:601-604); if a.out2 != nullptr the product
 // (the `evals` of the result, ring_nq.rs:606) is also written there.
-template <int LP, bool FINAL, bool MUL_IN>
+template <int LP, bool FINAL, bool MUL_IN, bool WIDE>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassArgs a) {
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -386,26 +479,29 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     }
 
     __syncthreads();
+    // inputs are canonical (evals, or their product): the first round that runs starts from bound 2,
+    // later ones from the normalised 4 (WIDE); a non-FINAL pass hands values below 4q (WIDE) / 2q on
+    constexpr int BF = 2, BN = 4;
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
         constexpr bool L = C::in_lds(3);
-        round_inv<4, false>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
+        round_inv_sel<4, false, WIDE, BF>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::a_of(2), true>(v, lds, w, tf);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         constexpr bool L = C::in_lds(2);
-        round_inv<4, false>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
+        round_inv_sel<4, false, WIDE, (C::NR == 3 ? BF : BN)>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::a_of(1), (C::NR <= 3)>(v, lds, w, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         constexpr bool L = C::in_lds(1);
-        round_inv<4, false>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
+        round_inv_sel<4, false, WIDE, (C::NR == 2 ? BF : BN)>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
         exchange_contig<LP, A, C::A0, (C::NR <= 2)>(v, lds, w, tf);
     }
     // FINAL implies s0 == 0 (this pass holds the m = 1 stage)
-    round_inv<C::R0, FINAL>(v, TW(C::in_lds(0)), T0(C::in_lds(0), 0, 0), m, a.ninv, a.s_ninv);
+    round_inv_sel<C::R0, FINAL, WIDE, (C::NR == 1 ? BF : BN)>(v, TW(C::in_lds(0)), T0(C::in_lds(0), 0, 0), m, a.ninv, a.s_ninv);
 
     if (active) {
 #pragma unroll
@@ -447,28 +543,29 @@ __device__ __forceinline__ void fwd_rounds_single(u64 (&v)[16], u64 *lds, const 
     for (int k = 0; k < 16; k++) v[k] = canon4(v[k], m);   // the last stage left x', y' < 4q
 }
 
-template <int LP>
+template <int LP, bool WIDE>
 __device__ __forceinline__ void inv_rounds_single(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 w,
                                                   u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
     using C = ContigCfg<LP>;
     auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
+    constexpr int BF = 2, BN = 4;   // canonical inputs for the first round that runs, 4 after a round
     // the tile was last gathered by a forward exchange: every scatter here is preceded by a barrier
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
-        round_inv<4, false>(v, TW(C::in_lds(3)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        round_inv_sel<4, false, WIDE, BF>(v, TW(C::in_lds(3)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
         exchange_contig<LP, A, C::a_of(2), false>(v, lds, w, tf);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv<4, false>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        round_inv_sel<4, false, WIDE, (C::NR == 3 ? BF : BN)>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
         exchange_contig<LP, A, C::a_of(1), false>(v, lds, w, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv<4, false>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        round_inv_sel<4, false, WIDE, (C::NR == 2 ? BF : BN)>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), m, ninv, s_ninv);
         exchange_contig<LP, A, C::A0, false>(v, lds, w, tf);
     }
-    round_inv<C::R0, true>(v, TW(C::in_lds(0)), 1u, m, ninv, s_ninv);
+    round_inv_sel<C::R0, true, WIDE, (C::NR == 1 ? BF : BN)>(v, TW(C::in_lds(0)), 1u, m, ninv, s_ninv);
 }
 
 template <int LP, bool WIDE>
@@ -522,7 +619,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
     for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);   // zip_eq(l,r).map(l*r), ring_nq.rs:601-604
     store_evals(a.out2, va);
     if constexpr (C::NR == 1) { /* twiddles published above */ } else if (a.flags == 3u) __syncthreads();   // no forward exchange ran
-    inv_rounds_single<LP>(va, lds, ltw_i, a.tw_inv, w, tf, m, a.ninv, a.s_ninv);
+    inv_rounds_single<LP, WIDE>(va, lds, ltw_i, a.tw_inv, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
 #pragma unroll
@@ -615,7 +712,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     for (int k = 0; k < 16; k++) st_at(pout, ((field_of<ALAST>(tf, k) << lb) + c) * 8u, v[k]);  // lazy: < 4q, or < 6q (WIDE)
 }
 
-template <int LA, int CW>
+template <int LA, int CW, bool WIDE>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kernel(PassArgs a) {
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -639,17 +736,18 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
     __syncthreads();
 
+    // the contiguous pass before this one hands values below 4q (WIDE) / 2q: every round starts from 4
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::a_of(1), true>(v, lds, c, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv<4, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::A0, (C::NR <= 2)>(v, lds, c, tf);
     }
-    round_inv<C::R0, true>(v, tw, 1u, m, a.ninv, a.s_ninv);
+    round_inv_sel<C::R0, true, WIDE, 4>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
     for (int k = 0; k < 16; k++) st_at(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, canon2(v[k], m));
 }
@@ -969,7 +1067,7 @@ static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     return post_launch();
 }
 
-template <int LP, bool FINAL, bool MUL_IN>
+template <int LP, bool FINAL, bool MUL_IN, bool WIDE>
 static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 nb = 1ull << (a.log_n - LP);
@@ -977,9 +1075,9 @@ static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
     const u64 grid = nb * groups;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)ntt_inv_contig_kernel<LP, FINAL, MUL_IN>, C::LDS_BYTES)) return e;
+    if (hipError_t e = allow_big_lds((const void *)ntt_inv_contig_kernel<LP, FINAL, MUL_IN, WIDE>, C::LDS_BYTES)) return e;
     KernelTimer kt(MUL_IN ? "ntt_inv_contig_mul" : (FINAL ? "ntt_inv_contig_final" : "ntt_inv_contig"), LP, st);
-    hipLaunchKernelGGL((ntt_inv_contig_kernel<LP, FINAL, MUL_IN>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((ntt_inv_contig_kernel<LP, FINAL, MUL_IN, WIDE>), dim3((unsigned)grid),
                        dim3(C::TH), C::LDS_BYTES, st, a);
     return post_launch();
 }
@@ -993,7 +1091,7 @@ static hipError_t launch_strided(const PassArgs &a, hipStream_t st) {
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     KernelTimer kt(INV ? "ntt_inv_strided" : (RSRC ? "ntt_fwd_strided_reduce" : "ntt_fwd_strided"), LA, st);
     if (INV)
-        hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW>), dim3((unsigned)grid), dim3(C::TH),
+        hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW, WIDE>), dim3((unsigned)grid), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     else
         hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, WIDE, RSRC>), dim3((unsigned)grid), dim3(C::TH),
@@ -1063,15 +1161,16 @@ static hipError_t fwd_contig_dispatch(int lp, bool final, bool wide, const PassA
     return hipErrorInvalidValue;
 }
 
+template <bool WIDE>
 static hipError_t inv_contig_dispatch(int lp, bool final, bool mul_in, const PassArgs &a,
                                       hipStream_t st) {
     switch (lp) {
-#define X(LP_)                                                                             \
-    case LP_:                                                                              \
-        if (final) return mul_in ? launch_inv_contig<LP_, true, true>(a, st)               \
-                                 : launch_inv_contig<LP_, true, false>(a, st);             \
-        return mul_in ? launch_inv_contig<LP_, false, true>(a, st)                         \
-                      : launch_inv_contig<LP_, false, false>(a, st);
+#define X(LP_)                                                                                   \
+    case LP_:                                                                                    \
+        if (final) return mul_in ? launch_inv_contig<LP_, true, true, WIDE>(a, st)               \
+                                 : launch_inv_contig<LP_, true, false, WIDE>(a, st);             \
+        return mul_in ? launch_inv_contig<LP_, false, true, WIDE>(a, st)                         \
+                      : launch_inv_contig<LP_, false, false, WIDE>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
@@ -1252,7 +1351,8 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
     }
     if (L <= kMaxSinglePassLog) {
         a.in = in; a.in2 = in2; a.out2 = evals_out; a.out = out; a.batch = batch;
-        return inv_contig_dispatch(L, true, in2 != nullptr, a, st);
+        return p.wide ? inv_contig_dispatch<true>(L, true, in2 != nullptr, a, st)
+                      : inv_contig_dispatch<false>(L, true, in2 != nullptr, a, st);
     }
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
@@ -1262,10 +1362,11 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
         a.in = in + b0 * n; a.in2 = in2 ? in2 + b0 * n : nullptr;
         a.out2 = evals_out ? evals_out + b0 * n : nullptr;
         a.out = out + b0 * n; a.batch = nb;
-        hipError_t e = inv_contig_dispatch(LB, false, in2 != nullptr, a, st);
+        hipError_t e = p.wide ? inv_contig_dispatch<true>(LB, false, in2 != nullptr, a, st)
+                              : inv_contig_dispatch<false>(LB, false, in2 != nullptr, a, st);
         if (e != hipSuccess) return e;
         a.in = out + b0 * n; a.in2 = nullptr; a.out2 = nullptr;
-        e = strided_dispatch<true, false>(LA, a, st);
+        e = p.wide ? strided_dispatch<true, true>(LA, a, st) : strided_dispatch<true, false>(LA, a, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

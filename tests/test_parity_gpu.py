@@ -485,3 +485,22 @@ def test_three_kernel_product_path_for_single_pass_sizes(pkg, oracle):
         env = dict(os.environ, FHE_RQ_MUL_FUSED=fused)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "product parity ok" in r.stdout, fused + r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [18, 19, 20])
+def test_largest_sizes(pkg, oracle, log_n):
+    """n = 2^18 .. 2^20 (the engine's limit): 8 strided + 10..12 contiguous stages, the only sizes
+    whose contiguous pass is longer than 8 stages AND not the whole transform"""
+    q, n, batch = Q61, 1 << log_n, 2
+    a = oracle.fill_synthetic(q, 300 + log_n, 0, batch * n)
+    b = oracle.fill_synthetic(q, 400 + log_n, 0, batch * n)
+    a[:4] = [0, q - 1, 1, q - 1]
+    plan = pkg.Plan(q, n)
+    A = plan.forward(a)
+    assert np.array_equal(A, oracle.ntt(q, n, a))
+    assert np.array_equal(plan.inverse(A), a)
+    assert np.array_equal(plan.inverse(b), oracle.intt(q, n, b))
+    c, ce, ae, be = plan.rq_mul(a, b)
+    oc, oce, oae, obe = oracle.rq_mul(q, n, a, b)
+    assert np.array_equal(c.reshape(-1), oc.reshape(-1)) and np.array_equal(ce.reshape(-1), oce.reshape(-1))

@@ -366,3 +366,34 @@ def test_gpu_host_mirrors_read_like_the_reference(pkg, oracle):
     assert np.array_equal(res.a, want[:k]) and np.array_equal(res.b, want[k])
     x, y = tfhe.Tn(rng.integers(0, U64, n, dtype=np.uint64)), tfhe.Tn(rng.integers(0, U64, n, dtype=np.uint64))
     assert np.array_equal((x * y).coeffs, oracle.tn_mul(n, x.coeffs, y.coeffs)[0])
+
+
+@pytest.mark.gpu
+def test_gpu_reducing_loads_at_every_transform_size(pkg, oracle):
+    """the operand reduction/padding fused into the forward load (SRC_REDUCE / RSRC kernels) exists
+    per transform size: Tn x Tn (no padding) runs it at n, naive_mul (zero-padding) at 2n — cover every
+    single-pass size 16..8192 and the three strided shapes (2^14, 2^15, >= 2^16)"""
+    B = pkg.binding
+    rng = np.random.default_rng(31)
+    for n in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+        batch = 2 if n <= 8192 else 1
+        a = rng.integers(0, U64, (batch, n), dtype=np.uint64)
+        b = rng.integers(0, U64, (batch, n), dtype=np.uint64)
+        assert np.array_equal(B.tn_mul(n, a, b), oracle.tn_mul(n, a, b)), n
+    for n in (8, 16, 128, 4096, 8192, 16384, 32768):            # transforms of 2n = 16 .. 65536
+        a = rng.integers(0, Q61, (1, n), dtype=np.int64)
+        b = rng.integers(0, Q61, (1, n), dtype=np.int64)
+        assert np.array_equal(B.r_naive_mul(n, a, b), oracle.r_naive_mul(n, a, b)), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [32, 128, 256, 512, 2048, 4096, 8192])
+def test_gpu_external_product_digit_load_at_every_single_pass_size(pkg, oracle, n):
+    """the bit-extracting forward load (SRC_DIGITS) is instantiated per size: the sizes the shapes
+    of test_gpu_external_product do not touch, with l < 64 and a ragged polynomial count"""
+    k, l, batch = 1, 3, 3
+    rng = np.random.default_rng(n)
+    tggsw = rng.integers(0, U64, (k + 1, l, k + 1, n), dtype=np.uint64)
+    tglwe = rng.integers(0, U64, (batch, k + 1, n), dtype=np.uint64)
+    got = pkg.binding.tggsw_external_product(n, k, l, tggsw, tglwe).reshape(batch, k + 1, n)
+    assert np.array_equal(got, oracle.external_product(n, k, l, tggsw, tglwe))

@@ -103,6 +103,32 @@ __global__ __launch_bounds__(256) void zr_mul_bcast_kernel(const u64 *__restrict
     }
 }
 
+// External product, one-prime form: the key words are split into 32-bit halves laid out as
+// [t][half][c][n] (t = TGLev and level, c = component), so that one multiply-accumulate over the
+// digit transforms yields both half-sums; each is below (k+1)*l*n*2^32 in magnitude and is lifted
+// exactly from its residue mod P1, then  S = S_lo + (S_hi << 32)  mod 2^64.
+__global__ __launch_bounds__(256) void zr_split32_kernel(const u64 *__restrict__ g, u64 *__restrict__ out, u64 T,
+                                                         u32 k1, u32 n) {
+    const u64 per = (u64)k1 * n, total = T * per, stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 t = i / per, r = i - t * per;
+        const u64 v = g[i];
+        out[(t * 2) * per + r] = v & 0xffffffffull;
+        out[(t * 2 + 1) * per + r] = v >> 32;
+    }
+}
+__global__ __launch_bounds__(256) void zr_combine32_kernel(const u64 *__restrict__ r, u64 *__restrict__ out, u64 batch,
+                                                           u32 k1, u32 n, u64 p1, u64 half1) {
+    const u64 per = (u64)k1 * n, total = batch * per, stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 b = i / per, cj = i - b * per;
+        u64 lo = r[b * 2 * per + cj], hi = r[b * 2 * per + per + cj];
+        if (lo >= half1) lo -= p1;          // centred lift, two's complement
+        if (hi >= half1) hi -= p1;
+        out[i] = lo + (hi << 32);
+    }
+}
+
 // Garner: residues r1 (mod P1), r2 (mod P2), r3 (mod P3) of an integer V with |V| < P/2
 // (SIGNED) or 0 <= V < P  ->  V mod 2^64.
 template <int K, bool SIGNED>
@@ -497,12 +523,35 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
     if (!d_tggsw || !d_tglwe || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tggsw_external_product_dev: NULL buffer");
     REQUIRE_ALIGNED(d_tggsw); REQUIRE_ALIGNED(d_tglwe); REQUIRE_ALIGNED(d_out);
     const u32 k1 = k + 1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u64 grows = (u64)k1 * l * k1, drows = batch * k1 * l, orows = batch * k1;
+    // One-prime form (see zr_split32_kernel): the digit transforms — the dominant cost — are needed
+    // for ONE prime instead of two.  Valid while each half-sum stays below P1/2: (k+1)*l*n <= 2^26.
+    // Needs the bit-extracting transform (single-pass sizes); larger n takes the two-prime form.
+    if ((u64)k1 * l * n <= (1ull << 26) && n >= 16 && n <= (1ull << fhe::kMaxSinglePassLog)) {
+        ZCtx z1;
+        if ((rc = zctx_init(&z1, n, 1)) != FHE_OK) return rc;
+        void *wsv = nullptr;
+        if ((rc = fhe_workspace_get(1, (2 * grows + drows + 2 * orows) * n * 8, &wsv)) != FHE_OK) return rc;
+        u64 *G2 = (u64 *)wsv, *D = G2 + 2 * grows * n, *R = D + drows * n;
+        const u64 T = (u64)k1 * l;
+        hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G2, T, k1, (u32)n);
+        LAUNCH_OK("zr_split32_kernel");
+        if ((rc = z_forward(z1, 0, G2, G2, 2 * grows, st)) != FHE_OK) return rc;          // halves are < 2^32 < P1
+        hipError_t e = fhe::launch_ntt_forward_digits(z1.dp[0], (const u64 *)d_tglwe, D, orows, (u32)l, st);
+        if (e != hipSuccess) return fhe_hip_fail(e, "digit forward NTT");
+        // R[b][half][c] = sum_t G2[t][half][c] * D[b][t]: 2*k1 output rows per ciphertext
+        hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, 2 * k1, n))), dim3(256), 0, st, (const u64 *)G2, (const u64 *)D, R, (u64)batch, (u32)n, (u32)T, 2 * k1, (u64)0, z1.cc.m[0]);
+        LAUNCH_OK("mac_rows_kernel");
+        if ((rc = z_inverse(z1, 0, R, R, 2 * orows, st)) != FHE_OK) return rc;
+        hipLaunchKernelGGL(fhe::zr_combine32_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)R, (u64 *)d_out, (u64)batch, k1, (u32)n, z1.cc.p1, z1.cc.half1);
+        LAUNCH_OK("zr_combine32_kernel");
+        return FHE_OK;
+    }
     ZCtx z;
     // digits are 0/1: |sum| < (k+1) * l * n * 2^64
     rc = zctx_init(&z, n, primes_for_bits(64 + ceil_log2(n) + ceil_log2((u64)k1 * l), true));
     if (rc != FHE_OK) return rc;
-    hipStream_t st = (hipStream_t)hip_stream;
-    const u64 grows = (u64)k1 * l * k1, drows = batch * k1 * l, orows = batch * k1;
     void *wsv = nullptr;
     rc = fhe_workspace_get(1, (grows + 2 * drows + (size_t)z.K * orows) * n * 8, &wsv);
     if (rc != FHE_OK) return rc;

@@ -366,11 +366,22 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     // [decomposition: batch*k*l rows] [rhs: batch*k1 rows] [keyed_mac scratch: T*k1 + batch*T rows]
     if ((rc = fhe_workspace_get(1, (batch * T + batch * k1 + (u64)T * k1 + batch * T) * n * 8, &w)) != FHE_OK) return rc;
     u64 *DEC = (u64 *)w, *RHS = DEC + batch * T * n, *WS = RHS + batch * k1 * n;
-    // decompose the k mask polynomials of every ciphertext (the body row is skipped): rows (b, i) -> [b][i][d]
-    hipLaunchKernelGGL(fhe::decompose_kernel, dim3(fhe_ew_grid(batch * k * n)), dim3(256), 0, st, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)n, (u64)plan->q, (u32)beta, (u32)l, (u32)k, (u64)k1 * n);
-    LAUNCH_OK("decompose_kernel");
+    // decompose the k mask polynomials of every ciphertext (the body row is skipped): rows (b, i) -> [b][i][d].
+    // Base 2 at single-pass sizes: the digit is extracted in the load of its forward transform
+    // (SRC_ZQBITS), so DEC receives the transforms and the digit polynomials never exist.
+    bool dec_is_evals = false;
+    if (beta == 2) {
+        hipError_t e = fhe::launch_ntt_forward_zqbits(dp, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)l, (u32)k, (u64)k1 * n, st);
+        if (e == hipSuccess) dec_is_evals = true;
+        else if (e != hipErrorNotSupported) return fhe_hip_fail(e, "digit forward NTT");
+        else (void)hipGetLastError();
+    }
+    if (!dec_is_evals) {
+        hipLaunchKernelGGL(fhe::decompose_kernel, dim3(fhe_ew_grid(batch * k * n)), dim3(256), 0, st, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)n, (u64)plan->q, (u32)beta, (u32)l, (u32)k, (u64)k1 * n);
+        LAUNCH_OK("decompose_kernel");
+    }
     // ksk viewed as [T = k*l][k1][n]; DEC as [batch][T][n]
-    if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, flags & FHE_A_IS_EVALS, DEC, false, RHS, false, T, k1, batch, WS, st)) != FHE_OK) return rc;
+    if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, flags & FHE_A_IS_EVALS, DEC, dec_is_evals, RHS, false, T, k1, batch, WS, st)) != FHE_OK) return rc;
     hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(fhe_ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
     LAUNCH_OK("ks_tail_kernel");
     return FHE_OK;

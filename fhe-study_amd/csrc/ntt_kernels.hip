@@ -362,6 +362,23 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
         const u64 *__restrict__ src = a.in + row * n;
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = (src[field_of<C::A0>(tf, k)] >> sh) & 1ull;
+    } else if constexpr (SRC == SRC_ZQBITS) {
+        // Rq::decompose(2, l) in the load (ring_nq.rs:67-78, zq.rs:176-190): digit d of a coefficient is
+        // bit l-1-d, or 1 for every d when the value is >= 2^l (with the reference's `1 << l` taken
+        // modulo 64 as a --release build does)
+        static_assert(FINAL, "digit loads exist for the single-pass kernels only");
+        const u64 p = pg * C::W + (w < live ? w : 0u);
+        const u64 row = p / a.digit_l;
+        const u32 d = (u32)(p - row * a.digit_l);
+        const u64 grp_i = row / a.src_grp;
+        const u64 *__restrict__ src = a.in + grp_i * a.src_gstride + (row - grp_i * a.src_grp) * n;
+        const u64 sat = 1ull << (a.digit_l & 63u);
+        const u32 sh = a.digit_l - 1u - d;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u64 x = src[field_of<C::A0>(tf, k)];
+            v[k] = x >= sat ? 1ull : (x >> sh) & 1ull;        // q >= 3: both are canonical
+        }
     } else if constexpr (SRC == SRC_REDUCE) {
         static_assert(FINAL, "reducing loads exist for the single-pass kernels only");
         const u64 p = pg * C::W + (w < live ? w : 0u);
@@ -1061,7 +1078,7 @@ static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>, C::LDS_BYTES)) return e;
-    KernelTimer kt(SRC == SRC_DIGITS ? "ntt_fwd_digits" : SRC == SRC_REDUCE ? "ntt_fwd_reduce" : (FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig"), LP, st);
+    KernelTimer kt(SRC == SRC_DIGITS ? "ntt_fwd_digits" : SRC == SRC_ZQBITS ? "ntt_fwd_zqbits" : SRC == SRC_REDUCE ? "ntt_fwd_reduce" : (FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig"), LP, st);
     hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>), dim3((unsigned)grid), dim3(C::TH),
                        C::LDS_BYTES, st, a);
     return post_launch();
@@ -1280,6 +1297,24 @@ hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *ou
     a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l;
     switch (L) {
 #define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, SRC_DIGITS>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_ntt_forward_zqbits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
+                                     uint32_t grp, u64 gstride, hipStream_t st) {
+    const int L = p.log_n;
+    if (L < 4 || L > kMaxSinglePassLog || !p.wide || l == 0 || l > 64 || grp == 0 || p.mod.q < 3) return hipErrorNotSupported;
+    if (rows == 0) return hipSuccess;
+    PassArgs a{};
+    a.tw = p.tw_fwd;
+    a.mod = p.mod;
+    a.log_n = p.log_n;
+    a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l; a.src_grp = grp; a.src_gstride = gstride;
+    switch (L) {
+#define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, SRC_ZQBITS>(a, st);
         CONTIG_CASES(X)
 #undef X
     }

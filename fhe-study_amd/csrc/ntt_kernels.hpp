@@ -37,6 +37,10 @@ struct PassArgs {
     uint32_t log_n;
     uint32_t digit_l;    // SRC_DIGITS: output polynomial p is bit (digit_l-1 - p%digit_l) of input row p/digit_l
     uint32_t src_log_n;  // SRC_REDUCE: input rows have 2^src_log_n arbitrary 64-bit words (<= n); the rest is 0
+    // SRC_ZQBITS (Zq::decompose, base 2): input row r = (group r / src_grp, member r % src_grp) lives at
+    // in + group*src_gstride + member*n, so the k mask rows of each (k+1)-row ciphertext are picked in place
+    uint32_t src_grp;
+    u64 src_gstride;
     // fused product kernel (rq_mul_fused_kernel) only:
     const Tw *tw_inv;    // inverse table (tw holds the forward one)
     u64 *out3, *out4;    // evals of the two operands, or nullptr
@@ -44,7 +48,7 @@ struct PassArgs {
 };
 
 // what a forward kernel's load does besides loading
-enum : int { SRC_PLAIN = 0, SRC_DIGITS = 1, SRC_REDUCE = 2 };
+enum : int { SRC_PLAIN = 0, SRC_DIGITS = 1, SRC_REDUCE = 2, SRC_ZQBITS = 3 };
 
 // Brackets one launch with HIP events when fhe_ntt_kernel_timing_enable(1).
 struct KernelTimer {
@@ -60,6 +64,11 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
 // load).  Single-pass sizes and q < 2^61 only: returns hipErrorNotSupported otherwise.
 hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
                                      hipStream_t st);
+// out[r*l + d] = NTT(digit d of Zq::decompose(beta = 2, l) of every coefficient of input row r), rows
+// gathered as PassArgs::src_grp / src_gstride describe (arith/src/zq.rs:176-190: bit l-1-d, or all ones
+// when the value is >= 2^l).  Single-pass sizes and q < 2^61 only: hipErrorNotSupported otherwise.
+hipError_t launch_ntt_forward_zqbits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
+                                     uint32_t grp, u64 gstride, hipStream_t st);
 // out[r] = NTT(in[r] reduced mod q and zero-padded from 2^src_log_n to n words): the operand
 // preparation of the exact products over Z (zring.hip) fused into the load.  q < 2^61 and
 // n >= 16 only: returns hipErrorNotSupported otherwise.

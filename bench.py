@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — NTT/s of the batched negacyclic forward NTT (N=2^16, q = 2^61-2^21+1)
-on MI355X, with the kernel roofline and the CPU baseline in the same JSON line.
+"""bench.py — throughput of the hot path on MI355X with the roofline and the CPU baseline in the
+same JSON line.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`
   (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).
 
-A "step" is one pass of the hot path over one batch: `batch_per_gpu` independent
-polynomials through fhe_ntt_forward_dev (device-resident in → out, HBM to HBM).
-The batch is block-partitioned over ranks; there is no data-path collective
-(SURVEY.md §8e), so per-GPU work is fixed as N grows: "scaling": "weak".
-PyTorch is used for device memory, streams and torch.distributed only.
+Default workload = BASELINE.json configs[4] on one GPU (`--config 5`): forward negacyclic NTT,
+N = 65536, q = 2^61-2^21+1, 65536 polynomials per GPU (32 GiB in + 32 GiB out of the 288 GB HBM),
+synthetic coefficients generated on the device, device-resident in -> out.
+A "step" is one pass of the hot path over one batch.  The batch is block-partitioned over ranks;
+there is no data-path collective, so per-GPU work is fixed as N grows: "weak".
 
-Workload = BASELINE.json configs[4] on one GPU: N=65536, batch=65536 polynomials
-(32 GiB in + 32 GiB out of the 288 GB HBM), synthetic coefficients generated on
-the device, outputs spot-checked against the CPU oracle.
+`--config {2,3,4}` measure the other BASELINE.json configurations with the same JSON shape
+(their own metric names; the contract line is the default):
+  2  forward + inverse NTT, N = 4096, batch 4096                     -> NTT/s
+  3  BFV ciphertext x ciphertext multiply + relinearise, N = 8192     -> ct-mul/s
+  4  TGGSW x TGLWE external product, N = 1024, k = 1, l = 64, 630 products (per GPU: the
+     fhe_shard_range share of 630 when N > 1)                         -> products/s
+
+`roofline` describes the WHOLE step against the HBM roofline (algorithmic bytes of SURVEY.md §8d
+per unit / measured time per unit); `roofline.kernels` holds every kernel's own average launch
+time (HIP events on the launch stream) and, for the dominant one, its own algorithmic rate;
+`roofline.valu` prices the same step against the measured integer ceiling of the chip
+(butterflies per second of tools/ubench_bfly.hip), which is what binds every configuration here.
+PyTorch is used for device memory, streams and torch.distributed only.
 """
 import argparse
 import json
@@ -27,11 +37,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 Q61 = 2305843009211596801
+Q16 = 65537
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Chip-wide ceiling of the 64-bit Shoup/Harvey butterfly in registers, no memory at all:
+# tools/ubench_bfly.hip v8 (the production form) at 8 waves per SIMD, profiles/r01_ubench_bfly.txt.
+VALU_PEAK_GBFLY = 2018.7
 # HBM traffic per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
 # WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Counters cannot be read from inside this process.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def parse():
@@ -39,13 +53,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-n", type=int, default=16)
-    ap.add_argument("--batch-per-gpu", type=int, default=65536)
-    ap.add_argument("--q", type=int, default=Q61)
+    ap.add_argument("--config", type=int, default=5, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configuration (1-based; 5 = the headline, the contract line)")
+    ap.add_argument("--log-n", type=int, default=None)
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="config 4 only: shard exactly this many products over the ranks (strong scaling; 630 = configs[3])")
+    ap.add_argument("--q", type=int, default=None)
     ap.add_argument("--batch-tile", type=int, default=0, help="polynomials per launch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-all-ranks", action="store_true",
+                    help="every rank checks its own shard against the oracle (default: rank 0 only)")
+    ap.add_argument("--gather-check", action="store_true",
+                    help="config 5, N > 1: all-gather the shards (sharding.ShardedNTT driven by Plan.forward_dev) "
+                         "and compare with the single-rank transform of the whole batch on rank 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -55,32 +78,217 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(q, n, seconds):
-    """The oracle's reference-cost-model port (16-byte {q,v} AoS, u128 %, per-call table
-    clone under a mutex — arith/src/ntt.rs:20-73) timed on this host's cores, on a bounded
-    sample of the same synthetic workload."""
-    from oracle import load_oracle
-
-    O = load_oracle()
-    O.roots(q, n)  # table build is a one-off in the reference too (CACHE), keep it out of the timing
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 16)   # the GPU box's CPU share for one GPU
-    probe = O.fill_synthetic(q, 0xF4E50005, 0, 4 * n)
+    return min(cores, 16)   # the GPU box's CPU share for one GPU
+
+
+def threaded_rate(fn, units_per_call, seconds, cores):
+    """fn() processes `units_per_call` units on one thread (ctypes releases the GIL): run it on
+    `cores` threads for about `seconds`; returns (units/s, units, wall seconds)."""
+    import threading
+
     t0 = time.perf_counter()
-    O.ref_ntt_aos(q, n, probe, threads=1)
-    per_ntt = (time.perf_counter() - t0) / 4
-    one_core = 1.0 / per_ntt
-    count = max(cores, int(seconds / per_ntt) // cores * cores)
-    count = min(count, 8192)
-    x = O.fill_synthetic(q, 0xF4E50005, 0, count * n)
+    fn()
+    per_call = time.perf_counter() - t0
+    calls = max(1, int(seconds / per_call))
+    done = [0] * cores
+
+    def work(i):
+        for _ in range(calls):
+            fn()
+            done[i] += units_per_call
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
-    O.ref_ntt_aos(q, n, x, threads=cores)
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
     dt = time.perf_counter() - t0
+    return sum(done) / dt, sum(done), dt, units_per_call / per_call
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads: each returns a dict of closures / constants over device-resident buffers
+# ------------------------------------------------------------------------------------------------
+def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
+    B = pkg.binding
+    if inverse_too:   # config 2
+        q, log_n, batch = args.q or Q61, args.log_n or 12, args.batch_per_gpu or 4096
+        seed = 0xF4E50002
+    else:             # config 5
+        q, log_n, batch = args.q or Q61, args.log_n or 16, args.batch_per_gpu or 65536
+        seed = 0xF4E50005
+    n = 1 << log_n
+    plan = pkg.Plan(q, n)
+    B._check(pkg.load_library().fhe_ntt_plan_prepare(plan.handle))
+    x = torch.empty(batch * n, dtype=torch.int64, device=dev)
+    y = torch.empty(batch * n, dtype=torch.int64, device=dev)
+    z = torch.empty(batch * n, dtype=torch.int64, device=dev) if inverse_too else None
+    first = rank * batch * n      # rank r owns rows [r*batch, (r+1)*batch) of the global batch
+    B.fill_synthetic_dev(q, seed, first, batch * n, x.data_ptr(), st)
+
+    def step():
+        plan.forward_dev(x.data_ptr(), y.data_ptr(), batch, st)
+        if inverse_too:
+            plan.inverse_dev(y.data_ptr(), z.data_ptr(), batch, st)
+
+    def parity(O, np):
+        rng = np.random.default_rng(7)
+        rows = sorted(set(list(range(min(8, batch))) + list(range(max(0, batch - 8), batch)) +
+                          [int(r) for r in rng.integers(0, batch, 48)]))
+        Y = y.view(batch, n)
+        bad = 0
+        for r in rows:
+            a = O.fill_synthetic(q, seed, first + r * n, n)
+            if not np.array_equal(Y[r].cpu().numpy().view(np.uint64), O.ntt(q, n, a)):
+                bad += 1
+        if inverse_too and not torch.equal(z, x):
+            bad += 1
+        return len(rows), bad
+
+    def cpu(O, np, seconds):
+        """The oracle's reference-cost-model port (16-byte {q,v} AoS, u128 %, per-call table clone under
+        a mutex — arith/src/ntt.rs:20-73) on this host's cores, on a bounded sample of the same rows."""
+        O.roots(q, n)  # table build is a one-off in the reference too (CACHE): keep it out of the timing
+        cores = host_cores()
+        probe = O.fill_synthetic(q, seed, 0, 4 * n)
+        t0 = time.perf_counter()
+        O.ref_ntt_aos(q, n, probe, threads=1)
+        per_ntt = (time.perf_counter() - t0) / 4
+        count = max(cores, int(seconds / per_ntt) // cores * cores)
+        count = min(count, 8192 if n >= 16384 else 1 << 18)
+        xs = O.fill_synthetic(q, seed, 0, count * n)
+        t0 = time.perf_counter()
+        O.ref_ntt_aos(q, n, xs, threads=cores)
+        dt = time.perf_counter() - t0
+        return {"value": count / dt, "unit": "NTT/s", "cores": cores, "kind": "port",
+                "sample": f"{count} forward NTTs of the same synthetic rows (N={n}), {cores} threads, {dt:.1f} s; "
+                          f"single thread: {1.0 / per_ntt:.1f} NTT/s",
+                "value_1core": 1.0 / per_ntt}
+
+    transforms = 2 if inverse_too else 1
+    name = (f"batched forward+inverse negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
+            "(BASELINE.json configs[1] shape), device-resident" if inverse_too else
+            f"batched forward negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
+            "(BASELINE.json configs[4] shape), device-resident in->out")
     return {
-        "value": count / dt, "unit": "NTT/s", "cores": cores, "kind": "port",
-        "sample": f"{count} forward NTTs of the same synthetic rows (N={n}), {cores} threads, {dt:.1f} s; "
-                  f"single thread: {one_core:.1f} NTT/s",
-        "value_1core": one_core,
+        "metric": ("NTT/s (N=4096, 64-bit q, forward+inverse) per node; achieved HBM GB/s vs roofline" if inverse_too
+                   else "NTT/s (N=2^16, 64-bit q) per node; achieved HBM GB/s vs roofline"),
+        "unit": "NTT/s", "units_per_step": transforms * batch, "step": step, "parity": parity, "cpu": cpu,
+        "alg_bytes_per_unit": 16 * n,            # SURVEY.md §8d: read N + write N coefficients of 8 B
+        "bfly_per_unit": (n // 2) * log_n,
+        "pass_bytes_per_launch_per_unit": 16 * n,  # every pass kernel reads and writes each coefficient once
+        "config": {"workload": name, "n": n, "q": q, "batch_per_gpu": batch, "global_batch": world * batch,
+                   "parallelism": f"batch-sharded x{world}, no collective"},
+        "plan": plan, "x": x, "y": y, "n": n, "q": q, "batch": batch, "seed": seed,
+    }
+
+
+def workload_bfv(args, pkg, torch, dev, st, rank, world):
+    """config 3: RLWE::mul = tensor + relinearize_204 (bfv/src/lib.rs:59-90,251-271) at N = 8192 with the
+    parameters the reference's i64/f64 arithmetic admits: q = 65537, t = 2, p = q^2."""
+    import numpy as np
+
+    B, L = pkg.binding, pkg.load_library()
+    q, n, t = Q16, 1 << (args.log_n or 13), 2
+    batch = args.batch_per_gpu or 2048
+    pq = q * q * q
+    rng = np.random.default_rng(0xF4E50003 + rank)
+    ab = torch.from_numpy(rng.integers(0, q, (4, batch, n), dtype=np.int64)).to(dev)
+    rlk = torch.from_numpy(np.random.default_rng(0xF4E50003).integers(0, pq, (2, n), dtype=np.int64)).to(dev)
+    out = torch.empty((2, batch, n), dtype=torch.int64, device=dev)
+
+    def step():
+        B._check(L.fhe_bfv_mul_dev(q, n, t, pq, rlk.data_ptr(), ab.data_ptr(), out.data_ptr(), batch, st))
+
+    def parity(O, np):
+        a, r = ab.cpu().numpy().view(np.uint64), rlk.cpu().numpy().view(np.uint64)
+        rows, bad = [0, batch - 1], 0
+        for i in rows:
+            w0, w1 = O.bfv_mul(q, n, t, pq, r[0], r[1], a[0, i:i + 1], a[1, i:i + 1], a[2, i:i + 1], a[3, i:i + 1])
+            if not (np.array_equal(out[0, i].cpu().numpy().view(np.uint64), w0[0]) and
+                    np.array_equal(out[1, i].cpu().numpy().view(np.uint64), w1[0])):
+                bad += 1
+        return len(rows), bad
+
+    def cpu(O, np, seconds):
+        a, r = ab[:, :1].cpu().numpy().view(np.uint64), rlk.cpu().numpy().view(np.uint64)
+        cores = host_cores()
+        fn = lambda: O.bfv_mul(q, n, t, pq, r[0], r[1], a[0], a[1], a[2], a[3])
+        rate, units, dt, one = threaded_rate(fn, 1, seconds, cores)
+        return {"value": rate, "unit": "ct-mul/s", "cores": cores, "kind": "port",
+                "sample": f"{units} ciphertext products (the reference's schoolbook ring_n::naive_mul + f64 scale-round, "
+                          f"oracle/fhe_next_oracle.c) on {cores} threads, {dt:.1f} s; single thread {one:.2f}/s",
+                "value_1core": one}
+
+    log2n = (2 * n).bit_length() - 1
+    # tensor: 1 prime x (4 forward + 3 inverse) size-2N transforms; relinearise: 2 primes x (1 forward + 2 inverse)
+    # (the key's two forward transforms per prime are per call, not per ciphertext)
+    transforms = 7 + 2 * 3
+    return {
+        "metric": "BFV ct x ct multiply + relinearise per second (N=8192, q=65537, t=2, p=q^2) per node",
+        "unit": "ct-mul/s", "units_per_step": batch, "step": step, "parity": parity, "cpu": cpu,
+        "alg_bytes_per_unit": (4 + 2) * 8 * n,      # two ciphertexts in, one out; the key is shared by the batch
+        "bfly_per_unit": transforms * n * log2n,    # (2N/2) * log2(2N) per size-2N transform
+        "pass_bytes_per_launch_per_unit": None,
+        "config": {"workload": f"RLWE::mul (tensor + relinearize_204), N={n}, q={q}, t={t}, p=q^2, {batch} ciphertext pairs "
+                               "per GPU (BASELINE.json configs[2]), device-resident",
+                   "n": n, "q": q, "batch_per_gpu": batch, "global_batch": world * batch,
+                   "parallelism": f"batch-sharded x{world}, no collective"},
+    }
+
+
+def workload_extprod(args, pkg, torch, dev, st, rank, world):
+    """config 4: 630 TGGSW x TGLWE external products (tfhe/src/tggsw.rs:45-62), N = 1024, k = 1, l = 64;
+    with N ranks each owns its fhe_shard_range block of the 630 (79 x 7 + 77 at 8)."""
+    import numpy as np
+
+    B, L = pkg.binding, pkg.load_library()
+    n, k, l = 1 << (args.log_n or 10), 1, 64
+    # weak scaling by default (630 products per GPU); --global-batch 630 block-shards exactly 630 as configs[3] states
+    total = args.global_batch if args.global_batch else (args.batch_per_gpu or 630) * world
+    b0, b1 = B.shard_range(total, world, rank)
+    batch = b1 - b0
+    g = torch.from_numpy(np.random.default_rng(0xF4E50004).integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).to(dev)
+    allc = np.random.default_rng(0xF4E50104).integers(-(1 << 63), 1 << 63, (total, k + 1, n), dtype=np.int64)
+    c = torch.from_numpy(allc[b0:b1].copy()).to(dev)
+    out = torch.empty_like(c)
+
+    def step():
+        B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), out.data_ptr(), batch, st))
+
+    def parity(O, np):
+        rows = sorted(set([0, batch // 2, batch - 1])) if batch else []
+        if not rows:
+            return 0, 0
+        want = O.external_product(n, k, l, g.cpu().numpy().view(np.uint64), c[rows].cpu().numpy().view(np.uint64))
+        bad = sum(0 if np.array_equal(out[r].cpu().numpy().view(np.uint64), want[i]) else 1 for i, r in enumerate(rows))
+        return len(rows), bad
+
+    def cpu(O, np, seconds):
+        gh, ch = g.cpu().numpy().view(np.uint64), c[:1].cpu().numpy().view(np.uint64)
+        cores = host_cores()
+        rate, units, dt, one = threaded_rate(lambda: O.external_product(n, k, l, gh, ch), 1, seconds, cores)
+        return {"value": rate, "unit": "products/s", "cores": cores, "kind": "port",
+                "sample": f"{units} external products (the reference's schoolbook Tn x Tn, oracle/fhe_next_oracle.c) on "
+                          f"{cores} threads, {dt:.1f} s; single thread {one:.2f}/s",
+                "value_1core": one}
+
+    log2n = n.bit_length() - 1
+    transforms = (k + 1) * l + 2 * (k + 1)     # digit transforms + the inverses of the two 32-bit key halves
+    return {
+        "metric": "TGGSW x TGLWE external products per second (N=1024, k=1, l=64) per node",
+        "unit": "products/s", "units_per_step": batch, "step": step, "parity": parity, "cpu": cpu,
+        "alg_bytes_per_unit": 2 * (k + 1) * 8 * n,    # ciphertext in + out; the TGGSW key is shared by the batch
+        "bfly_per_unit": transforms * (n // 2) * log2n,
+        "pass_bytes_per_launch_per_unit": None,
+        "config": {"workload": f"TGGSW x TGLWE external product, N={n}, k={k}, l={l}, {total} products block-sharded over "
+                               f"{world} GPU(s) by fhe_shard_range (BASELINE.json configs[3]), device-resident",
+                   "n": n, "k": k, "l": l, "batch_per_gpu": batch, "global_batch": total,
+                   "parallelism": f"product-sharded x{world}, no collective"},
+        "global_units_per_step": total, "scaling": "strong" if args.global_batch else "weak",
     }
 
 
@@ -112,24 +320,21 @@ def main():
 
     import fhe_study_amd as pkg  # after torch: both then share one libamdhip64
 
-    lib = pkg.load_library()      # raises if libfhe_ntt.so is missing: no fallback
+    pkg.load_library()      # raises if libfhe_ntt.so is missing: no fallback
     B = pkg.binding
-    q, n = args.q, 1 << args.log_n
-    batch = args.batch_per_gpu
-    plan = pkg.Plan(q, n)
     if args.batch_tile:
         B.set_batch_tile(args.batch_tile)
-
     stream = torch.cuda.current_stream()
     st = stream.cuda_stream
-    x = torch.empty(batch * n, dtype=torch.int64, device=dev)
-    y = torch.empty(batch * n, dtype=torch.int64, device=dev)
-    seed = 0xF4E50005
-    first = rank * batch * n      # rank r owns rows [r*batch, (r+1)*batch) of the global batch
-    B.fill_synthetic_dev(q, seed, first, batch * n, x.data_ptr(), st)
-
-    def step():
-        plan.forward_dev(x.data_ptr(), y.data_ptr(), batch, st)
+    if args.config == 5:
+        W = workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too=False)
+    elif args.config == 2:
+        W = workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too=True)
+    elif args.config == 3:
+        W = workload_bfv(args, pkg, torch, dev, st, rank, world)
+    else:
+        W = workload_extprod(args, pkg, torch, dev, st, rank, world)
+    step = W["step"]
 
     for _ in range(args.warmup):
         step()
@@ -164,75 +369,104 @@ def main():
 
     out = None
     if rank == 0:
-        total_ntts = world * batch * args.steps
-        value = total_ntts / elapsed
-        alg_bytes_per_ntt = 16 * n   # read N + write N coefficients of 8 B
+        global_units = W.get("global_units_per_step", world * W["units_per_step"])
+        value = global_units * args.steps / elapsed
+        per_gpu = value / world
         kernels = {k: {"avg_us": 1e3 * ms / cnt, "launches": cnt, "total_ms": ms}
                    for k, (ms, cnt) in timing.items() if cnt}
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
-        roofline = None
-        if dom:
+        achieved = per_gpu * W["alg_bytes_per_unit"] / 1e9           # the whole step, algorithmic GB/s per GPU
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "what": "whole step: algorithmic bytes per unit (SURVEY.md §8d) x units per second per GPU",
+            "algorithmic_bytes_per_unit": W["alg_bytes_per_unit"],
+            "dominant_kernel": dom, "kernels": kernels,
+            "valu": {"bound": "integer butterflies (no MFMA on this path)", "achieved": per_gpu * W["bfly_per_unit"] / 1e9,
+                     "peak": VALU_PEAK_GBFLY, "unit": "Gbutterfly/s",
+                     "frac": per_gpu * W["bfly_per_unit"] / 1e9 / VALU_PEAK_GBFLY,
+                     "butterflies_per_unit": W["bfly_per_unit"],
+                     "peak_source": "tools/ubench_bfly.hip v8 (production butterfly, registers only), profiles/r01_ubench_bfly.txt"},
+        }
+        if dom and W["pass_bytes_per_launch_per_unit"]:
             launches_per_step = kernels[dom]["launches"] / prof_steps
-            polys_per_launch = batch / launches_per_step
-            # each pass kernel reads and writes every coefficient of its polynomials once
-            bytes_per_launch = alg_bytes_per_ntt * polys_per_launch
-            achieved = bytes_per_launch / (kernels[dom]["avg_us"] * 1e-6) / 1e9
+            units_per_launch = W["batch"] / launches_per_step
+            bytes_per_launch = W["pass_bytes_per_launch_per_unit"] * units_per_launch
+            k_ach = bytes_per_launch / (kernels[dom]["avg_us"] * 1e-6) / 1e9
             traffic, traffic_src = None, None
-            try:
-                with open(PMC_TRAFFIC_FILE) as f:
-                    pmc = json.load(f)
-                per_poly = pmc["kernels"][dom]["hbm_bytes_per_polynomial"]
-                traffic = per_poly * polys_per_launch
-                traffic_src = pmc["source"]
-            except (OSError, KeyError, ValueError):
-                pass
-            roofline = {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "avg_launch_us": kernels[dom]["avg_us"], "polys_per_launch": polys_per_launch,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                # the whole transform (all its kernels): 16*N bytes per NTT over the timed region
-                "transform_achieved": (value / world) * alg_bytes_per_ntt / 1e9,
-                "transform_frac": (value / world) * alg_bytes_per_ntt / 1e9 / HBM_PEAK_GBS,
-                "kernels": kernels,
-            }
+            for f in PMC_TRAFFIC_FILES:
+                try:
+                    with open(f) as fh:
+                        pmc = json.load(fh)
+                    traffic = pmc["kernels"][dom]["hbm_bytes_per_polynomial"] * units_per_launch
+                    traffic_src = pmc["source"]
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
+            roofline["traffic"] = traffic
+            roofline["traffic_source"] = traffic_src
+            roofline["dominant_kernel_launch"] = {
+                "kernel": dom, "avg_launch_us": kernels[dom]["avg_us"], "polys_per_launch": units_per_launch,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "achieved": k_ach, "frac": k_ach / HBM_PEAK_GBS,
+                "note": "one of the passes of the transform taken alone; the transform is `frac` above"}
+            # kept under their round-1 names for comparison across rounds
+            roofline["transform_achieved"] = achieved
+            roofline["transform_frac"] = achieved / HBM_PEAK_GBS
         out = {
-            "metric": "NTT/s (N=2^16, 64-bit q) per node; achieved HBM GB/s vs roofline",
-            "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
+            "metric": W["metric"], "value": value, "unit": W["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"batched forward negacyclic NTT, N={n}, q={q}, "
-                                   f"{batch} polynomials per GPU (BASELINE.json configs[4] shape), "
-                                   "device-resident in->out",
-                       "n": n, "q": q, "batch_per_gpu": batch, "global_batch": world * batch,
-                       "parallelism": f"batch-sharded x{world}, no collective"},
-            "roofline": roofline,
+            "higher_is_better": True, "scaling": W.get("scaling", "weak"), "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic", "config": W["config"], "roofline": roofline,
         }
 
-    # ---- parity subset: first 8, last 8, 48 pseudo-random rows ----------
-    if rank == 0 and not args.no_parity:
+    # ---- parity against the CPU oracle (checker only; never inside the timed region) ----------
+    if not args.no_parity and (rank == 0 or args.parity_all_ranks):
         import numpy as np
         from oracle import load_oracle
 
-        O = load_oracle()
-        rng = np.random.default_rng(7)
-        rows = sorted(set(list(range(min(8, batch))) + list(range(max(0, batch - 8), batch)) +
-                          [int(r) for r in rng.integers(0, batch, 48)]))
-        Y = y.view(batch, n)
-        bad = 0
-        for r in rows:
-            a = O.fill_synthetic(q, seed, first + r * n, n)
-            if not np.array_equal(Y[r].cpu().numpy().view(np.uint64), O.ntt(q, n, a)):
-                bad += 1
-        out["parity"] = {"rows_checked": len(rows), "mismatching_rows": bad, "oracle": "oracle/ntt_oracle.c"}
+        rows, bad = W["parity"](load_oracle(), np)
+        mine = torch.tensor([rows, bad, 1], dtype=torch.int64, device=cdev)
+    else:
+        mine = torch.tensor([0, 0, 0], dtype=torch.int64, device=cdev)
+    if dist is not None and args.parity_all_ranks:
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+    if rank == 0 and not args.no_parity:
+        rows, bad, ranks = (int(v) for v in mine.tolist())
+        out["parity"] = {"rows_checked": rows, "mismatching_rows": bad, "ranks_checked": ranks,
+                         "oracle": "oracle/ (CPU restatement of the reference)"}
         if bad:
             print(json.dumps(out))
-            raise SystemExit(f"PARITY FAILURE: {bad} of {len(rows)} rows differ from the oracle")
+            raise SystemExit(f"PARITY FAILURE: {bad} of {rows} checked units differ from the oracle")
 
-    if args.allgather and dist is not None and args.backend == "nccl":
+    # ---- N > 1: shards gathered through sharding.ShardedNTT == the single-rank transform ----------
+    if args.gather_check and dist is not None and args.config == 5:
+        import numpy as np
+
+        n, q, batch, plan, seed = W["n"], W["q"], W["batch"], W["plan"], W["seed"]
+        gbatch = world * batch
+
+        def transform(rows):     # the per-rank engine: Plan.forward_dev on device tensors
+            d = rows.to(dev)
+            o = torch.empty_like(d)
+            plan.forward_dev(d.data_ptr(), o.data_ptr(), d.shape[0], st)
+            torch.cuda.synchronize()
+            return o.to(cdev)
+
+        def rows_fn(b0, b1):     # each rank generates its own rows (never broadcast)
+            d = torch.empty((b1 - b0) * n, dtype=torch.int64, device=dev)
+            B.fill_synthetic_dev(q, seed, b0 * n, (b1 - b0) * n, d.data_ptr(), st)
+            torch.cuda.synchronize()
+            return d.view(b1 - b0, n)
+
+        eng = pkg.sharding.ShardedNTT(transform)
+        full = eng.forward_sharded(rows_fn, gbatch, gather=True)
+        if rank == 0:
+            whole = transform(rows_fn(0, gbatch))
+            out["gather_check"] = {"rows": gbatch, "equal_to_single_rank_transform": bool(torch.equal(full, whole))}
+
+    if args.allgather and dist is not None and args.backend == "nccl" and args.config == 5:
         # optional: the one collective of SURVEY.md §8e, timed on its own (not part of `value`)
+        y, n, batch = W["y"], W["n"], W["batch"]
         slab = min(batch, 1024) * n
         gathered = torch.empty(world * slab, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(gathered, y[:slab])
@@ -246,7 +480,10 @@ def main():
                                 "GBps_per_rank": (world - 1) * slab * 8 / dt / 1e9}
 
     if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(q, n, args.cpu_seconds)
+        import numpy as np
+        from oracle import load_oracle
+
+        out["cpu_baseline"] = W["cpu"](load_oracle(), np, args.cpu_seconds)
 
     if rank == 0:
         print(json.dumps(out))

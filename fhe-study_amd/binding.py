@@ -46,6 +46,7 @@ EXPORTS = [
     "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
+    "fhe_ntt_plan_prepare", "fhe_ntt_set_check_canonical", "fhe_shard_range",
     # next rows: exact products over Z / mod 2^64 on top of the engine
     "fhe_r_naive_mul", "fhe_r_naive_mul_dev", "fhe_mul_div_round_dev",
     "fhe_bfv_tensor", "fhe_bfv_tensor_dev", "fhe_bfv_relinearize_dev", "fhe_bfv_mul", "fhe_bfv_mul_dev",
@@ -205,6 +206,9 @@ def load_library():
     L.fhe_rq_mul_by_f64_dev.argtypes = [_u64, ctypes.c_double, _vp, _vp, _sz, _vp]
     L.fhe_rq_div_round_dev.argtypes = [_u64, _u64, _vp, _vp, _sz, _vp]
     L.fhe_ntt_device_count.argtypes = []
+    L.fhe_ntt_plan_prepare.argtypes = [_vp]
+    L.fhe_ntt_set_check_canonical.argtypes = [_int]
+    L.fhe_shard_range.argtypes = [_sz, _uint, _uint, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
     L.fhe_last_error.restype = ctypes.c_char_p
     L.fhe_ntt_version.restype = ctypes.c_char_p
     for name in EXPORTS:
@@ -398,6 +402,18 @@ def fill_synthetic_dev(q, seed, first_index, count, d_out, stream=None):
 
 def device_count():
     return int(load_library().fhe_ntt_device_count())
+
+
+def set_check_canonical(on):
+    """FHE_NTT_CHECK_CANONICAL at run time: transforms reject inputs >= q instead of returning garbage."""
+    _check(load_library().fhe_ntt_set_check_canonical(int(bool(on))))
+
+
+def shard_range(total, world, rank):
+    """[begin, end) of `total` units owned by `rank` of `world` (fhe_shard_range; host-only)."""
+    b, e = _sz(0), _sz(0)
+    _check(load_library().fhe_shard_range(int(total), int(world), int(rank), ctypes.byref(b), ctypes.byref(e)))
+    return int(b.value), int(e.value)
 
 
 def set_batch_tile(polys):

@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -185,6 +186,8 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     std::lock_guard<std::mutex> lk(plan->dev_lock);
     DeviceTables &t = plan->dev[dev];
     if (!t.ready) {
+        // First use on this device: a blocking allocation + upload (fhe_ntt_plan_prepare does it
+        // ahead of time, e.g. before a stream capture).  Nothing is kept on a failure.
         const u64 n = plan->n, q = plan->q;
         std::vector<fhe::Tw> f(n), i(n);
         for (u64 k = 0; k < n; k++) {
@@ -193,10 +196,18 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
             i[k].w = plan->roots_inv[k];
             i[k].wp = shoup(plan->roots_inv[k], q);
         }
-        HIP_TRY(hipMalloc((void **)&t.tw_fwd, n * sizeof(fhe::Tw)));
-        HIP_TRY(hipMalloc((void **)&t.tw_inv, n * sizeof(fhe::Tw)));
-        HIP_TRY(hipMemcpy(t.tw_fwd, f.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(t.tw_inv, i.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice));
+        fhe::Tw *df = nullptr, *di = nullptr;
+        hipError_t e = hipMalloc((void **)&df, n * sizeof(fhe::Tw));
+        if (e == hipSuccess) e = hipMalloc((void **)&di, n * sizeof(fhe::Tw));
+        if (e == hipSuccess) e = hipMemcpy(df, f.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(di, i.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (df) (void)hipFree(df);
+            if (di) (void)hipFree(di);
+            return hip_fail(e, "uploading the twiddle tables");
+        }
+        t.tw_fwd = df;
+        t.tw_inv = di;
         t.ready = true;
     }
     dp->tw_fwd = t.tw_fwd;
@@ -206,6 +217,65 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     dp->s_ninv = plan->s_ninv;
     dp->log_n = plan->log_n;
     dp->wide = (plan->q >> 61) == 0;
+    return FHE_OK;
+}
+
+extern "C" int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    fhe::DevicePlan dp;
+    return fhe_device_plan(plan, &dp);
+}
+
+// contiguous block partition of `total` independent units over `world` devices:
+// rank r owns [r*ceil(total/world), min(total, (r+1)*ceil(total/world)))
+extern "C" int fhe_shard_range(size_t total, unsigned world, unsigned rank, size_t *begin, size_t *end) {
+    if (!begin || !end) return fail(FHE_E_NULL, "fhe_shard_range: NULL output");
+    if (world == 0 || rank >= world) return fail(FHE_E_INVALID, "fhe_shard_range: need rank < world (got %u, %u)", rank, world);
+    const size_t per = total / world + (total % world != 0);
+    const size_t b0 = (size_t)rank * per < total ? (size_t)rank * per : total;
+    *begin = b0;
+    *end = total - b0 < per ? total : b0 + per;
+    return FHE_OK;
+}
+
+// ---- opt-in input validation ---------------------------------------------------------------
+// The reference cannot construct a Zq with v >= q (Zq::from_u64 reduces, zq.rs:21-30); a C caller
+// can hand one over, and the lazy butterflies then return words that are simply wrong.  With
+// FHE_NTT_CHECK_CANONICAL=1 in the environment (or fhe_ntt_set_check_canonical(1)) every transform /
+// product entry point first scans its coefficient inputs on the device and returns
+// FHE_E_NOT_CANONICAL instead.  It synchronises the stream, so it is a debugging aid, off by default.
+static std::mutex g_check_lock;
+static int g_check_canonical = -1;   // -1: not read from the environment yet
+static bool check_canonical_on() {
+    std::lock_guard<std::mutex> lk(g_check_lock);
+    if (g_check_canonical < 0) {
+        const char *e = getenv("FHE_NTT_CHECK_CANONICAL");
+        g_check_canonical = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_check_canonical == 1;
+}
+extern "C" int fhe_ntt_set_check_canonical(int on) {
+    std::lock_guard<std::mutex> lk(g_check_lock);
+    g_check_canonical = on ? 1 : 0;
+    return FHE_OK;
+}
+static int check_canonical_dev(const fhe_ntt_plan *plan, const void *d_x, size_t count, hipStream_t st, const char *who) {
+    if (!check_canonical_on() || !d_x || count == 0) return FHE_OK;
+    void *df = nullptr;
+    size_t cap = 0;
+    int dev = 0;
+    int rc = fhe_stage_acquire(sizeof(int), &df, &cap, &dev);
+    if (rc != FHE_OK) return rc;
+    int flag = 0;
+    hipError_t e = hipMemsetAsync(df, 0, sizeof(int), st);
+    if (e == hipSuccess) e = fhe::launch_check_canonical((const u64 *)d_x, count, plan->q, (int *)df, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, df, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    else (void)hipStreamSynchronize(st);
+    fhe_stage_release(df, cap, dev);
+    if (e != hipSuccess) return hip_fail(e, "canonical check");
+    if (flag) return fail(FHE_E_NOT_CANONICAL, "%s: an input coefficient >= q=%llu (FHE_NTT_CHECK_CANONICAL)", who,
+                          (unsigned long long)plan->q);
     return FHE_OK;
 }
 
@@ -241,29 +311,40 @@ extern "C" int fhe_ntt_set_batch_tile(size_t polys) {
     return FHE_OK;
 }
 
-// grow-only per-device workspaces (slot 0: fhe_rq_mul_dev(d_work = NULL), slot 1: zring / glue).
-// Growing never frees a buffer that enqueued work may still be using: the old buffer is retired
-// and released at fhe_ntt_shutdown().  Callers that rely on the library workspace must issue
-// those calls on ONE stream at a time per device (the contents are per call, not per stream).
+// Grow-only library workspaces, one per (slot, device, STREAM): slot 0 = fhe_rq_mul_dev(d_work = NULL)
+// and the tensor result of fhe_bfv_mul_dev, slot 1 = zring / glue intermediates.  The contents
+// belong to one call; calls on the same stream are ordered by the stream, calls on different
+// streams get different buffers, so the *_dev entry points may be issued concurrently from any
+// number of streams and threads (tests/test_parity_gpu.py::test_two_streams_share_no_workspace).
+// hipStreamPerThread is ONE handle that names a different stream in every thread, so for it
+// the key also carries the calling thread.  Growing never frees a buffer that enqueued work may
+// still be using: the old buffer is retired and released at fhe_ntt_shutdown().
 struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
+struct WsKey {
+    int slot, dev;
+    hipStream_t st;
+    size_t tid;
+    bool operator<(const WsKey &o) const {
+        if (slot != o.slot) return slot < o.slot;
+        if (dev != o.dev) return dev < o.dev;
+        if (st != o.st) return st < o.st;
+        return tid < o.tid;
+    }
+};
 static std::mutex g_ws_lock;
-static Workspace g_ws[2][kMaxDevices];
+static std::map<WsKey, Workspace> g_ws;
 static std::vector<void *> g_ws_retired;
 
-std::mutex &fhe_host_workspace_lock() {
-    static std::mutex m;
-    return m;
-}
-
-int fhe_workspace_get(int slot, size_t bytes, void **out) {
+int fhe_workspace_get(int slot, size_t bytes, hipStream_t st, void **out) {
     int dev = 0;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    const size_t tid = st == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0;
     std::lock_guard<std::mutex> lk(g_ws_lock);
-    Workspace &w = g_ws[slot][dev];
+    Workspace &w = g_ws[WsKey{slot, dev, st, tid}];
     if (w.bytes < bytes) {
         // grow geometrically so that the buffers retired on the way sum to less than the live one
         size_t want = w.bytes + w.bytes / 2;
@@ -351,12 +432,9 @@ static void stage_free_all() {
 void fhe_workspace_free_all() {
     stage_free_all();
     std::lock_guard<std::mutex> lk(g_ws_lock);
-    for (auto &slot : g_ws)
-        for (auto &w : slot) {
-            if (w.ptr) (void)hipFree(w.ptr);
-            w.ptr = nullptr;
-            w.bytes = 0;
-        }
+    for (auto &kv : g_ws)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_ws.clear();
     for (void *p : g_ws_retired) (void)hipFree(p);
     g_ws_retired.clear();
 }
@@ -453,6 +531,7 @@ extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, v
     fhe::DevicePlan dp;
     int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
+    if ((rc = check_canonical_dev(plan, d_in, batch * plan->n, (hipStream_t)hip_stream, "fhe_ntt_forward_dev")) != FHE_OK) return rc;
     hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_in, (u64 *)d_out, batch,
                                            fhe_batch_tile_for(plan), (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward");
@@ -469,6 +548,7 @@ extern "C" int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, v
     fhe::DevicePlan dp;
     int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
+    if ((rc = check_canonical_dev(plan, d_in, batch * plan->n, (hipStream_t)hip_stream, "fhe_ntt_inverse_dev")) != FHE_OK) return rc;
     hipError_t e = fhe::launch_ntt_inverse(dp, (const u64 *)d_in, nullptr, nullptr, (u64 *)d_out,
                                            batch, fhe_batch_tile_for(plan), (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_inverse");
@@ -500,6 +580,8 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t elems = batch * plan->n, bytes = elems * sizeof(u64);
     const u64 tile = fhe_batch_tile_for(plan);
+    if ((rc = check_canonical_dev(plan, d_a, elems, st, "fhe_rq_mul_dev (a)")) != FHE_OK) return rc;
+    if ((rc = check_canonical_dev(plan, d_b, elems, st, "fhe_rq_mul_dev (b)")) != FHE_OK) return rc;
 
     // single-pass sizes: the whole product in one kernel (both forward transforms, the pointwise
     // product and the inverse transform stay on chip); FHE_RQ_MUL_FUSED=0 selects the three-kernel path
@@ -521,7 +603,7 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
     u64 *work = (u64 *)d_work;
     if ((need_wa || need_wb) && !work) {
         void *w = nullptr;
-        rc = fhe_workspace_get(0, 2 * bytes, &w);
+        rc = fhe_workspace_get(0, 2 * bytes, st, &w);
         if (rc != FHE_OK) return rc;
         work = (u64 *)w;
     }
@@ -558,6 +640,8 @@ extern "C" int fhe_rq_pointwise_mul_dev(const fhe_ntt_plan *plan, const void *d_
     fhe::DevicePlan dp;
     int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
+    if ((rc = check_canonical_dev(plan, d_a, batch * plan->n, (hipStream_t)hip_stream, "fhe_rq_pointwise_mul_dev (a)")) != FHE_OK) return rc;
+    if ((rc = check_canonical_dev(plan, d_b, batch * plan->n, (hipStream_t)hip_stream, "fhe_rq_pointwise_mul_dev (b)")) != FHE_OK) return rc;
     hipError_t e = fhe::launch_pointwise_mul(dp, (const u64 *)d_a, (const u64 *)d_b, (u64 *)d_c,
                                              batch * plan->n, (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_pointwise_mul");
@@ -731,7 +815,7 @@ extern "C" int fhe_ntt_device_count(void) {
 }
 
 extern "C" const char *fhe_last_error(void) { return g_err; }
-extern "C" const char *fhe_ntt_version(void) { return "fhe_ntt 0.1 (gfx950)"; }
+extern "C" const char *fhe_ntt_version(void) { return "fhe_ntt 0.2 (gfx950)"; }
 
 extern "C" int fhe_ntt_shutdown(void) {
     {

@@ -39,12 +39,8 @@ int fhe_hip_fail(hipError_t e, const char *what);
 int fhe_current_device(int *dev);
 int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp);
 fhe::u64 fhe_batch_tile_for(const fhe_ntt_plan *plan);
-// grow-only per-device scratch; slot 0 = fhe_rq_mul_dev, slot 1 = zring
-int fhe_workspace_get(int slot, size_t bytes, void **out);
-// Serialises HOST-buffer entry points that use the shared workspace (each runs on its own
-// per-thread stream, so two host threads would otherwise overlap in it).  Held from the first
-// launch until the results are back on the host.
-std::mutex &fhe_host_workspace_lock();
+// grow-only scratch per (slot, device, stream); slot 0 = fhe_rq_mul_dev / bfv tensor, slot 1 = zring, glue
+int fhe_workspace_get(int slot, size_t bytes, hipStream_t st, void **out);
 void fhe_workspace_free_all();
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
 int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);
@@ -69,14 +65,13 @@ static inline unsigned fhe_ew_grid(fhe::u64 count) {
         if (e_ != hipSuccess) return fhe_hip_fail(e_, what); \
     } while (0)
 
-// Staging of HOST buffers around a *_dev entry point that uses the shared workspace: uploads on
-// the calling thread's stream, holds fhe_host_workspace_lock() until its destructor body has
-// freed the device buffers (hipFree drains the stream on error paths).
+// Staging of HOST buffers around a *_dev entry point: uploads on the calling thread's stream
+// (hipStreamPerThread, for which the library workspace is per thread: no lock is needed); the
+// destructor drains the stream on error paths before the buffers go back to the pool.
 struct FheHostStage {
     struct Buf { void *p; size_t cap; int dev; };
     std::vector<Buf> bufs;
     bool clean = false;   // the stream has been synchronised after the last use of the buffers
-    std::lock_guard<std::mutex> ws_lock{fhe_host_workspace_lock()};
     ~FheHostStage() {
         if (!clean) (void)hipStreamSynchronize(hipStreamPerThread);   // error path: drain before reuse
         for (auto &b : bufs) fhe_stage_release(b.p, b.cap, b.dev);

@@ -242,8 +242,28 @@ extern "C" int fhe_rq_div_round_dev(uint64_t q, uint64_t s, const void *d_a, voi
     LAUNCH_OK("ewf_kernel<DivRound>");
     return FHE_OK;
 }
+// Argument ranges in which Zq::decompose (zq.rs:141-190) is defined.  Outside them the reference
+// panics (`beta.pow(l)` overflowing u32 and `>> i` with i >= 64 in a debug build, `q / beta^i` = 0
+// as a divisor in any build); the ABI answers FHE_E_INVALID and never launches.
+static int check_decompose_args(const char *who, u64 q, unsigned beta, unsigned l) {
+    if (beta < 2 || l < 1) return fhe_fail(FHE_E_INVALID, "%s: need beta >= 2, l >= 1", who);
+    if (beta == 2) {
+        if (l > 64) return fhe_fail(FHE_E_INVALID, "%s: beta = 2 needs l <= 64 (got %u)", who, l);
+        return FHE_OK;
+    }
+    u64 bl = 1;
+    for (unsigned i = 0; i < l; i++) {
+        bl *= beta;
+        if (bl >> 32) return fhe_fail(FHE_E_INVALID, "%s: beta^l = %u^%u overflows u32 (beta.pow(l), zq.rs:152)", who, beta, l);
+    }
+    if (q / bl == 0) return fhe_fail(FHE_E_INVALID, "%s: q / beta^l = 0 for q=%llu, beta=%u, l=%u (divisor at zq.rs:164-165)", who,
+                                     (unsigned long long)q, beta, l);
+    return FHE_OK;
+}
+
 extern "C" int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, const void *d_a, void *d_out, size_t rows, void *st) {
-    if (q == 0 || n == 0 || beta < 2 || l < 1) return fhe_fail(FHE_E_INVALID, "fhe_rq_decompose_dev: need q, n > 0, beta >= 2, l >= 1");
+    if (q == 0 || n == 0) return fhe_fail(FHE_E_INVALID, "fhe_rq_decompose_dev: need q, n > 0");
+    if (int vrc = check_decompose_args("fhe_rq_decompose_dev", q, beta, l)) return vrc;
     if (rows == 0) return FHE_OK;
     if (!d_a || !d_out) return fhe_fail(FHE_E_NULL, "fhe_rq_decompose_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
@@ -276,7 +296,7 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     const u64 n = plan->n, rows = batch * k;
     const bool a_ev = flags & FHE_A_IS_EVALS, b_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
     void *w = nullptr;
-    if ((rc = fhe_workspace_get(1, (2 * rows + batch) * n * 8, &w)) != FHE_OK) return rc;
+    if ((rc = fhe_workspace_get(1, (2 * rows + batch) * n * 8, st, &w)) != FHE_OK) return rc;
     u64 *WA = (u64 *)w, *WB = WA + rows * n, *WC = WB + rows * n;
     const u64 *A = (const u64 *)d_a, *B = (const u64 *)d_b;
     if (!a_ev) { if ((rc = fwd(plan, dp, A, WA, rows, st)) != FHE_OK) return rc; A = WA; }
@@ -302,7 +322,7 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     const u64 n = plan->n, total = batch * rows;
     const bool a_ev = flags & FHE_A_IS_EVALS, p_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
     void *w = nullptr;
-    if ((rc = fhe_workspace_get(1, (2 * total + batch) * n * 8, &w)) != FHE_OK) return rc;
+    if ((rc = fhe_workspace_get(1, (2 * total + batch) * n * 8, st, &w)) != FHE_OK) return rc;
     u64 *WA = (u64 *)w, *WC = WA + total * n, *WP = WC + total * n;
     const u64 *A = (const u64 *)d_a, *P = (const u64 *)d_p;
     if (!a_ev) { if ((rc = fwd(plan, dp, A, WA, total, st)) != FHE_OK) return rc; A = WA; }
@@ -341,7 +361,7 @@ extern "C" int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
     const u64 n = plan->n;
     void *w = nullptr;
-    if ((rc = fhe_workspace_get(1, ((u64)l * (k + 1) + batch * l) * n * 8, &w)) != FHE_OK) return rc;
+    if ((rc = fhe_workspace_get(1, ((u64)l * (k + 1) + batch * l) * n * 8, (hipStream_t)stream, &w)) != FHE_OK) return rc;
     return keyed_mac(plan, dp, (const u64 *)d_glev, flags & FHE_A_IS_EVALS, (const u64 *)d_v, flags & FHE_B_IS_EVALS, (u64 *)d_out,
                      flags & FHE_OUT_EVALS, l, k + 1, batch, (u64 *)w, (hipStream_t)stream);
 }
@@ -355,6 +375,7 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     if (rc != FHE_OK) return rc;
     if (batch == 0) return FHE_OK;
     if (k == 0 || l == 0 || beta < 2) return fhe_fail(FHE_E_INVALID, "fhe_glwe_key_switch_dev: need k, l >= 1, beta >= 2");
+    if ((rc = check_decompose_args("fhe_glwe_key_switch_dev", plan->q, beta, l)) != FHE_OK) return rc;
     if (!d_glwe || !d_ksk || !d_out) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch_dev: NULL buffer");
     REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_ksk); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
@@ -364,7 +385,7 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     const u32 k1 = k + 1, T = k * l;
     void *w = nullptr;
     // [decomposition: batch*k*l rows] [rhs: batch*k1 rows] [keyed_mac scratch: T*k1 + batch*T rows]
-    if ((rc = fhe_workspace_get(1, (batch * T + batch * k1 + (u64)T * k1 + batch * T) * n * 8, &w)) != FHE_OK) return rc;
+    if ((rc = fhe_workspace_get(1, (batch * T + batch * k1 + (u64)T * k1 + batch * T) * n * 8, st, &w)) != FHE_OK) return rc;
     u64 *DEC = (u64 *)w, *RHS = DEC + batch * T * n, *WS = RHS + batch * k1 * n;
     // decompose the k mask polynomials of every ciphertext (the body row is skipped): rows (b, i) -> [b][i][d].
     // Base 2 at single-pass sizes: the digit is extracted in the load of its forward transform

@@ -376,7 +376,7 @@ extern "C" int fhe_r_naive_mul_dev(uint64_t n, const void *d_a, const void *d_b,
     hipStream_t st = (hipStream_t)hip_stream;
     const u64 words = batch * n2;
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (2 + (size_t)z.K) * words * 8, &wsv);
+    rc = fhe_workspace_get(1, (2 + (size_t)z.K) * words * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;   // R: K residue arrays
     for (int k = 0; k < z.K; k++) {
@@ -423,9 +423,9 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
     hipStream_t st = (hipStream_t)hip_stream;
     const u64 words = batch * n2;   // per polynomial set
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (4 + 3 * (size_t)z.K + 3) * words * 8, &wsv);
+    rc = fhe_workspace_get(1, (4 + 3 * (size_t)z.K) * words * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
-    u64 *AB = (u64 *)wsv, *R = AB + 4 * words, *V = R + 3 * (u64)z.K * words;
+    u64 *AB = (u64 *)wsv, *R = AB + 4 * words;
     for (int k = 0; k < z.K; k++) {
         if ((rc = z_forward_src(z, k, (const u64 *)d_ab, AB, 4 * batch, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 3 * (u64)k * words;
@@ -434,7 +434,6 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
         if ((rc = z_inverse(z, k, Rk, Rk, 3 * batch, st)) != FHE_OK) return rc;
     }
     // recombine, scale by t/q, round, reduce, fold — in one kernel (the integers are never stored)
-    (void)V;
     return z_crt_mdr(z, R, R + 3 * words, R + 6 * words, nullptr, (u64 *)d_c, 3 * batch, n, q, t, q, st);
 }
 
@@ -455,9 +454,9 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
     hipStream_t st = (hipStream_t)hip_stream;
     const u64 words = batch * n2, bn = batch * n;
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (1 + 2 * (size_t)z.K + 2 + 1) * words * 8 + 2 * n2 * 8, &wsv);
+    rc = fhe_workspace_get(1, (1 + 2 * (size_t)z.K) * words * 8 + 2 * n2 * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
-    u64 *X = (u64 *)wsv, *R = X + words, *V = R + 2 * (u64)z.K * words, *Rr = V + 2 * words, *Y = Rr + words;
+    u64 *X = (u64 *)wsv, *R = X + words, *Y = R + 2 * (u64)z.K * words;
     const u64 *c2 = (const u64 *)d_c + 2 * bn;
     for (int k = 0; k < z.K; k++) {
         if ((rc = z_forward_src(z, k, c2, X, batch, n, st)) != FHE_OK) return rc;
@@ -468,7 +467,7 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
         if ((rc = z_inverse(z, k, Rk, Rk, 2 * batch, st)) != FHE_OK) return rc;
     }
     // (c0, c1) + mul_div_round(crt(..), 1, p): recombination, scaling, fold and the final add in one kernel
-    (void)V; (void)Rr; (void)bn;
+    (void)bn;
     return z_crt_mdr(z, R, R + 2 * words, R + 4 * words, (const u64 *)d_c, (u64 *)d_out, 2 * batch, n, q, 1, p, st);
 }
 
@@ -478,7 +477,7 @@ extern "C" int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, 
     // the tensor result lives in workspace slot 0 (both stages use slot 1); a stream-ordered
     // allocation per call cost up to 2 ms at 2048 ciphertexts whenever the pool had trimmed itself
     void *c = nullptr;
-    int rc = fhe_workspace_get(0, 3 * batch * n * 8, &c);
+    int rc = fhe_workspace_get(0, 3 * batch * n * 8, (hipStream_t)hip_stream, &c);
     if (rc != FHE_OK) return rc;
     rc = fhe_bfv_tensor_dev(q, n, t, d_ab, c, batch, hip_stream);
     if (rc == FHE_OK) rc = fhe_bfv_relinearize_dev(q, n, pq, d_rlk, c, d_out, batch, hip_stream);
@@ -499,7 +498,7 @@ extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void
     hipStream_t st = (hipStream_t)hip_stream;
     const u64 words = batch * n;
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (2 + (size_t)z.K) * words * 8, &wsv);
+    rc = fhe_workspace_get(1, (2 + (size_t)z.K) * words * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *A = (u64 *)wsv, *B = A + words, *R = B + words;
     for (int k = 0; k < z.K; k++) {
@@ -532,7 +531,7 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
         ZCtx z1;
         if ((rc = zctx_init(&z1, n, 1)) != FHE_OK) return rc;
         void *wsv = nullptr;
-        if ((rc = fhe_workspace_get(1, (2 * grows + drows + 2 * orows) * n * 8, &wsv)) != FHE_OK) return rc;
+        if ((rc = fhe_workspace_get(1, (2 * grows + drows + 2 * orows) * n * 8, st, &wsv)) != FHE_OK) return rc;
         u64 *G2 = (u64 *)wsv, *D = G2 + 2 * grows * n, *R = D + drows * n;
         const u64 T = (u64)k1 * l;
         hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G2, T, k1, (u32)n);
@@ -553,7 +552,7 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
     rc = zctx_init(&z, n, primes_for_bits(64 + ceil_log2(n) + ceil_log2((u64)k1 * l), true));
     if (rc != FHE_OK) return rc;
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (grows + 2 * drows + (size_t)z.K * orows) * n * 8, &wsv);
+    rc = fhe_workspace_get(1, (grows + 2 * drows + (size_t)z.K * orows) * n * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *G = (u64 *)wsv, *Dg = G + grows * n, *D = Dg + drows * n, *R = D + drows * n;
     bool digits_done = false;
@@ -599,7 +598,7 @@ extern "C" int fhe_tglwe_mul_tn_dev(uint64_t n, unsigned k, const void *d_tglwe,
     hipStream_t st = (hipStream_t)hip_stream;
     const u64 rows = batch * k1;
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (rows + batch + (size_t)z.K * rows) * n * 8, &wsv);
+    rc = fhe_workspace_get(1, (rows + batch + (size_t)z.K * rows) * n * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *A = (u64 *)wsv, *P = A + rows * n, *R = P + batch * n;
     for (int kk = 0; kk < z.K; kk++) {
@@ -631,7 +630,7 @@ extern "C" int fhe_tglev_mul_dev(uint64_t n, unsigned k, unsigned l, const void 
     hipStream_t st = (hipStream_t)hip_stream;
     const u64 grows = (u64)l * k1, vrows = batch * l, orows = batch * k1;
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (grows + vrows + (size_t)z.K * orows) * n * 8, &wsv);
+    rc = fhe_workspace_get(1, (grows + vrows + (size_t)z.K * orows) * n * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *G = (u64 *)wsv, *V = G + grows * n, *R = V + vrows * n;
     for (int kk = 0; kk < z.K; kk++) {

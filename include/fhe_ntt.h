@@ -16,11 +16,19 @@
  *     and a message retrievable with fhe_last_error() (thread-local).  The
  *     reference panics in the same situations; the Rust shim turns a non-zero
  *     return into `panic!`.
- *   - All functions are thread-safe.  Plans are immutable and owned by the
- *     library until fhe_ntt_shutdown().
+ *   - All functions are thread-safe and may be called concurrently, on the same
+ *     or different plans.  Plans are immutable and owned by the library until
+ *     fhe_ntt_shutdown().  Entry points that need intermediates use a
+ *     library-owned workspace keyed by (device, stream): calls on one stream
+ *     are ordered by the stream, calls on different streams (or, for
+ *     hipStreamPerThread / the host-buffer entry points, different threads)
+ *     never share a buffer.
  *   - `*_dev` variants take DEVICE pointers of the current HIP device and a
  *     `hipStream_t` passed as `void*` (NULL = the default stream); they only
- *     enqueue work and never synchronise.  Device buffers must be 16-byte
+ *     enqueue work and never synchronise — except the first use of a plan on a
+ *     device, which uploads its tables (call fhe_ntt_plan_prepare() beforehand
+ *     to keep that out of, e.g., a stream capture), growth of a library
+ *     workspace, and the opt-in FHE_NTT_CHECK_CANONICAL mode.  Device buffers must be 16-byte
  *     aligned (FHE_E_INVALID otherwise; anything hipMalloc returns is).  Host-pointer variants copy
  *     host→device→host around the same kernels and return when `out` is valid.
  *   - There is no CPU fallback: without a HIP device every compute entry point
@@ -73,6 +81,10 @@ int fhe_ntt_plan_info(const fhe_ntt_plan *plan, uint64_t *q, uint64_t *n, uint64
                       uint64_t *n_inv);
 /* copies the n-entry tables (either pointer may be NULL). */
 int fhe_ntt_plan_tables(const fhe_ntt_plan *plan, uint64_t *roots, uint64_t *roots_inv);
+/* Uploads the plan's twiddle tables to the CURRENT device now (blocking) instead
+ * of at the first transform there — the device-side half of CACHE's one-off
+ * table build (ntt.rs:20-38). */
+int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan);
 
 /* ---- transforms: host buffers ------------------------------------------- */
 /* NTT::ntt(&Rq)->Rq, arith/src/ntt.rs:44-73: natural order in, bit-reversed
@@ -103,6 +115,13 @@ int fhe_rq_pointwise_mul(const fhe_ntt_plan *plan, const uint64_t *a, const uint
                          uint64_t *c, size_t batch);
 /* FHE_OK, or FHE_E_NOT_CANONICAL if any of the batch*n values is >= q. */
 int fhe_rq_check_canonical(const fhe_ntt_plan *plan, const uint64_t *x, size_t batch);
+/* Opt-in validation: with FHE_NTT_CHECK_CANONICAL=1 in the environment, or after
+ * fhe_ntt_set_check_canonical(1), fhe_ntt_forward/inverse, fhe_rq_mul and
+ * fhe_rq_pointwise_mul (host and _dev forms) scan their coefficient inputs on the
+ * device first and return FHE_E_NOT_CANONICAL for a value >= q instead of
+ * undefined words (the reference cannot build such a Zq, zq.rs:21-30; a C caller
+ * can).  The scan synchronises the stream: a debugging aid, off by default. */
+int fhe_ntt_set_check_canonical(int on);
 
 /* ---- transforms: device-resident buffers -------------------------------- */
 int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, void *d_out, size_t batch,
@@ -270,6 +289,17 @@ int fhe_rq_div_round_dev(uint64_t q, uint64_t s, const void *d_a, void *d_c, siz
 int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, const void *d_a, void *d_out, size_t rows, void *hip_stream);
 
 /* ---- misc ---------------------------------------------------------------- */
+/* ---- multi-device --------------------------------------------------------
+ * The path shards over independent polynomials / products: one
+ * host thread (or process) per device, each calling hipSetDevice() and then the
+ * entry points above on its own block of rows; plans are shared, tables and
+ * workspaces are per device.  fhe_shard_range gives the contiguous block
+ * [*begin, *end) of `total` units owned by `rank` of `world`: ceil(total/world)
+ * units per rank, the last ranks short or empty (630 units over 8 ranks:
+ * 79 x 7 + 77).  No collective is involved; gathering shards, where a consumer
+ * needs them on one device, is the caller's (RCCL all-gather / hipMemcpyPeer). */
+int fhe_shard_range(size_t total, unsigned world, unsigned rank, size_t *begin, size_t *end);
+
 int fhe_ntt_device_count(void);            /* HIP devices visible (0 if none) */
 const char *fhe_last_error(void);          /* thread-local, never NULL */
 const char *fhe_ntt_version(void);

@@ -146,6 +146,17 @@ def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
     assert L.fhe_tr_dot_dev(None, d, d, d, 2, 1, 0, None) == B.FHE_E_NULL
     assert L.fhe_rq_add_dev(plan.handle, None, d, d, 1, None) == B.FHE_E_NULL
     assert L.fhe_mul_div_round_dev(Q16, 8, d, 1, 0, d, 1, None) == B.FHE_E_BAD_Q           # den = 0
+    # Zq::decompose is only defined where beta^l fits u32 and q / beta^l >= 1 (zq.rs:152,164-165), base 2
+    # where l <= 64: outside, the reference panics (overflow / division by zero) — never a launch here
+    assert L.fhe_rq_decompose_dev(Q16, 8, 2, 65, d, d, 1, None) == B.FHE_E_INVALID
+    assert L.fhe_rq_decompose_dev(Q16, 8, 2, 64, None, d, 1, None) == B.FHE_E_NULL              # l = 64 itself is accepted
+    assert L.fhe_rq_decompose_dev(Q61, 8, 16, 9, d, d, 1, None) == B.FHE_E_INVALID              # 16^9 overflows u32
+    assert b"overflows u32" in L.fhe_last_error()
+    assert L.fhe_rq_decompose_dev(Q16, 8, 4, 9, d, d, 1, None) == B.FHE_E_INVALID               # 4^9 > q: divisor 0
+    assert b"divisor" in L.fhe_last_error()
+    assert L.fhe_rq_decompose_dev(Q16, 8, 4, 8, None, d, 1, None) == B.FHE_E_NULL               # 4^8 = 65536 <= q: fine
+    assert L.fhe_glwe_key_switch_dev(plan.handle, 1, 2, 65, d, d, d, 1, 0, None) == B.FHE_E_INVALID
+    assert L.fhe_glwe_key_switch_dev(plan.handle, 1, 4, 9, d, d, d, 1, 0, None) == B.FHE_E_INVALID
     # empty batches are no-ops everywhere
     assert L.fhe_tn_mul_dev(8, None, None, None, 0, None) == 0
     assert L.fhe_bfv_mul_dev(Q16, 16, 2, Q16 * Q16 * Q16, None, None, None, 0, None) == 0
@@ -164,3 +175,32 @@ def test_header_is_plain_c_and_the_c_example_links(pkg, tmp_path):
                            os.path.join(ROOT, "examples", "rq_mul.c"), "-L" + libdir, "-lfhe_ntt",
                            "-Wl,-rpath," + libdir])
     assert os.path.exists(exe)
+
+
+def test_shard_range_of_the_c_abi_is_the_partition_sharding_py_uses(pkg):
+    """fhe_shard_range (host-only): the block partition of SURVEY.md §8e, identical to the Python twin
+    the torch.distributed drivers use; argument errors are codes, not crashes."""
+    import ctypes
+
+    L, B = pkg.load_library(), pkg.binding
+    for total in (0, 1, 7, 8, 630, 65536, 65537):
+        for world in (1, 2, 3, 4, 8):
+            rows = []
+            for r in range(world):
+                b0, b1 = B.shard_range(total, world, r)
+                assert (b0, b1) == pkg.sharding.shard_range(total, world, r)
+                rows += list(range(b0, b1))
+            assert rows == list(range(total))
+    assert [B.shard_range(630, 8, r)[1] - B.shard_range(630, 8, r)[0] for r in range(8)] == [79] * 7 + [77]
+    b, e = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.fhe_shard_range(10, 0, 0, ctypes.byref(b), ctypes.byref(e)) == B.FHE_E_INVALID
+    assert L.fhe_shard_range(10, 2, 2, ctypes.byref(b), ctypes.byref(e)) == B.FHE_E_INVALID
+    assert L.fhe_shard_range(10, 2, 1, None, ctypes.byref(e)) == B.FHE_E_NULL
+
+
+def test_plan_prepare_and_check_switch_need_no_gpu_to_fail_cleanly(pkg):
+    L, B = pkg.load_library(), pkg.binding
+    assert L.fhe_ntt_plan_prepare(None) == B.FHE_E_NULL
+    if B.device_count() == 0:
+        assert L.fhe_ntt_plan_prepare(pkg.Plan(Q16, 8).handle) == B.FHE_E_NO_DEVICE
+    assert L.fhe_ntt_set_check_canonical(1) == 0 and L.fhe_ntt_set_check_canonical(0) == 0

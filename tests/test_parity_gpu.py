@@ -279,30 +279,6 @@ def test_config5_n65536_properties(pkg, oracle):
         assert np.array_equal(A.view(batch, n)[r].cpu().numpy().view(np.uint64), oracle.ntt(q, n, row))
 
 
-def test_experimental_dma_kernels_parity(pkg, oracle):
-    """FHE_NTT_DMA=1 selects the persistent LDS-DMA kernels for the n = 2^16 passes (off by
-    default: measured slower); they must still be bit-exact.  The switch is read
-    once per process, hence the child process."""
-    import os
-    import subprocess
-    import sys
-
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import fhe_study_amd as pkg\n"
-        "from oracle import load_oracle\n"
-        "O = load_oracle(); q, n = pkg.Q61, 65536\n"
-        "for batch in (1, 19):\n"
-        "    a = O.fill_synthetic(q, 5, 0, batch * n)\n"
-        "    A = pkg.Plan(q, n).forward(a)\n"
-        "    assert np.array_equal(A, O.ntt(q, n, a)), batch\n"
-        "    assert np.array_equal(pkg.Plan(q, n).inverse(A), a), batch\n"
-        "print('dma parity ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, FHE_NTT_DMA="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "dma parity ok" in r.stdout, r.stdout + r.stderr
-
-
 def _is_prime(n):
     if n < 2:
         return False

@@ -1,0 +1,234 @@
+"""GPU tests added in round 2: the full-size BASELINE.json configurations, the API holes closed
+(per-stream workspaces, opt-in canonical check, plan preparation) and the multi-rank driver run
+as real processes.  Everything is compared word for word with the CPU oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import Q16, Q61, ROOT
+
+pytestmark = pytest.mark.gpu
+U64 = 1 << 64
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(pkg):
+    assert pkg.binding.device_count() >= 1, "no HIP device: -m gpu tests need a real MI355X"
+
+
+def _u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+# ---- BASELINE.json configs at FULL size ----------------------------------------------------------
+
+def test_config5_full_size_n65536_batch65536(pkg, oracle):
+    """configs[4] on one GPU exactly as bench.py runs it: N = 2^16, q61, 65536 polynomials (32 GiB in,
+    32 GiB out).  Round trip bit-exact over all 2^32 words; forward == oracle on the first 8, last 8 and
+    48 pseudo-random rows; outputs canonical."""
+    import torch
+
+    q, n, batch = Q61, 65536, 65536
+    plan = pkg.Plan(q, n)
+    st = torch.cuda.current_stream().cuda_stream
+    seed = 0xF4E50005
+    x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
+    y = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
+    pkg.binding.fill_synthetic_dev(q, seed, 0, batch * n, x.data_ptr(), st)
+    plan.forward_dev(x.data_ptr(), y.data_ptr(), batch, st)
+    rows = sorted(set(list(range(8)) + list(range(batch - 8, batch)) +
+                      [int(r) for r in np.random.default_rng(7).integers(0, batch, 48)]))
+    Y = y.view(batch, n)
+    for r in rows:
+        a = oracle.fill_synthetic(q, seed, r * n, n)
+        assert np.array_equal(_u64(Y[r]), oracle.ntt(q, n, a)), f"row {r}"
+    # canonical: 0 <= y < q as unsigned words (q < 2^63, so the int64 view is order-preserving)
+    chunk = 1 << 28
+    for i in range(0, batch * n, chunk):
+        part = y[i:i + chunk]
+        assert int(part.min()) >= 0 and int(part.max()) < q
+    plan.inverse_dev(y.data_ptr(), y.data_ptr(), batch, st)        # in place, back to coefficients
+    for i in range(0, batch * n, chunk):
+        assert torch.equal(y[i:i + chunk], x[i:i + chunk]), f"round trip differs in words [{i}, {i + chunk})"
+
+
+def test_config4_630_external_products_sharded_like_8_gpus(pkg, oracle):
+    """configs[3]: 630 TGGSW x TGLWE external products (N=1024, k=1, l=64), block-sharded 79 x 7 + 77 by
+    fhe_shard_range as 8 ranks would; here the 8 shards run one after another on one GPU.  The
+    concatenation equals the unsharded run, and 8 products (first / last of a shard, shard boundaries)
+    equal the oracle's schoolbook."""
+    import torch
+
+    n, k, l, total, world = 1024, 1, 64, 630, 8
+    L, B = pkg.load_library(), pkg.binding
+    rng = np.random.default_rng(44)
+    g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).cuda()
+    c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (total, k + 1, n), dtype=np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    whole = torch.empty_like(c)
+    B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), whole.data_ptr(), total, st))
+    parts, sizes = [], []
+    for r in range(world):
+        b0, b1 = B.shard_range(total, world, r)
+        sizes.append(b1 - b0)
+        out = torch.empty((b1 - b0, k + 1, n), dtype=torch.int64, device="cuda")
+        shard = c[b0:b1].contiguous()
+        B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), shard.data_ptr(), out.data_ptr(), b1 - b0, st))
+        parts.append(out)
+    assert sizes == [79] * 7 + [77]
+    got = torch.cat(parts)
+    assert torch.equal(got, whole)
+    check = [0, 78, 79, 315, 552, 553, 628, 629]
+    want = oracle.external_product(n, k, l, _u64(g), _u64(c[check]))
+    assert np.array_equal(_u64(got[check]), want)
+
+
+def test_config3_bfv_multiply_n8192_batch(pkg, oracle):
+    """configs[2] at the batch bench.py times (256 ciphertext pairs, N = 8192): every pair of the batch is
+    the same function of its inputs (rows permuted in -> rows permuted out), and two pairs equal the
+    oracle's schoolbook tensor + relinearisation word for word."""
+    import torch
+
+    q, n, t, batch = Q16, 8192, 2, 256
+    pq = q * q * q
+    L, B = pkg.load_library(), pkg.binding
+    rng = np.random.default_rng(33)
+    ab = torch.from_numpy(rng.integers(0, q, (4, batch, n), dtype=np.int64)).cuda()
+    rlk = torch.from_numpy(rng.integers(0, pq, (2, n), dtype=np.int64)).cuda()
+    out = torch.empty((2, batch, n), dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    B._check(L.fhe_bfv_mul_dev(q, n, t, pq, rlk.data_ptr(), ab.data_ptr(), out.data_ptr(), batch, st))
+    perm = torch.from_numpy(np.random.default_rng(5).permutation(batch)).cuda()
+    ab2 = ab[:, perm].contiguous()
+    out2 = torch.empty_like(out)
+    B._check(L.fhe_bfv_mul_dev(q, n, t, pq, rlk.data_ptr(), ab2.data_ptr(), out2.data_ptr(), batch, st))
+    assert torch.equal(out2, out[:, perm])
+    a, r = _u64(ab), _u64(rlk)
+    for i in (0, batch - 1):
+        w0, w1 = oracle.bfv_mul(q, n, t, pq, r[0], r[1], a[0, i:i + 1], a[1, i:i + 1], a[2, i:i + 1], a[3, i:i + 1])
+        assert np.array_equal(_u64(out[0, i]), w0[0]) and np.array_equal(_u64(out[1, i]), w1[0])
+
+
+# ---- the reference's round-trip loop with fresh randomness ------------------------------------------
+
+def test_intt_ntt_identity_1000_fresh_polynomials_n512(pkg):
+    """arith/src/ntt.rs:217-234 draws 1000 polynomials from an UNSEEDED generator; restated with
+    fresh entropy on every run (the seed is printed on failure), through the HIP path."""
+    seed = int.from_bytes(os.urandom(8), "little")
+    rng = np.random.default_rng(seed)
+    plan = pkg.Plan(Q16, 512)
+    for _ in range(4):                                   # 4 x 250 = 1000, as separate calls
+        a = rng.integers(0, Q16, size=(250, 512), dtype=np.uint64)
+        assert np.array_equal(plan.inverse(plan.forward(a)).reshape(a.shape), a), f"seed {seed}"
+
+
+# ---- API holes -----------------------------------------------------------------------------------------
+
+def test_two_streams_share_no_workspace(pkg, oracle):
+    """*_dev entry points that use the library workspace, issued on two streams with no
+    synchronisation between them: each stream has its own workspace, so both results are exact.
+    (Round 1 kept one buffer per device: this test then fails with silently wrong words.)"""
+    import torch
+
+    L, B = pkg.load_library(), pkg.binding
+    q, n, batch = Q61, 16384, 24                          # two-pass size: fhe_rq_mul_dev needs scratch
+    plan = pkg.Plan(q, n)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ops = []
+    for i, s in enumerate((s1, s2)):
+        a = oracle.fill_synthetic(q, 100 + i, 0, batch * n)
+        b = oracle.fill_synthetic(q, 200 + i, 0, batch * n)
+        da = torch.from_numpy(a.view(np.int64).copy()).cuda()
+        db = torch.from_numpy(b.view(np.int64).copy()).cuda()
+        ops.append((s, da, db, torch.empty_like(da), oracle.rq_mul(q, n, a, b)[0]))
+    # external products on the same two streams, interleaved with the ring products
+    nn, k, l, eb = 1024, 1, 64, 16
+    rng = np.random.default_rng(9)
+    g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, nn), dtype=np.int64)).cuda()
+    ext = []
+    for i, s in enumerate((s1, s2)):
+        c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (eb, k + 1, nn), dtype=np.int64)).cuda()
+        ext.append((s, c, torch.empty_like(c), oracle.external_product(nn, k, l, _u64(g), _u64(c))))
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for (s, da, db, dc, _), (_, c, eo, _) in zip(ops, ext):
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, stream=s.cuda_stream)
+            B._check(L.fhe_tggsw_external_product_dev(nn, k, l, g.data_ptr(), c.data_ptr(), eo.data_ptr(), eb, s.cuda_stream))
+    torch.cuda.synchronize()
+    for (_, _, _, dc, want), (_, _, eo, ewant) in zip(ops, ext):
+        assert np.array_equal(_u64(dc), want)
+        assert np.array_equal(_u64(eo), ewant)
+
+
+def test_opt_in_canonical_check_rejects_what_the_reference_cannot_construct(pkg, oracle):
+    """FHE_NTT_CHECK_CANONICAL (here through fhe_ntt_set_check_canonical): a value >= q handed to a
+    transform comes back as FHE_E_NOT_CANONICAL; canonical inputs are unaffected; switched off
+    (the default) the call returns FHE_OK as before."""
+    B = pkg.binding
+    q, n = Q61, 4096
+    plan = pkg.Plan(q, n)
+    good = oracle.fill_synthetic(q, 1, 0, 3 * n)
+    bad = good.copy()
+    bad[2 * n + 17] = q                                    # the smallest non-canonical value
+    B.set_check_canonical(True)
+    try:
+        assert np.array_equal(plan.forward(good), oracle.ntt(q, n, good))
+        for call in (lambda: plan.forward(bad), lambda: plan.inverse(bad), lambda: plan.rq_mul(good, bad),
+                     lambda: plan.rq_mul(bad, good), lambda: plan.pointwise_mul(bad, good)):
+            with pytest.raises(pkg.FheError) as ei:
+                call()
+            assert ei.value.code == B.FHE_E_NOT_CANONICAL
+    finally:
+        B.set_check_canonical(False)
+    plan.forward(bad)                                      # undefined words, but FHE_OK: the documented default
+    assert np.array_equal(plan.forward(good), oracle.ntt(q, n, good))
+
+
+def test_plan_prepare_makes_the_first_transform_capturable(pkg, oracle):
+    """fhe_ntt_plan_prepare uploads the tables ahead of time, so the very first transform of a plan
+    can already sit inside a stream capture (no allocation, copy or synchronisation in it)."""
+    import torch
+
+    L = pkg.load_library()
+    q, n, batch = 12289, 2048, 4                            # a plan no other test creates
+    plan = pkg.Plan(q, n)
+    pkg.binding._check(L.fhe_ntt_plan_prepare(plan.handle))
+    a = oracle.fill_synthetic(q, 77, 0, batch * n)
+    da = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    out = torch.empty_like(da)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.forward_dev(da.data_ptr(), out.data_ptr(), batch, torch.cuda.current_stream().cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(_u64(out), oracle.ntt(q, n, a))
+
+
+# ---- the multi-rank driver, run as real processes ---------------------------------------------------------
+
+def test_bench_two_ranks_on_one_gpu(pkg, oracle, tmp_path):
+    """bench.py under torch.distributed.run with two ranks sharing cuda:0 (gloo for the
+    rendezvous/barriers, as a 1-GPU box allows): exercises process-group setup, the barrier + MAX
+    timing, rank-offset input generation and the parity leg of BOTH ranks; n_gpus must read 2."""
+    from test_sharding_gloo import _free_port
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--share-gpu", "--backend", "gloo", "--batch-per-gpu", "256", "--no-cpu-baseline",
+           "--parity-all-ranks", "--gather-check"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 512
+    assert out["parity"]["mismatching_rows"] == 0
+    assert out["parity"]["ranks_checked"] == 2
+    assert out["gather_check"]["equal_to_single_rank_transform"] is True

@@ -14,8 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")  # env: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "ntt_kernels.hip", "zring.hip", "glue.hip"]
-HEADERS = ["ntt_kernels.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp",
+SOURCES = ["capi.hip", "ntt_kernels.hip", "digit_mac.hip", "zring.hip", "glue.hip"]
+HEADERS = ["ntt_kernels.hpp", "ntt_rounds.hpp", "digit_mac.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp",
            os.path.join("..", "..", "include", "fhe_ntt.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
 # -ffp-contract=off: zring.hip restates the reference's f64 scale-and-round (one IEEE rounding
@@ -47,6 +47,7 @@ EXPORTS = [
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
     "fhe_ntt_plan_prepare", "fhe_ntt_set_check_canonical", "fhe_shard_range",
+    "fhe_tggsw_prepared_words", "fhe_tggsw_prepare_dev", "fhe_tggsw_external_product_prepared_dev",
     # next rows: exact products over Z / mod 2^64 on top of the engine
     "fhe_r_naive_mul", "fhe_r_naive_mul_dev", "fhe_mul_div_round_dev",
     "fhe_bfv_tensor", "fhe_bfv_tensor_dev", "fhe_bfv_relinearize_dev", "fhe_bfv_mul", "fhe_bfv_mul_dev",
@@ -183,6 +184,10 @@ def load_library():
     L.fhe_tn_mul_dev.argtypes = [_u64, _vp, _vp, _vp, _sz, _vp]
     L.fhe_tggsw_external_product.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz]
     L.fhe_tggsw_external_product_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_tggsw_prepared_words.argtypes = [_u64, _uint, _uint]
+    L.fhe_tggsw_prepared_words.restype = _sz
+    L.fhe_tggsw_prepare_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp]
+    L.fhe_tggsw_external_product_prepared_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
     L.fhe_tr_dot_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
     L.fhe_tr_mul_r_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
     L.fhe_glev_mul_dev.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]

@@ -607,24 +607,40 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
         if (rc != FHE_OK) return rc;
         work = (u64 *)w;
     }
-    // A = NTT(a): the operand's cached evals if it has them (ring_nq.rs:590-594)
+    // an operand that already is evals keeps them as they are (ring_nq.rs:590-599); a copy if the caller
+    // wants them in a second place
+    if (a_is_evals && d_a_evals_out && d_a_evals_out != d_a)
+        HIP_TRY(hipMemcpyAsync(d_a_evals_out, d_a, bytes, hipMemcpyDeviceToDevice, st));
+    if (b_is_evals && d_b_evals_out && d_b_evals_out != d_b)
+        HIP_TRY(hipMemcpyAsync(d_b_evals_out, d_b, bytes, hipMemcpyDeviceToDevice, st));
+
+    // two-pass sizes: strided(a) | strided(b) in one launch, one middle kernel (both contiguous forward
+    // passes, the pointwise product, the contiguous inverse pass), strided inverse.  The product must not
+    // overwrite an operand's evals the middle kernel still has to read: c aliasing an evals INPUT is the
+    // one case that takes the unfused chain below.  FHE_RQ_MUL_FUSED=0 selects that chain too.
+    u64 *wa = d_a_evals_out ? (u64 *)d_a_evals_out : work;
+    u64 *wb = d_b_evals_out ? (u64 *)d_b_evals_out : (work ? work + elems : nullptr);
+    const bool c_aliases_evals_in = (a_is_evals && d_c == d_a) || (b_is_evals && d_c == d_b);
+    if (fused_on && !c_aliases_evals_in) {
+        hipError_t fe = fhe::launch_rq_mul_two_pass(dp, (const u64 *)d_a, a_is_evals != 0, (const u64 *)d_b, b_is_evals != 0,
+                                                    (u64 *)d_c, (u64 *)d_c_evals, wa, d_a_evals_out != nullptr, wb,
+                                                    d_b_evals_out != nullptr, batch, tile, st);
+        if (fe == hipSuccess) return FHE_OK;
+        if (fe != hipErrorNotSupported) return hip_fail(fe, "launch_rq_mul_two_pass");
+        (void)hipGetLastError();
+    }
+    // A = NTT(a): the operand's cached evals if it has them
     const u64 *A = (const u64 *)d_a;
     if (!a_is_evals) {
-        u64 *dst = d_a_evals_out ? (u64 *)d_a_evals_out : work;
-        hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_a, dst, batch, tile, st);
+        hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_a, wa, batch, tile, st);
         if (e != hipSuccess) return hip_fail(e, "forward(a)");
-        A = dst;
-    } else if (d_a_evals_out && d_a_evals_out != d_a) {
-        HIP_TRY(hipMemcpyAsync(d_a_evals_out, d_a, bytes, hipMemcpyDeviceToDevice, st));
+        A = wa;
     }
     const u64 *B = (const u64 *)d_b;
     if (!b_is_evals) {
-        u64 *dst = d_b_evals_out ? (u64 *)d_b_evals_out : work + elems;
-        hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_b, dst, batch, tile, st);
+        hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_b, wb, batch, tile, st);
         if (e != hipSuccess) return hip_fail(e, "forward(b)");
-        B = dst;
-    } else if (d_b_evals_out && d_b_evals_out != d_b) {
-        HIP_TRY(hipMemcpyAsync(d_b_evals_out, d_b, bytes, hipMemcpyDeviceToDevice, st));
+        B = wb;
     }
     // c = intt(A .* B), C = A .* B optionally kept (ring_nq.rs:601-606)
     hipError_t e = fhe::launch_ntt_inverse(dp, A, B, (u64 *)d_c_evals, (u64 *)d_c, batch, tile, st);

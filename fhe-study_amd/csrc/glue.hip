@@ -16,7 +16,10 @@
 // forward transforms, one multiply-accumulate pass and ONE inverse per output polynomial.
 #include <vector>
 
+#include <cstdlib>
+
 #include "capi_internal.hpp"
+#include "digit_mac.hpp"
 #include "zq_device.hpp"
 #include "mac_kernel.hpp"
 
@@ -384,6 +387,28 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     const u64 n = plan->n;
     const u32 k1 = k + 1, T = k * l;
     void *w = nullptr;
+    // Base 2 at 2^8 <= n <= 2^12: decomposition, digit transforms and the multiply-accumulate against the
+    // key are ONE kernel (digit_mac.hip): RHS[b][c] = sum_t KSK[t][c] (.) NTT(digit_t(b)), nothing else stored.
+    static const bool fused_on = [] { const char *e = getenv("FHE_DIGIT_MAC_FUSED"); return !(e && e[0] == '0'); }();
+    if (beta == 2 && fused_on && dp.wide && dp.log_n >= 8 && dp.log_n <= 12 && (k1 == 2 || k1 == 3) && k1 * (n / 256) <= 32) {
+        const u32 parts = fhe::digit_mac_parts(batch, T, dp.log_n);
+        // [key transforms: T*k1 rows] [rhs: batch*k1 rows] [partial sums: parts*batch*k1 rows]
+        if ((rc = fhe_workspace_get(1, ((u64)T * k1 + (u64)(parts + 1) * batch * k1) * n * 8, st, &w)) != FHE_OK) return rc;
+        u64 *KEY = (u64 *)w, *RHS = KEY + (u64)T * k1 * n, *PART = parts > 1 ? RHS + batch * k1 * n : RHS;
+        const u64 *key = (const u64 *)d_ksk;
+        if (!(flags & FHE_A_IS_EVALS)) { if ((rc = fwd(plan, dp, key, KEY, (u64)T * k1, st)) != FHE_OK) return rc; key = KEY; }
+        hipError_t e = fhe::launch_digit_mac(dp, fhe::SRC_ZQBITS, (const u64 *)d_glwe, (u64)k1 * n, k, l, key, k1, PART, parts, batch, st);
+        if (e == hipSuccess) {
+            if (parts > 1 && (e = fhe::launch_sum_parts(PART, RHS, batch, parts, (u64)k1 * n, plan->q, st)) != hipSuccess)
+                return fhe_hip_fail(e, "sum_parts_kernel");
+            if ((rc = inv(plan, dp, RHS, RHS, batch * k1, st)) != FHE_OK) return rc;
+            hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(fhe_ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
+            LAUNCH_OK("ks_tail_kernel");
+            return FHE_OK;
+        }
+        if (e != hipErrorNotSupported) return fhe_hip_fail(e, "digit_mac_kernel");
+        (void)hipGetLastError();
+    }
     // [decomposition: batch*k*l rows] [rhs: batch*k1 rows] [keyed_mac scratch: T*k1 + batch*T rows]
     if ((rc = fhe_workspace_get(1, (batch * T + batch * k1 + (u64)T * k1 + batch * T) * n * 8, st, &w)) != FHE_OK) return rc;
     u64 *DEC = (u64 *)w, *RHS = DEC + batch * T * n, *WS = RHS + batch * k1 * n;

@@ -22,289 +22,11 @@
 //   A round holds field bits [a, a+4) in registers (k = those 4 bits) and runs
 //   the stages for bits a+3, a+2, ... ; with H = f >> (a+4) the index of stage i
 //   of the round is (T0 << i) + (k >> (4-i)),  T0 = (1<<(s0+ls0)) + (blk<<ls0) + H.
-#include <type_traits>
-
-#include "ntt_kernels.hpp"
-#include "zq_device.hpp"
+#include "ntt_rounds.hpp"
 
 #include <cstdlib>
 
 namespace fhe {
-
-// ---------------------------------------------------------------------------
-// one round: R stages on the 16 register-resident coefficients
-// ---------------------------------------------------------------------------
-// Lazy ranges of the forward rounds:
-//   WIDE (q < 2^61, 8q < 2^64): values are tracked as multiples of q at compile time.  A stage
-//   takes x < B*q to x' = u + t, y' = u - t + 2q < (B+2)*q, so it needs B <= 6; when B > 6 the
-//   stage first subtracts 4q from x >= 4q (B <= 8 -> 4).  BIN is the bound of the round's inputs
-//   (2 for the first round of a transform — canonical inputs, with slack —, 6 after a round),
-//   fwd_bound_out the bound of its outputs: one conditional subtraction per TWO butterflies in
-//   steady state, one per FOUR in a first round.  TIGHT_LAST: the round's last stage brings x
-//   below 2q first, so the outputs are below 4q (cheaper to canonicalise than < 6q or < 8q).
-//   END6: the round's last stage also corrects when its inputs exceed 4q, so the round (the last
-//   of a strided pass) ends below 6q whatever its length — the bound the next pass starts from.
-//   otherwise (q < 2^62): Harvey's [0,4q) with a 2q correction in every butterfly.
-constexpr int fwd_stage_needs_csub(int bound_in) { return bound_in > 6; }
-constexpr int fwd_bound_out(int R, int bin) {
-    int b = bin;
-    for (int i = 0; i < R; i++) b = (fwd_stage_needs_csub(b) ? 4 : b) + 2;
-    return b;
-}
-constexpr int kPassBound = 6;   // bound (in q) of what a forward strided pass hands to the contiguous pass
-template <int R, bool WIDE, int BIN = 6, bool TIGHT_LAST = false, bool END6 = false>
-__device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
-                                          const Mod &m) {
-    static_assert(BIN >= 1 && BIN <= 8, "input bound out of range");
-#pragma unroll
-    for (int i = 0; i < R; i++) {
-        const int span = 8 >> i;
-        constexpr int kNone = 0;
-        const int bin_i = fwd_bound_out(i, BIN);                 // bound of this stage's inputs
-        const bool corr = fwd_stage_needs_csub(bin_i) || (END6 && i == R - 1 && bin_i > 4);
-        const bool tight = TIGHT_LAST && i == R - 1;             // bring x below 2q: x' and y' < 4q
-#ifdef FHE_ABLATE_NO_BUTTERFLIES   // timing-only build: memory pattern without the arithmetic
-        if (i >= 0) continue;
-#endif
-#pragma unroll
-        for (int g = 0; g < (1 << i); g++) {
-            const Tw t = tw[(T0 << i) + g];
-#pragma unroll
-            for (int l = 0; l < span; l++) {
-                const int k = g * 2 * span + l;
-                if (!WIDE) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
-                else if (tight && bin_i > 4) ct_bfly<6>(v[k], v[k + span], t.w, t.wp, m);
-                else if (tight && bin_i > 2) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
-                else if (tight) ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
-                else if (corr) ct_bfly<4>(v[k], v[k + span], t.w, t.wp, m);
-                else ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
-            }
-        }
-    }
-}
-
-// FOLD: this round contains the transform's last GS stage (m = 1, ntt.rs:85 loop
-// exit) and the n^-1 scaling of ntt.rs:100-102 is folded into it:
-//   r[j] = (U+V)*n_inv,  r[j+t] = (U-V)*(roots_inv[1]*n_inv).
-template <int R, bool FOLD>
-__device__ __forceinline__ void round_inv(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
-                                          const Mod &m, const Tw ninv, const Tw s_ninv) {
-#pragma unroll
-    for (int i = R - 1; i >= 0; i--) {
-        const int span = 8 >> i;
-#pragma unroll
-        for (int g = 0; g < (1 << i); g++) {
-            if (FOLD && i == 0) {
-#pragma unroll
-                for (int l = 0; l < span; l++) {
-                    const int k = g * 2 * span + l;
-                    const u64 s = add64(v[k], v[k + span]);                    // < 4q, fine for Shoup
-                    const u64 d = add64(add64(v[k], m.q2p1), ~v[k + span]);    // x - y + 2q
-                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, m);
-                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, m);
-                }
-            } else {
-                const Tw t = tw[(T0 << i) + g];
-#pragma unroll
-                for (int l = 0; l < span; l++) {
-                    const int k = g * 2 * span + l;
-                    gs_bfly(v[k], v[k + span], t.w, t.wp, m);
-                }
-            }
-        }
-    }
-}
-
-// ---- inverse rounds for q < 2^61 (8q < 2^64): per-register value bounds -----------------------
-// A Gentleman-Sande butterfly only needs x + y < 2^64 and x - y + K*q > 0: with bounds (in q) bx, by
-// of its inputs, bx + by <= 8 is enough, the sum leaves with bound bx + by and the product with 2.
-// So instead of one conditional subtraction per butterfly the round follows the bounds of its 16
-// registers at compile time and subtracts 4q only where a pair would exceed 8: 12 instead of 32
-// per round from canonical inputs, 20 instead of 32 in steady state.  A round starts from a uniform
-// bound BIN (after the LDS transpose a register may come from any register of another thread) and
-// ends by bringing every register below BOUT*q.
-struct InvSched {
-    unsigned char cx[4][8];   // stage (in execution order), butterfly: x -= 4q if x >= 4q first
-    unsigned char cy[4][8];   // same for y
-    unsigned char ky[4][8];   // bound of y entering the subtraction: d = x - y + ky*q
-    unsigned char fin[16];    // register: final conditional subtraction of 4q
-};
-constexpr InvSched inv_sched(int R, int bin, bool fold, int bout) {
-    InvSched s{};
-    int B[16] = {};
-    for (int k = 0; k < 16; k++) B[k] = bin;
-    int st = 0;
-    for (int i = R - 1; i >= 0; i--, st++) {
-        const int span = 8 >> i;
-        int j = 0;
-        for (int g = 0; g < (1 << i); g++)
-            for (int l = 0; l < span; l++, j++) {
-                const int k = g * 2 * span + l, k2 = k + span;
-                int bx = B[k], by = B[k2];
-                bool cx = false, cy = false;
-                if (bx + by > 8) {
-                    if (bx >= by) { cx = true; bx = bx > 4 ? 4 : bx; }
-                    else { cy = true; by = by > 4 ? 4 : by; }
-                }
-                if (bx + by > 8) {
-                    if (!cx) { cx = true; bx = bx > 4 ? 4 : bx; }
-                    else { cy = true; by = by > 4 ? 4 : by; }
-                }
-                s.cx[st][j] = cx;
-                s.cy[st][j] = cy;
-                s.ky[st][j] = (unsigned char)by;
-                B[k] = (fold && i == 0) ? 2 : bx + by;
-                B[k2] = 2;
-            }
-    }
-    for (int k = 0; k < 16; k++) s.fin[k] = B[k] > bout;
-    return s;
-}
-
-template <int R, bool FOLD, int BIN, int BOUT>
-__device__ __forceinline__ void round_inv_w(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
-                                            const Tw ninv, const Tw s_ninv) {
-    static_assert(BIN == 2 || BIN == 4, "rounds start from canonical (2) or normalised (4) inputs");
-    static_assert(BOUT == 4, "rounds end below 4q");
-    constexpr InvSched S = inv_sched(R, BIN, FOLD, BOUT);
-    const u64 q4 = 0ull - m.neg4q;
-    const u64 K[5] = {0ull, m.q2p1, q4 + 1ull, q4 + m.q2p1, 2ull * q4 + 1ull};   // (2j)*q + 1
-    int st = 0;
-#pragma unroll
-    for (int i = R - 1; i >= 0; i--, st++) {
-        const int span = 8 >> i;
-#pragma unroll
-        for (int g = 0; g < (1 << i); g++) {
-            Tw t{};
-            if (!(FOLD && i == 0)) t = tw[(T0 << i) + g];
-#pragma unroll
-            for (int l = 0; l < span; l++) {
-                const int k = g * 2 * span + l, j = g * span + l;
-                u64 x = v[k], y = v[k + span];
-                if (S.cx[st][j]) x = csub_neg(x, m.neg4q);
-                if (S.cy[st][j]) y = csub_neg(y, m.neg4q);
-                const u64 d = add64(add64(x, K[S.ky[st][j] / 2]), ~y);        // x - y + ky*q  in (0, 8q)
-                const u64 s = add64(x, y);                                      // < 8q
-                if (FOLD && i == 0) {
-                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, m);
-                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, m);
-                } else {
-                    v[k] = s;
-                    v[k + span] = mul_shoup_acc(0, d, t.w, t.wp, m.nq);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (S.fin[k]) v[k] = csub_neg(v[k], m.neg4q);
-}
-
-// WIDE: the bound-tracking rounds above (values below 4q between rounds); otherwise [0,2q) throughout
-template <int R, bool FOLD, bool WIDE, int BIN>
-__device__ __forceinline__ void round_inv_sel(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
-                                              const Tw ninv, const Tw s_ninv) {
-    if constexpr (WIDE) round_inv_w<R, FOLD, BIN, 4>(v, tw, T0, m, ninv, s_ninv);
-    else round_inv<R, FOLD>(v, tw, T0, m, ninv, s_ninv);
-}
-
-// field value of register k for a thread whose non-register field bits are tf,
-// register window = field bits [A, A+4)
-template <int A>
-__device__ __forceinline__ u32 field_of(u32 tf, int k) {
-    const u32 lo = tf & ((1u << A) - 1u);
-    const u32 hi = tf >> A;
-    return (hi << (A + 4)) | ((u32)k << A) | lo;
-}
-
-// LDS slot of tile element e in the contiguous kernels: one 8-byte pad every 16
-// elements so that the a=0 window (lane stride 16 elements) is conflict-free.
-__device__ __forceinline__ u32 pad16(u32 e) { return e + (e >> 4); }
-
-// stage a pass-local twiddle table into LDS: local index li in [1, M): ls = floor(log2 li),
-// global index (1 << (s0+ls)) + (blk << ls) + (li - 2^ls); the rounds then index it with
-// T0 = (1 << ls0) + H, i.e. as if the pass were a transform of its own.
-template <int M, int TH>
-__device__ __forceinline__ void stage_twiddles(Tw *ltw, const Tw *__restrict__ tw, u32 s0, u32 blk,
-                                               u32 tid) {
-    for (u32 li = tid; li < (u32)M; li += TH) {
-        const u32 ls = 31u - (u32)__builtin_clz(li | 1u);   // entry 0 is never used: copy tw[.] of li = 1
-        const u32 l1 = li | (li == 0);
-        ltw[li] = tw[(1u << (s0 + ls)) + (blk << ls) + (l1 - (1u << ls))];
-    }
-}
-
-// Global access as (wave-uniform 64-bit base) + (32-bit per-lane BYTE offset): the form the
-// saddr/voffset addressing mode takes, so an access costs one v_add_u32, not 64-bit arithmetic.
-// Coefficient data is touched once per pass, so accesses in which a wave instruction covers whole
-// cache lines carry the non-temporal hint (plain copy: 5.41 -> 5.71 TB/s with it,
-// tools/ubench_mem.hip; forward 2^16 transform 7.40 -> 7.25 ms).  The inverse contiguous pass reads
-// and writes a line in pieces spread over several instructions and needs the cache to merge them:
-// with the hint it ran 3.69 -> 5.5 ms, so it uses the plain forms (ld_c / st_c).
-typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-template <typename T>
-__device__ __forceinline__ T ld_at(const u64 *ubase, u32 byte_off);
-template <>
-__device__ __forceinline__ u64 ld_at<u64>(const u64 *ubase, u32 byte_off) {
-    return __builtin_nontemporal_load(
-        reinterpret_cast<const u64 *>(reinterpret_cast<const unsigned char *>(ubase) + byte_off));
-}
-__device__ __forceinline__ void st_at(u64 *ubase, u32 byte_off, u64 x) {
-    __builtin_nontemporal_store(x, reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ubase) + byte_off));
-}
-template <typename T>
-__device__ __forceinline__ T ld_c(const u64 *ubase, u32 byte_off) {
-    return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(ubase) + byte_off);
-}
-template <typename T>
-__device__ __forceinline__ void st_c(u64 *ubase, u32 byte_off, T x) {
-    *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ubase) + byte_off) = x;
-}
-
-// ---------------------------------------------------------------------------
-// CONTIGUOUS pass: blocks of M = 2^LP consecutive coefficients.
-// Workgroup = W units (unit = one M-block of one polynomial, all W units share
-// `blk`, hence the twiddles), TPB = M/16 threads per unit.
-// ---------------------------------------------------------------------------
-template <int LP>
-struct ContigCfg {
-    static constexpr int M = 1 << LP;
-    static constexpr int TPB = M / 16;
-    static constexpr int TH = (LP <= 12) ? 256 : 512;
-    static constexpr int W = TH / TPB;
-    static constexpr int TILE = W * M;  // = 16 * TH
-    static constexpr int NR = (LP + 3) / 4;
-    static constexpr int R0 = LP - 4 * (NR - 1);
-    static constexpr int A0 = LP - 4;  // register window of round 0 = top 4 field bits
-    // The first 2^LTW_LOG entries of the pass-local twiddle table (all W units share `blk`) are
-    // staged into LDS once per workgroup: a round whose stages all lie below local stage
-    // LTW_LOG reads them with ds_read_b128 instead of 15 global loads through L1.  Later rounds
-    // (LP > 8: per-thread-unique twiddles, up to 64 KiB per block) stay on the global table.
-    static constexpr int LTW_LOG = LP < 8 ? LP : 8;
-    static constexpr int LTW_N = 1 << LTW_LOG;
-    static constexpr size_t DATA_BYTES = (size_t)(TILE + TILE / 16) * 8;
-    static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)LTW_N * sizeof(Tw);
-    // window base of round j >= 1
-    static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
-    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
-    static constexpr bool in_lds(int j) { return ls0_of(j) + (j == 0 ? R0 : 4) <= LTW_LOG; }
-};
-
-// scatter registers (window AF) -> barrier -> gather registers (window AT).
-// FIRST = false: the tile was read by an earlier exchange, so a barrier precedes the scatter.
-// No trailing barrier: whoever writes the tile next either is this function (FIRST = false)
-// or writes exactly the slots it has just gathered (the store transpose of the forward pass).
-template <int LP, int AF, int AT, bool FIRST>
-__device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u32 tf) {
-    constexpr int M = 1 << LP;
-    if (!FIRST) __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; k++) lds[pad16(w * M + field_of<AF>(tf, k))] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
-}
-
 // SRC_DIGITS (single-pass sizes only): the input is `batch / digit_l` rows of 64-bit words and
 // output polynomial p is the transform of bit digit_l-1-(p % digit_l) of row p / digit_l — the
 // gadget decomposition of ring_torus.rs:67-77 / torus.rs:43-52 done in the load, so the 0/1
@@ -331,11 +53,6 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     const u32 off = ((w < live ? w : 0u) << a.log_n) * 8u;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
-    // twiddle source and index of round j (local stage ls0, high field bits H)
-    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : a.tw; };
-    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
-        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
-    };
 
     u64 v[16];
     if constexpr (SRC == SRC_DIGITS) {
@@ -382,28 +99,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     // needed from round 1 on, so the barrier of the first exchange also publishes it.
     stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, s0, blk, tid);
 
-    // bounds (in q) entering each round; inputs are canonical or come from a strided pass (< 6q).
-    // The transform's very last stage (FINAL) brings x below 2q: outputs < 4q.
-    constexpr int B0 = kPassBound, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1), B3 = fwd_bound_out(4, B2);
-    round_fwd<C::R0, WIDE, B0, FINAL && C::NR == 1>(v, a.tw, (1u << s0) + blk, m);
-    if constexpr (C::NR > 1) {
-        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        constexpr bool L = C::in_lds(1);
-        exchange_contig<LP, C::A0, A, true>(v, lds, w, tf);
-        round_fwd<4, WIDE, B1, FINAL && C::NR == 2>(v, TW(L), T0(L, LS, tf >> A), m);
-    }
-    if constexpr (C::NR > 2) {
-        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        constexpr bool L = C::in_lds(2);
-        exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE, B2, FINAL && C::NR == 3>(v, TW(L), T0(L, LS, tf >> A), m);
-    }
-    if constexpr (C::NR > 3) {
-        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
-        constexpr bool L = C::in_lds(3);
-        exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
-        round_fwd<4, WIDE, B3, FINAL && C::NR == 4>(v, TW(L), T0(L, LS, tf >> A), m);
-    }
+    fwd_rounds_contig<LP, WIDE, FINAL, kPassBound, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
     // transpose through LDS so the store is one contiguous slab per wave.  (Storing the 128
     // contiguous bytes a thread owns after the last round as 8 x 16 B straight from registers
     // was measured slower for the forward kernel: 4.91 ms vs 4.40 ms per 16384 polynomials;
@@ -443,10 +139,6 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     u64 *__restrict__ pout = a.out + ubase;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
-    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : a.tw; };
-    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
-        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
-    };
     stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, s0, blk, tid);  // published by the barrier below
 
     // first window = field bits [0,4): a thread's 16 coefficients are 128 contiguous bytes,
@@ -480,29 +172,8 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     }
 
     __syncthreads();
-    // inputs are canonical (evals, or their product): the first round that runs starts from bound 2,
-    // later ones from the normalised 4 (WIDE); a non-FINAL pass hands values below 4q (WIDE) / 2q on
-    constexpr int BF = 2, BN = 4;
-    if constexpr (C::NR > 3) {
-        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
-        constexpr bool L = C::in_lds(3);
-        round_inv_sel<4, false, WIDE, BF>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
-        exchange_contig<LP, A, C::a_of(2), true>(v, lds, w, tf);
-    }
-    if constexpr (C::NR > 2) {
-        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        constexpr bool L = C::in_lds(2);
-        round_inv_sel<4, false, WIDE, (C::NR == 3 ? BF : BN)>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
-        exchange_contig<LP, A, C::a_of(1), (C::NR <= 3)>(v, lds, w, tf);
-    }
-    if constexpr (C::NR > 1) {
-        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        constexpr bool L = C::in_lds(1);
-        round_inv_sel<4, false, WIDE, (C::NR == 2 ? BF : BN)>(v, TW(L), T0(L, LS, tf >> A), m, a.ninv, a.s_ninv);
-        exchange_contig<LP, A, C::A0, (C::NR <= 2)>(v, lds, w, tf);
-    }
-    // FINAL implies s0 == 0 (this pass holds the m = 1 stage)
-    round_inv_sel<C::R0, FINAL, WIDE, (C::NR == 1 ? BF : BN)>(v, TW(C::in_lds(0)), T0(C::in_lds(0), 0, 0), m, a.ninv, a.s_ninv);
+    // inputs are canonical (evals, or their product); a non-FINAL pass hands values below 4q (WIDE) / 2q on
+    inv_rounds_contig<LP, WIDE, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
 
     if (active) {
 #pragma unroll
@@ -629,6 +300,83 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
 }
 
 // ---------------------------------------------------------------------------
+// MIDDLE of the product at two-pass sizes (n >= 2^14).  ring_nq.rs:586-607 as passes over HBM is
+//   strided(a) -> contiguous(a) | strided(b) -> contiguous(b) | [A .* B -> contiguous^-1] -> strided^-1.
+// The forward's contiguous pass and the inverse's first pass act on the SAME 2^LP-coefficient blocks
+// (block `blk` of a polynomial), so the three middle passes are one kernel here: a block of each
+// operand comes in from its strided pass (lazy, < 6q), runs its LP forward stages in registers / LDS,
+// the pointwise product is formed in registers (zip_eq(l,r).map(l*r), ring_nq.rs:601-604) and runs the
+// LP inverse stages; what leaves is what ntt_inv_contig_kernel would have written (lazy, < 4q / 2q),
+// for the strided inverse pass to finish.  HBM traffic of a product: 104n -> 72n bytes (+8n per
+// evals output kept).  An operand flagged as evals (flags bit 0 / 1) is read as such: 16 consecutive
+// canonical values per thread, no forward stages.  out2 / out3 / out4: the evals of the product and
+// of the two operands (ring_nq.rs:568-573,606), optional.
+// ---------------------------------------------------------------------------
+template <int LP, bool WIDE>
+__global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    Tw *ltw_f = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    Tw *ltw_i = ltw_f + C::LTW_N;
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u32 s0 = a.log_n - LP;
+    const u32 blk = blockIdx.x & ((1u << s0) - 1u);
+    const u64 pg = (u64)(blockIdx.x >> s0);
+    const u64 n = 1ull << a.log_n;
+    const u32 live = (u32)min((u64)C::W, a.batch - pg * C::W);
+    const bool active = w < live;
+    const u64 ubase = pg * C::W * n + (u64)blk * C::M;
+    const u32 off = ((active ? w : 0u) << a.log_n) * 8u;
+    const Mod &m = a.mod;
+    stage_twiddles<C::LTW_N, C::TH>(ltw_f, a.tw, s0, blk, tid);       // both published by the barrier(s)
+    stage_twiddles<C::LTW_N, C::TH>(ltw_i, a.tw_inv, s0, blk, tid);   // that precede their first LDS use
+    static_assert(C::NR >= 2, "two-pass sizes have LP >= 8");
+
+    auto operand = [&](const u64 *__restrict__ src, bool is_evals, u64 (&v)[16], auto fresh) {
+        const u64 *__restrict__ p = src + ubase;
+        if (is_evals) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const ulonglong2 x = ld_c<ulonglong2>(p, off + tf * 128u + j * 16u);
+                v[2 * j] = x.x;
+                v[2 * j + 1] = x.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
+            fwd_rounds_contig<LP, WIDE, true, kPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = canon4(v[k], m);   // the last stage left x', y' < 4q
+        }
+    };
+    auto store_evals = [&](u64 *dst, const u64 (&v)[16]) {
+        if (!dst || !active) return;
+        u64 *__restrict__ p = dst + ubase;
+#pragma unroll
+        for (int j = 0; j < 8; j++) st_c<ulonglong2>(p, off + tf * 128u + j * 16u, ulonglong2{v[2 * j], v[2 * j + 1]});
+    };
+
+    u64 va[16], vb[16];
+    operand(a.in, a.flags & 1u, va, std::true_type{});
+    store_evals(a.out3, va);
+    operand(a.in2, a.flags & 2u, vb, std::false_type{});   // the tile may have been used by the first operand
+    store_evals(a.out4, vb);
+#pragma unroll
+    for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
+    store_evals(a.out2, va);
+    // the inverse rounds' first exchange follows a forward exchange's gather unless both operands were
+    // evals; its leading barrier (FRESH = false) also publishes the inverse twiddle tile in that case
+    if (a.flags == 3u) __syncthreads();   // no forward exchange ran: publish the twiddle tiles here
+    inv_rounds_contig<LP, WIDE, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    if (active) {
+        u64 *__restrict__ pout = a.out + ubase;
+#pragma unroll
+        for (int k = 0; k < 16; k++) st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, va[k]);   // lazy
+    }
+}
+
+// ---------------------------------------------------------------------------
 // STRIDED pass: the first LA stages of a forward transform (last LA of an
 // inverse), on the (2^LA rows) x (2^LB columns) view of one polynomial.
 // Workgroup tile = all 2^LA rows x CW adjacent columns; lanes run along columns,
@@ -673,8 +421,9 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     // wave-uniform 64-bit base (SGPRs) + 32-bit per-lane element offsets: one v_add_u32 per
     // access instead of 64-bit address arithmetic (a polynomial spans < 2^32 bytes)
     const u64 ubase = (poly << a.log_n) + (u64)cg * CW;
-    const u64 *__restrict__ pin = a.in + ubase;
-    u64 *__restrict__ pout = a.out + ubase;
+    // gridDim.y = 2: the two operands of a product in one launch (row 1 = in2 -> out2)
+    const u64 *__restrict__ pin = (blockIdx.y ? a.in2 : a.in) + ubase;
+    u64 *__restrict__ pout = (blockIdx.y ? a.out2 : a.out) + ubase;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     const Tw *tw = ltw;
@@ -836,11 +585,6 @@ __global__ __launch_bounds__(256) void check_canonical_kernel(const u64 *__restr
 // ---------------------------------------------------------------------------
 static inline hipError_t post_launch() { return hipGetLastError(); }
 
-// dynamic LDS above 64 KiB must be opted into per kernel
-static inline hipError_t allow_big_lds(const void *fn, size_t bytes) {
-    if (bytes <= 65536) return hipSuccess;
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
 
 template <int LP, bool FINAL, bool WIDE, int SRC = SRC_PLAIN>
 static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
@@ -873,7 +617,7 @@ static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
 }
 
 template <int LA, int CW, bool INV, bool WIDE, bool RSRC = false>
-static hipError_t launch_strided(const PassArgs &a, hipStream_t st) {
+static hipError_t launch_strided(const PassArgs &a, hipStream_t st, unsigned operands = 1) {
     using C = StridedCfg<LA, CW>;
     const u64 ncg = (1ull << (a.log_n - LA)) / CW;
     const u64 grid = ncg * a.batch;
@@ -886,7 +630,7 @@ static hipError_t launch_strided(const PassArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW, WIDE>), dim3((unsigned)grid), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     else
-        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, WIDE, RSRC>), dim3((unsigned)grid), dim3(C::TH),
+        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, WIDE, RSRC>), dim3((unsigned)grid, operands), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     return post_launch();
 }
@@ -922,11 +666,11 @@ static hipError_t inv_contig_dispatch(int lp, bool final, bool mul_in, const Pas
 }
 
 template <bool INV, bool WIDE>
-static hipError_t strided_dispatch(int la, const PassArgs &a, hipStream_t st) {
+static hipError_t strided_dispatch(int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
     switch (la) {
-        case 6: return launch_strided<6, 128, INV, WIDE>(a, st);
-        case 7: return launch_strided<7, 64, INV, WIDE>(a, st);
-        case 8: return launch_strided<8, 32, INV, WIDE>(a, st);   // 16 / 64 columns measured equal / slower
+        case 6: return launch_strided<6, 128, INV, WIDE>(a, st, operands);
+        case 7: return launch_strided<7, 64, INV, WIDE>(a, st, operands);
+        case 8: return launch_strided<8, 32, INV, WIDE>(a, st, operands);   // 16 / 64 columns measured equal / slower
     }
     return hipErrorInvalidValue;
 }
@@ -1003,6 +747,72 @@ hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_eva
 #undef X
     }
     return hipErrorInvalidValue;
+}
+
+template <int LP, bool WIDE>
+static hipError_t launch_rq_mul_mid_lp(const PassArgs &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    const u64 nb = 1ull << (a.log_n - LP);
+    const u64 grid = nb * ((a.batch + C::W - 1) / C::W);
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = C::LDS_BYTES + (size_t)C::LTW_N * sizeof(Tw);   // a second twiddle tile
+    if (hipError_t e = allow_big_lds((const void *)rq_mul_mid_kernel<LP, WIDE>, lds_bytes)) return e;
+    KernelTimer kt("rq_mul_mid", LP, st);
+    hipLaunchKernelGGL((rq_mul_mid_kernel<LP, WIDE>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
+    return post_launch();
+}
+
+// c = a * b at two-pass sizes: [strided(a) | strided(b)] (one launch) -> middle kernel -> strided^-1.
+// wa / wb: where the strided pass of each coefficient operand goes (scratch, or the operand's evals
+// output, which the middle kernel then overwrites in place with the canonical evals).
+hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_evals, const u64 *b_, bool b_is_evals,
+                                  u64 *c, u64 *c_evals, u64 *wa, bool keep_a_evals, u64 *wb, bool keep_b_evals,
+                                  u64 batch, u64 batch_tile, hipStream_t st) {
+    const int L = p.log_n;
+    if (L <= kMaxSinglePassLog || L > kMaxLog) return hipErrorNotSupported;
+    if (batch == 0) return hipSuccess;
+    const int LB = contig_bits(L), LA = L - LB;
+    const u64 n = 1ull << L;
+    if (batch_tile == 0) batch_tile = batch;
+    for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
+        const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile, o = b0 * n;
+        PassArgs f{};
+        f.tw = p.tw_fwd; f.mod = p.mod; f.log_n = p.log_n; f.batch = nb;
+        hipError_t e = hipSuccess;
+        if (!a_is_evals && !b_is_evals) {
+            f.in = a_ + o; f.out = wa + o; f.in2 = b_ + o; f.out2 = wb + o;
+            e = p.wide ? strided_dispatch<false, true>(LA, f, st, 2) : strided_dispatch<false, false>(LA, f, st, 2);
+        } else if (!a_is_evals) {
+            f.in = a_ + o; f.out = wa + o;
+            e = p.wide ? strided_dispatch<false, true>(LA, f, st) : strided_dispatch<false, false>(LA, f, st);
+        } else if (!b_is_evals) {
+            f.in = b_ + o; f.out = wb + o;
+            e = p.wide ? strided_dispatch<false, true>(LA, f, st) : strided_dispatch<false, false>(LA, f, st);
+        }
+        if (e != hipSuccess) return e;
+        PassArgs m{};
+        m.tw = p.tw_fwd; m.tw_inv = p.tw_inv; m.mod = p.mod; m.ninv = p.ninv; m.s_ninv = p.s_ninv;
+        m.log_n = p.log_n; m.batch = nb;
+        m.in = (a_is_evals ? a_ : wa) + o; m.in2 = (b_is_evals ? b_ : wb) + o;
+        m.out = c + o; m.out2 = c_evals ? c_evals + o : nullptr;
+        m.out3 = (keep_a_evals && !a_is_evals) ? wa + o : nullptr;
+        m.out4 = (keep_b_evals && !b_is_evals) ? wb + o : nullptr;
+        m.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
+        switch (LB) {
+#define X(LP_) case LP_: e = p.wide ? launch_rq_mul_mid_lp<LP_, true>(m, st) : launch_rq_mul_mid_lp<LP_, false>(m, st); break;
+            X(8) X(9) X(10) X(11) X(12)
+#undef X
+            default: return hipErrorInvalidValue;
+        }
+        if (e != hipSuccess) return e;
+        PassArgs i{};
+        i.tw = p.tw_inv; i.mod = p.mod; i.ninv = p.ninv; i.s_ninv = p.s_ninv; i.log_n = p.log_n; i.batch = nb;
+        i.in = c + o; i.out = c + o;
+        e = p.wide ? strided_dispatch<true, true>(LA, i, st) : strided_dispatch<true, false>(LA, i, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,

@@ -81,6 +81,14 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
 // LDS.  evals_* may be nullptr.  Returns hipErrorNotSupported for other sizes.
 hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a, bool a_is_evals, const u64 *b, bool b_is_evals,
                                u64 *c, u64 *c_evals, u64 *a_evals, u64 *b_evals, u64 batch, hipStream_t st);
+// The same product at two-pass sizes (2^14 <= n <= 2^20): the two strided forward passes in one launch,
+// ONE middle kernel for contiguous-forward(a), contiguous-forward(b), pointwise product and
+// contiguous-inverse on each block, then the strided inverse pass — 72n bytes of HBM traffic instead
+// of 104n.  wa / wb (batch * n words each) receive the strided pass of a coefficient operand and, when
+// keep_*_evals, end up holding that operand's canonical evals; unused for an operand that is evals.
+hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a, bool a_is_evals, const u64 *b, bool b_is_evals,
+                                  u64 *c, u64 *c_evals, u64 *wa, bool keep_a_evals, u64 *wb, bool keep_b_evals,
+                                  u64 batch, u64 batch_tile, hipStream_t st);
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
                                 hipStream_t st);
 hipError_t launch_fill_synthetic(u64 *out, u64 count, u64 q, u64 seed, u64 first, hipStream_t st);

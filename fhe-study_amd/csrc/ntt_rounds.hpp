@@ -1,0 +1,369 @@
+// ntt_rounds.hpp — the device-side building blocks shared by every transform kernel: rounds of up to
+// four stages on 16 register-resident coefficients (forward Cooley-Tukey / inverse Gentleman-Sande,
+// with compile-time tracking of the lazy value bounds), the LDS exchange between rounds, the
+// pass-local twiddle tile and the global access helpers.  Used by ntt_kernels.hip (transforms,
+// products) and digit_mac.hip (decompose -> transform -> multiply-accumulate).
+// Index algebra: see the header of ntt_kernels.hip.
+#pragma once
+#include <type_traits>
+
+#include "ntt_kernels.hpp"
+#include "zq_device.hpp"
+
+namespace fhe {
+
+// ---------------------------------------------------------------------------
+// one round: R stages on the 16 register-resident coefficients
+// ---------------------------------------------------------------------------
+// Lazy ranges of the forward rounds:
+//   WIDE (q < 2^61, 8q < 2^64): values are tracked as multiples of q at compile time.  A stage
+//   takes x < B*q to x' = u + t, y' = u - t + 2q < (B+2)*q, so it needs B <= 6; when B > 6 the
+//   stage first subtracts 4q from x >= 4q (B <= 8 -> 4).  BIN is the bound of the round's inputs
+//   (2 for the first round of a transform — canonical inputs, with slack —, 6 after a round),
+//   fwd_bound_out the bound of its outputs: one conditional subtraction per TWO butterflies in
+//   steady state, one per FOUR in a first round.  TIGHT_LAST: the round's last stage brings x
+//   below 2q first, so the outputs are below 4q (cheaper to canonicalise than < 6q or < 8q).
+//   END6: the round's last stage also corrects when its inputs exceed 4q, so the round (the last
+//   of a strided pass) ends below 6q whatever its length — the bound the next pass starts from.
+//   otherwise (q < 2^62): Harvey's [0,4q) with a 2q correction in every butterfly.
+constexpr int fwd_stage_needs_csub(int bound_in) { return bound_in > 6; }
+constexpr int fwd_bound_out(int R, int bin) {
+    int b = bin;
+    for (int i = 0; i < R; i++) b = (fwd_stage_needs_csub(b) ? 4 : b) + 2;
+    return b;
+}
+constexpr int kPassBound = 6;   // bound (in q) of what a forward strided pass hands to the contiguous pass
+template <int R, bool WIDE, int BIN = 6, bool TIGHT_LAST = false, bool END6 = false>
+__device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
+                                          const Mod &m) {
+    static_assert(BIN >= 1 && BIN <= 8, "input bound out of range");
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int span = 8 >> i;
+        constexpr int kNone = 0;
+        const int bin_i = fwd_bound_out(i, BIN);                 // bound of this stage's inputs
+        const bool corr = fwd_stage_needs_csub(bin_i) || (END6 && i == R - 1 && bin_i > 4);
+        const bool tight = TIGHT_LAST && i == R - 1;             // bring x below 2q: x' and y' < 4q
+#ifdef FHE_ABLATE_NO_BUTTERFLIES   // timing-only build: memory pattern without the arithmetic
+        if (i >= 0) continue;
+#endif
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            const Tw t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l;
+                if (!WIDE) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
+                else if (tight && bin_i > 4) ct_bfly<6>(v[k], v[k + span], t.w, t.wp, m);
+                else if (tight && bin_i > 2) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
+                else if (tight) ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
+                else if (corr) ct_bfly<4>(v[k], v[k + span], t.w, t.wp, m);
+                else ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
+            }
+        }
+    }
+}
+
+// FOLD: this round contains the transform's last GS stage (m = 1, ntt.rs:85 loop
+// exit) and the n^-1 scaling of ntt.rs:100-102 is folded into it:
+//   r[j] = (U+V)*n_inv,  r[j+t] = (U-V)*(roots_inv[1]*n_inv).
+template <int R, bool FOLD>
+__device__ __forceinline__ void round_inv(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
+                                          const Mod &m, const Tw ninv, const Tw s_ninv) {
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            if (FOLD && i == 0) {
+#pragma unroll
+                for (int l = 0; l < span; l++) {
+                    const int k = g * 2 * span + l;
+                    const u64 s = add64(v[k], v[k + span]);                    // < 4q, fine for Shoup
+                    const u64 d = add64(add64(v[k], m.q2p1), ~v[k + span]);    // x - y + 2q
+                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, m);
+                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, m);
+                }
+            } else {
+                const Tw t = tw[(T0 << i) + g];
+#pragma unroll
+                for (int l = 0; l < span; l++) {
+                    const int k = g * 2 * span + l;
+                    gs_bfly(v[k], v[k + span], t.w, t.wp, m);
+                }
+            }
+        }
+    }
+}
+
+// ---- inverse rounds for q < 2^61 (8q < 2^64): per-register value bounds -----------------------
+// A Gentleman-Sande butterfly only needs x + y < 2^64 and x - y + K*q > 0: with bounds (in q) bx, by
+// of its inputs, bx + by <= 8 is enough, the sum leaves with bound bx + by and the product with 2.
+// So instead of one conditional subtraction per butterfly the round follows the bounds of its 16
+// registers at compile time and subtracts 4q only where a pair would exceed 8: 12 instead of 32
+// per round from canonical inputs, 20 instead of 32 in steady state.  A round starts from a uniform
+// bound BIN (after the LDS transpose a register may come from any register of another thread) and
+// ends by bringing every register below BOUT*q.
+struct InvSched {
+    unsigned char cx[4][8];   // stage (in execution order), butterfly: x -= 4q if x >= 4q first
+    unsigned char cy[4][8];   // same for y
+    unsigned char ky[4][8];   // bound of y entering the subtraction: d = x - y + ky*q
+    unsigned char fin[16];    // register: final conditional subtraction of 4q
+};
+constexpr InvSched inv_sched(int R, int bin, bool fold, int bout) {
+    InvSched s{};
+    int B[16] = {};
+    for (int k = 0; k < 16; k++) B[k] = bin;
+    int st = 0;
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+        int j = 0;
+        for (int g = 0; g < (1 << i); g++)
+            for (int l = 0; l < span; l++, j++) {
+                const int k = g * 2 * span + l, k2 = k + span;
+                int bx = B[k], by = B[k2];
+                bool cx = false, cy = false;
+                if (bx + by > 8) {
+                    if (bx >= by) { cx = true; bx = bx > 4 ? 4 : bx; }
+                    else { cy = true; by = by > 4 ? 4 : by; }
+                }
+                if (bx + by > 8) {
+                    if (!cx) { cx = true; bx = bx > 4 ? 4 : bx; }
+                    else { cy = true; by = by > 4 ? 4 : by; }
+                }
+                s.cx[st][j] = cx;
+                s.cy[st][j] = cy;
+                s.ky[st][j] = (unsigned char)by;
+                B[k] = (fold && i == 0) ? 2 : bx + by;
+                B[k2] = 2;
+            }
+    }
+    for (int k = 0; k < 16; k++) s.fin[k] = B[k] > bout;
+    return s;
+}
+
+template <int R, bool FOLD, int BIN, int BOUT>
+__device__ __forceinline__ void round_inv_w(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
+                                            const Tw ninv, const Tw s_ninv) {
+    static_assert(BIN == 2 || BIN == 4, "rounds start from canonical (2) or normalised (4) inputs");
+    static_assert(BOUT == 4, "rounds end below 4q");
+    constexpr InvSched S = inv_sched(R, BIN, FOLD, BOUT);
+    const u64 q4 = 0ull - m.neg4q;
+    const u64 K[5] = {0ull, m.q2p1, q4 + 1ull, q4 + m.q2p1, 2ull * q4 + 1ull};   // (2j)*q + 1
+    int st = 0;
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            Tw t{};
+            if (!(FOLD && i == 0)) t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l, j = g * span + l;
+                u64 x = v[k], y = v[k + span];
+                if (S.cx[st][j]) x = csub_neg(x, m.neg4q);
+                if (S.cy[st][j]) y = csub_neg(y, m.neg4q);
+                const u64 d = add64(add64(x, K[S.ky[st][j] / 2]), ~y);        // x - y + ky*q  in (0, 8q)
+                const u64 s = add64(x, y);                                      // < 8q
+                if (FOLD && i == 0) {
+                    v[k] = mul_shoup_lazy(s, ninv.w, ninv.wp, m);
+                    v[k + span] = mul_shoup_lazy(d, s_ninv.w, s_ninv.wp, m);
+                } else {
+                    v[k] = s;
+                    v[k + span] = mul_shoup_acc(0, d, t.w, t.wp, m.nq);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (S.fin[k]) v[k] = csub_neg(v[k], m.neg4q);
+}
+
+// WIDE: the bound-tracking rounds above (values below 4q between rounds); otherwise [0,2q) throughout
+template <int R, bool FOLD, bool WIDE, int BIN>
+__device__ __forceinline__ void round_inv_sel(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
+                                              const Tw ninv, const Tw s_ninv) {
+    if constexpr (WIDE) round_inv_w<R, FOLD, BIN, 4>(v, tw, T0, m, ninv, s_ninv);
+    else round_inv<R, FOLD>(v, tw, T0, m, ninv, s_ninv);
+}
+
+// field value of register k for a thread whose non-register field bits are tf,
+// register window = field bits [A, A+4)
+template <int A>
+__device__ __forceinline__ u32 field_of(u32 tf, int k) {
+    const u32 lo = tf & ((1u << A) - 1u);
+    const u32 hi = tf >> A;
+    return (hi << (A + 4)) | ((u32)k << A) | lo;
+}
+
+// LDS slot of tile element e in the contiguous kernels: one 8-byte pad every 16
+// elements so that the a=0 window (lane stride 16 elements) is conflict-free.
+__device__ __forceinline__ u32 pad16(u32 e) { return e + (e >> 4); }
+
+// stage a pass-local twiddle table into LDS: local index li in [1, M): ls = floor(log2 li),
+// global index (1 << (s0+ls)) + (blk << ls) + (li - 2^ls); the rounds then index it with
+// T0 = (1 << ls0) + H, i.e. as if the pass were a transform of its own.
+template <int M, int TH>
+__device__ __forceinline__ void stage_twiddles(Tw *ltw, const Tw *__restrict__ tw, u32 s0, u32 blk,
+                                               u32 tid) {
+    for (u32 li = tid; li < (u32)M; li += TH) {
+        const u32 ls = 31u - (u32)__builtin_clz(li | 1u);   // entry 0 is never used: copy tw[.] of li = 1
+        const u32 l1 = li | (li == 0);
+        ltw[li] = tw[(1u << (s0 + ls)) + (blk << ls) + (l1 - (1u << ls))];
+    }
+}
+
+// Global access as (wave-uniform 64-bit base) + (32-bit per-lane BYTE offset): the form the
+// saddr/voffset addressing mode takes, so an access costs one v_add_u32, not 64-bit arithmetic.
+// Coefficient data is touched once per pass, so accesses in which a wave instruction covers whole
+// cache lines carry the non-temporal hint (plain copy: 5.41 -> 5.71 TB/s with it,
+// tools/ubench_mem.hip; forward 2^16 transform 7.40 -> 7.25 ms).  The inverse contiguous pass reads
+// and writes a line in pieces spread over several instructions and needs the cache to merge them:
+// with the hint it ran 3.69 -> 5.5 ms, so it uses the plain forms (ld_c / st_c).
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T ld_at(const u64 *ubase, u32 byte_off);
+template <>
+__device__ __forceinline__ u64 ld_at<u64>(const u64 *ubase, u32 byte_off) {
+    return __builtin_nontemporal_load(
+        reinterpret_cast<const u64 *>(reinterpret_cast<const unsigned char *>(ubase) + byte_off));
+}
+__device__ __forceinline__ void st_at(u64 *ubase, u32 byte_off, u64 x) {
+    __builtin_nontemporal_store(x, reinterpret_cast<u64 *>(reinterpret_cast<unsigned char *>(ubase) + byte_off));
+}
+template <typename T>
+__device__ __forceinline__ T ld_c(const u64 *ubase, u32 byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(ubase) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_c(u64 *ubase, u32 byte_off, T x) {
+    *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ubase) + byte_off) = x;
+}
+
+// ---------------------------------------------------------------------------
+// CONTIGUOUS pass: blocks of M = 2^LP consecutive coefficients.
+// Workgroup = W units (unit = one M-block of one polynomial, all W units share
+// `blk`, hence the twiddles), TPB = M/16 threads per unit.
+// ---------------------------------------------------------------------------
+template <int LP>
+struct ContigCfg {
+    static constexpr int M = 1 << LP;
+    static constexpr int TPB = M / 16;
+    static constexpr int TH = (LP <= 12) ? 256 : 512;
+    static constexpr int W = TH / TPB;
+    static constexpr int TILE = W * M;  // = 16 * TH
+    static constexpr int NR = (LP + 3) / 4;
+    static constexpr int R0 = LP - 4 * (NR - 1);
+    static constexpr int A0 = LP - 4;  // register window of round 0 = top 4 field bits
+    // The first 2^LTW_LOG entries of the pass-local twiddle table (all W units share `blk`) are
+    // staged into LDS once per workgroup: a round whose stages all lie below local stage
+    // LTW_LOG reads them with ds_read_b128 instead of 15 global loads through L1.  Later rounds
+    // (LP > 8: per-thread-unique twiddles, up to 64 KiB per block) stay on the global table.
+    static constexpr int LTW_LOG = LP < 8 ? LP : 8;
+    static constexpr int LTW_N = 1 << LTW_LOG;
+    static constexpr size_t DATA_BYTES = (size_t)(TILE + TILE / 16) * 8;
+    static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)LTW_N * sizeof(Tw);
+    // window base of round j >= 1
+    static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
+    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
+    static constexpr bool in_lds(int j) { return ls0_of(j) + (j == 0 ? R0 : 4) <= LTW_LOG; }
+};
+
+// scatter registers (window AF) -> barrier -> gather registers (window AT).
+// FIRST = false: the tile was read by an earlier exchange, so a barrier precedes the scatter.
+// No trailing barrier: whoever writes the tile next either is this function (FIRST = false)
+// or writes exactly the slots it has just gathered (the store transpose of the forward pass).
+template <int LP, int AF, int AT, bool FIRST>
+__device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u32 tf) {
+    constexpr int M = 1 << LP;
+    if (!FIRST) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16(w * M + field_of<AF>(tf, k))] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
+}
+
+// The LP stages of a contiguous pass on the 16 registers of each thread: round 0 in the window the
+// load filled (field bits [LP-4, LP)), an LDS exchange before every later round, ending in window
+// [0,4) (16 consecutive coefficients per thread).  `ltw` is the pass-local twiddle tile staged by
+// stage_twiddles (published by the first exchange's barrier), `gtw` the global table for the rounds
+// that do not fit it; s0 / blk place the block in the transform (0, 0: the pass is the transform).
+// BIN: bound (in q) of the inputs; TIGHT: this pass holds the transform's last stage, which then
+// leaves x', y' < 4q.  FRESH: nobody has read the LDS tile since the last barrier.
+template <int LP, bool WIDE, bool TIGHT, int BIN, bool FRESH>
+__device__ __forceinline__ void fwd_rounds_contig(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
+                                                  u32 w, u32 tf, const Mod &m) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
+    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
+        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    };
+    constexpr int B0 = BIN, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1), B3 = fwd_bound_out(4, B2);
+    // Round 0's twiddles are the same for the whole workgroup (H = 0): read from the global
+    // table at a wave-uniform address (scalar loads, SGPR operands).
+    round_fwd<C::R0, WIDE, B0, TIGHT && C::NR == 1>(v, gtw, (1u << s0) + blk, m);
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        constexpr bool L = C::in_lds(1);
+        exchange_contig<LP, C::A0, A, FRESH>(v, lds, w, tf);
+        round_fwd<4, WIDE, B1, TIGHT && C::NR == 2>(v, TW(L), T0(L, LS, tf >> A), m);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        constexpr bool L = C::in_lds(2);
+        exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
+        round_fwd<4, WIDE, B2, TIGHT && C::NR == 3>(v, TW(L), T0(L, LS, tf >> A), m);
+    }
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        constexpr bool L = C::in_lds(3);
+        exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
+        round_fwd<4, WIDE, B3, TIGHT && C::NR == 4>(v, TW(L), T0(L, LS, tf >> A), m);
+    }
+}
+
+// The mirror image for an inverse contiguous pass: from window [0,4) (canonical inputs: the first
+// round that runs starts from bound 2, later ones from the normalised 4) up to window [LP-4, LP).
+// FOLD: the pass holds the transform's last GS stage (s0 = 0) with the n^-1 scaling folded in.
+// FRESH as above (an exchange precedes every round but the first).
+template <int LP, bool WIDE, bool FOLD, bool FRESH>
+__device__ __forceinline__ void inv_rounds_contig(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
+                                                  u32 w, u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
+    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
+        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    };
+    constexpr int BF = 2, BN = 4;
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        constexpr bool L = C::in_lds(3);
+        round_inv_sel<4, false, WIDE, BF>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::a_of(2), FRESH>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        constexpr bool L = C::in_lds(2);
+        round_inv_sel<4, false, WIDE, (C::NR == 3 ? BF : BN)>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::a_of(1), FRESH && (C::NR <= 3)>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        constexpr bool L = C::in_lds(1);
+        round_inv_sel<4, false, WIDE, (C::NR == 2 ? BF : BN)>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::A0, FRESH && (C::NR <= 2)>(v, lds, w, tf);
+    }
+    // FOLD implies s0 == 0 (this pass holds the m = 1 stage)
+    round_inv_sel<C::R0, FOLD, WIDE, (C::NR == 1 ? BF : BN)>(v, TW(C::in_lds(0)), T0(C::in_lds(0), 0, 0), m, ninv, s_ninv);
+}
+
+// dynamic LDS above 64 KiB must be opted into per kernel
+static inline hipError_t allow_big_lds(const void *fn, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace fhe

@@ -15,10 +15,12 @@
 // < 2n: nothing wraps); the torus product is negacyclic at length n with a centred lift.
 // K is chosen from a caller-supplied bound on the true coefficient magnitude.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "capi_internal.hpp"
+#include "digit_mac.hpp"
 #include "zq_device.hpp"
 #include "mac_kernel.hpp"
 
@@ -512,6 +514,85 @@ extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void
 }
 
 // ---- TFHE: TGGSW x TGLWE external product -------------------------------------------------------
+static bool one_prime_form(u64 n, unsigned k, unsigned l) {
+    return (u64)(k + 1) * l * n <= (1ull << 26) && n >= 16 && n <= (1ull << fhe::kMaxSinglePassLog);
+}
+
+// The TGGSW key as the external product consumes it: every word split into 32-bit halves, laid out
+// [t = TGLev*l + level][half][component][n], forward-transformed modulo P1 — (k+1)*l*2*(k+1) rows of n
+// words.  A bootstrapping key is used by every product of a blind rotation (tfhe/src/tlwe.rs), so it
+// is prepared ONCE; 0 words = this shape takes the two-prime form and has no prepared layout.
+extern "C" size_t fhe_tggsw_prepared_words(uint64_t n, unsigned k, unsigned l) {
+    if (n < 2 || (n & (n - 1)) || l < 1 || l > 64 || k < 1 || k > 64 || !one_prime_form(n, k, l)) return 0;
+    return (size_t)2 * (k + 1) * l * (k + 1) * n;
+}
+
+extern "C" int fhe_tggsw_prepare_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw, void *d_prepared, void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_tggsw_prepare_dev");
+    if (rc != FHE_OK) return rc;
+    if (l < 1 || l > 64 || k < 1 || k > 64) return fhe_fail(FHE_E_INVALID, "fhe_tggsw_prepare_dev: need 1 <= l <= 64, 1 <= k <= 64");
+    if (!one_prime_form(n, k, l)) return fhe_fail(FHE_E_INVALID, "fhe_tggsw_prepare_dev: no prepared form for n=%llu, k=%u, l=%u (fhe_tggsw_prepared_words is 0)", (unsigned long long)n, k, l);
+    if (!d_tggsw || !d_prepared) return fhe_fail(FHE_E_NULL, "fhe_tggsw_prepare_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_tggsw); REQUIRE_ALIGNED(d_prepared);
+    ZCtx z1;
+    if ((rc = zctx_init(&z1, n, 1)) != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u32 k1 = k + 1;
+    const u64 T = (u64)k1 * l, grows = T * k1;
+    hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, (u64 *)d_prepared, T, k1, (u32)n);
+    LAUNCH_OK("zr_split32_kernel");
+    return z_forward(z1, 0, (const u64 *)d_prepared, (u64 *)d_prepared, 2 * grows, st);          // halves are < 2^32 < P1
+}
+
+extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, unsigned l, const void *d_prepared,
+                                                       const void *d_tglwe, void *d_out, size_t batch, void *hip_stream) {
+    int rc = check_pow2_n(n, "fhe_tggsw_external_product_prepared_dev");
+    if (rc != FHE_OK) return rc;
+    if (l < 1 || l > 64 || k < 1 || k > 64) return fhe_fail(FHE_E_INVALID, "external product: need 1 <= l <= 64, 1 <= k <= 64");
+    if (!one_prime_form(n, k, l)) return fhe_fail(FHE_E_INVALID, "fhe_tggsw_external_product_prepared_dev: no prepared form for this shape");
+    if (batch == 0) return FHE_OK;
+    if (!d_prepared || !d_tglwe || !d_out) return fhe_fail(FHE_E_NULL, "fhe_tggsw_external_product_prepared_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_prepared); REQUIRE_ALIGNED(d_tglwe); REQUIRE_ALIGNED(d_out);
+    ZCtx z1;
+    if ((rc = zctx_init(&z1, n, 1)) != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const u32 k1 = k + 1;
+    const u64 T = (u64)k1 * l, orows = batch * k1, drows = batch * T;
+    const u64 *G2 = (const u64 *)d_prepared;
+    void *wsv = nullptr;
+    // Fused form: digit extraction, forward transform and multiply-accumulate in one kernel
+    // (digit_mac.hip); the digit transforms never reach memory.  R[b][half][c] = sum_t G2[t][half][c] * NTT(digit_t(b)).
+    static const bool fused_on = [] { const char *e = getenv("FHE_DIGIT_MAC_FUSED"); return !(e && e[0] == '0'); }();
+    const u32 parts = fhe::digit_mac_parts(batch, (u32)T, z1.dp[0].log_n);
+    if (fused_on) {
+        if ((rc = fhe_workspace_get(1, ((u64)parts + 1) * 2 * orows * n * 8, st, &wsv)) != FHE_OK) return rc;
+        u64 *R = (u64 *)wsv, *PART = parts > 1 ? R + 2 * orows * n : R;
+        hipError_t e = fhe::launch_digit_mac(z1.dp[0], fhe::SRC_DIGITS, (const u64 *)d_tglwe, (u64)k1 * n, k1, l, G2, 2 * k1, PART, parts, batch, st);
+        if (e == hipSuccess) {
+            if (parts > 1 && (e = fhe::launch_sum_parts(PART, R, batch, parts, 2ull * k1 * n, z1.cc.m[0].q, st)) != hipSuccess)
+                return fhe_hip_fail(e, "sum_parts_kernel");
+            if ((rc = z_inverse(z1, 0, R, R, 2 * orows, st)) != FHE_OK) return rc;
+            hipLaunchKernelGGL(fhe::zr_combine32_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)R, (u64 *)d_out, (u64)batch, k1, (u32)n, z1.cc.p1, z1.cc.half1);
+            LAUNCH_OK("zr_combine32_kernel");
+            return FHE_OK;
+        }
+        if (e != hipErrorNotSupported) return fhe_hip_fail(e, "digit_mac_kernel");
+        (void)hipGetLastError();
+    }
+    // unfused: every digit transform written to D, then one multiply-accumulate pass over it
+    if ((rc = fhe_workspace_get(1, (drows + 2 * orows) * n * 8, st, &wsv)) != FHE_OK) return rc;
+    u64 *D = (u64 *)wsv, *R = D + drows * n;
+    hipError_t e = fhe::launch_ntt_forward_digits(z1.dp[0], (const u64 *)d_tglwe, D, orows, (u32)l, st);
+    if (e != hipSuccess) return fhe_hip_fail(e, "digit forward NTT");
+    hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, 2 * k1, n))), dim3(256), 0, st, G2, (const u64 *)D, R, (u64)batch, (u32)n, (u32)T, 2 * k1, (u64)0, z1.cc.m[0]);
+    LAUNCH_OK("mac_rows_kernel");
+    if ((rc = z_inverse(z1, 0, R, R, 2 * orows, st)) != FHE_OK) return rc;
+    hipLaunchKernelGGL(fhe::zr_combine32_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)R, (u64 *)d_out, (u64)batch, k1, (u32)n, z1.cc.p1, z1.cc.half1);
+    LAUNCH_OK("zr_combine32_kernel");
+    return FHE_OK;
+}
+
+
 // d_tggsw [(k+1)][l][(k+1)][n], one key for the batch; d_tglwe [batch][(k+1)][n]; d_out likewise.
 extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw,
                                               const void *d_tglwe, void *d_out, size_t batch, void *hip_stream) {
@@ -527,25 +608,13 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
     // One-prime form (see zr_split32_kernel): the digit transforms — the dominant cost — are needed
     // for ONE prime instead of two.  Valid while each half-sum stays below P1/2: (k+1)*l*n <= 2^26.
     // Needs the bit-extracting transform (single-pass sizes); larger n takes the two-prime form.
-    if ((u64)k1 * l * n <= (1ull << 26) && n >= 16 && n <= (1ull << fhe::kMaxSinglePassLog)) {
-        ZCtx z1;
-        if ((rc = zctx_init(&z1, n, 1)) != FHE_OK) return rc;
+    if (one_prime_form(n, k, l)) {
+        // the key prepared on the fly (a caller with a long-lived key prepares it once:
+        // fhe_tggsw_prepare_dev + fhe_tggsw_external_product_prepared_dev)
         void *wsv = nullptr;
-        if ((rc = fhe_workspace_get(1, (2 * grows + drows + 2 * orows) * n * 8, st, &wsv)) != FHE_OK) return rc;
-        u64 *G2 = (u64 *)wsv, *D = G2 + 2 * grows * n, *R = D + drows * n;
-        const u64 T = (u64)k1 * l;
-        hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, G2, T, k1, (u32)n);
-        LAUNCH_OK("zr_split32_kernel");
-        if ((rc = z_forward(z1, 0, G2, G2, 2 * grows, st)) != FHE_OK) return rc;          // halves are < 2^32 < P1
-        hipError_t e = fhe::launch_ntt_forward_digits(z1.dp[0], (const u64 *)d_tglwe, D, orows, (u32)l, st);
-        if (e != hipSuccess) return fhe_hip_fail(e, "digit forward NTT");
-        // R[b][half][c] = sum_t G2[t][half][c] * D[b][t]: 2*k1 output rows per ciphertext
-        hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, 2 * k1, n))), dim3(256), 0, st, (const u64 *)G2, (const u64 *)D, R, (u64)batch, (u32)n, (u32)T, 2 * k1, (u64)0, z1.cc.m[0]);
-        LAUNCH_OK("mac_rows_kernel");
-        if ((rc = z_inverse(z1, 0, R, R, 2 * orows, st)) != FHE_OK) return rc;
-        hipLaunchKernelGGL(fhe::zr_combine32_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)R, (u64 *)d_out, (u64)batch, k1, (u32)n, z1.cc.p1, z1.cc.half1);
-        LAUNCH_OK("zr_combine32_kernel");
-        return FHE_OK;
+        if ((rc = fhe_workspace_get(0, 2 * grows * n * 8, st, &wsv)) != FHE_OK) return rc;
+        if ((rc = fhe_tggsw_prepare_dev(n, k, l, d_tggsw, wsv, hip_stream)) != FHE_OK) return rc;
+        return fhe_tggsw_external_product_prepared_dev(n, k, l, wsv, d_tglwe, d_out, batch, hip_stream);
     }
     ZCtx z;
     // digits are 0/1: |sum| < (k+1) * l * n * 2^64

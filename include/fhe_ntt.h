@@ -213,6 +213,18 @@ int fhe_tggsw_external_product(uint64_t n, unsigned k, unsigned l, const uint64_
                                const uint64_t *tglwe, uint64_t *out, size_t batch);
 int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw,
                                    const void *d_tglwe, void *d_out, size_t batch, void *hip_stream);
+/* Resident key ("pre-transformed, reusable across the 630 products"): the TGGSW rows in
+ * the layout the product consumes (32-bit halves, forward-transformed), built once and used by every
+ * later call — the bootstrapping key of a blind rotation serves all its external products.
+ *   fhe_tggsw_prepared_words   u64 words d_prepared must hold (0: this shape has no prepared form,
+ *                              i.e. (k+1)*l*n > 2^26 or n outside [16, 2^13]: use the plain entry point)
+ *   fhe_tggsw_prepare_dev      d_tggsw [(k+1)][l][(k+1)][n]  ->  d_prepared
+ *   ..._prepared_dev           the external product against a prepared key; same words as
+ *                              fhe_tggsw_external_product_dev on the original key. */
+size_t fhe_tggsw_prepared_words(uint64_t n, unsigned k, unsigned l);
+int fhe_tggsw_prepare_dev(uint64_t n, unsigned k, unsigned l, const void *d_tggsw, void *d_prepared, void *hip_stream);
+int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, unsigned l, const void *d_prepared,
+                                            const void *d_tglwe, void *d_out, size_t batch, void *hip_stream);
 
 /* TGLWE x Tn (plaintext product), tfhe/src/tglwe.rs:182-194: out[b][i] = tglwe[b][i] * p[b] mod
  * (2^64, X^n+1), i <= k.  tglwe, out: [batch][(k+1)][n]; p: [batch][n]. */

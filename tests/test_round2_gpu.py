@@ -232,3 +232,163 @@ def test_bench_two_ranks_on_one_gpu(pkg, oracle, tmp_path):
     assert out["parity"]["mismatching_rows"] == 0
     assert out["parity"]["ranks_checked"] == 2
     assert out["gather_check"]["equal_to_single_rank_transform"] is True
+
+
+# ---- the product at two-pass sizes: fused middle kernel ------------------------------
+
+@pytest.mark.parametrize("q,log_n,batch", [(Q61, 14, 19), (Q61, 15, 5), (Q61, 16, 17), (Q61, 17, 3), (Q61, 18, 2),
+                                           (Q61, 20, 1), (Q16, 14, 18), (4611686018425815041, 14, 3)])
+def test_two_pass_product_every_evals_combination(pkg, oracle, q, log_n, batch):
+    """n >= 2^14: strided(a) | strided(b) in one launch, ONE middle kernel (contiguous forward of both
+    operands, pointwise product, contiguous inverse), strided inverse.  Every combination of cached
+    evals (ring_nq.rs:590-599) and every optional output, ragged batches (W = 16 .. 1 units per
+    workgroup), a tiny and a 62-bit modulus; word for word against the oracle."""
+    n = 1 << log_n
+    a = oracle.fill_synthetic(q, 5 + log_n, 0, batch * n)
+    b = oracle.fill_synthetic(q, 6 + log_n, 0, batch * n)
+    want = oracle.rq_mul(q, n, a, b)                     # c, c_evals, a_evals, b_evals
+    c, ce, ae, be = want
+    P = pkg.Plan(q, n)
+    for got in (P.rq_mul(a, b), P.rq_mul(ae, b, a_is_evals=True), P.rq_mul(a, be, b_is_evals=True),
+                P.rq_mul(ae, be, a_is_evals=True, b_is_evals=True)):
+        for x, y in zip(got, want):
+            assert np.array_equal(np.asarray(x).reshape(-1), y.reshape(-1)), (q, n)
+    assert np.array_equal(P.rq_mul(a, b, want_evals=False)[0].reshape(-1), c.reshape(-1))
+
+
+def test_two_pass_product_device_entry_point_outputs_workspaces_and_tiles(pkg, oracle):
+    """fhe_rq_mul_dev at n = 2^16: library workspace and caller workspace, each optional output on its
+    own, the product written over an operand (c == a), and the batch walked in tiles."""
+    import torch
+
+    q, n, batch = Q61, 65536, 21
+    plan = pkg.Plan(q, n)
+    st = torch.cuda.current_stream().cuda_stream
+    a = oracle.fill_synthetic(q, 71, 0, batch * n)
+    b = oracle.fill_synthetic(q, 72, 0, batch * n)
+    c, ce, ae, be = oracle.rq_mul(q, n, a, b)
+    dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
+    da, db = dev(a), dev(b)
+    work = torch.empty(plan.workspace_bytes(batch) // 8, dtype=torch.int64, device="cuda")
+    for tile in (0, 4, 16):
+        pkg.binding.set_batch_tile(tile)
+        for w in (None, work.data_ptr()):
+            dc, dce, dae, dbe = (torch.empty_like(da) for _ in range(4))
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, d_work=w, stream=st)
+            assert np.array_equal(_u64(dc), c), (tile, w)
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, d_c_evals=dce.data_ptr(), d_work=w, stream=st)
+            assert np.array_equal(_u64(dc), c) and np.array_equal(_u64(dce), ce)
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, d_a_evals=dae.data_ptr(), d_work=w, stream=st)
+            assert np.array_equal(_u64(dc), c) and np.array_equal(_u64(dae), ae)
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, d_b_evals=dbe.data_ptr(), d_work=w, stream=st)
+            assert np.array_equal(_u64(dc), c) and np.array_equal(_u64(dbe), be)
+    pkg.binding.set_batch_tile(0)
+    # in place over an operand, and over an operand that is evals
+    x = da.clone()
+    plan.rq_mul_dev(x.data_ptr(), db.data_ptr(), x.data_ptr(), batch, stream=st)
+    assert np.array_equal(_u64(x), c)
+    x = dev(ae)
+    plan.rq_mul_dev(x.data_ptr(), db.data_ptr(), x.data_ptr(), batch, a_is_evals=True, stream=st)
+    assert np.array_equal(_u64(x), c)
+    # mul_mut (ring_nq.rs:564-583): the operands' buffers end up holding their evals
+    x, y = da.clone(), db.clone()
+    dc = torch.empty_like(da)
+    plan.rq_mul_dev(x.data_ptr(), y.data_ptr(), dc.data_ptr(), batch, d_a_evals=x.data_ptr(), d_b_evals=y.data_ptr(), stream=st)
+    assert np.array_equal(_u64(dc), c) and np.array_equal(_u64(x), ae) and np.array_equal(_u64(y), be)
+
+
+# ---- decompose -> forward NTT -> multiply-accumulate in one kernel (VERDICT r01 item 3) ------------------------
+
+@pytest.mark.parametrize("n,k,l,batch", [(1024, 1, 64, 5),      # BASELINE.json configs[3] shape: 4 units per workgroup, 4 parts
+                                         (256, 1, 64, 3),       # 16 units per workgroup
+                                         (512, 1, 7, 9),        # l not a multiple of the units: steps straddle source rows
+                                         (2048, 1, 33, 2),
+                                         (4096, 1, 64, 1)])     # 2(k+1) * n/256 = 64 accumulators: takes the unfused form
+def test_fused_external_product_and_prepared_key(pkg, oracle, n, k, l, batch):
+    """TGGSW x TGLWE through digit_mac_kernel (tfhe/src/tggsw.rs:45-62): same words as the oracle's
+    schoolbook; the key prepared once (fhe_tggsw_prepare_dev) gives the same words again, for several
+    batches, without touching the original key."""
+    import torch
+
+    L, B = pkg.load_library(), pkg.binding
+    rng = np.random.default_rng(n + l)
+    g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).cuda()
+    c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (batch, k + 1, n), dtype=np.int64)).cuda()
+    c[0, 0, :4] = torch.tensor([0, -1, 1, -(1 << 63)], dtype=torch.int64)        # all-zero / all-one digit columns
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty_like(c)
+    B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), out.data_ptr(), batch, st))
+    want = oracle.external_product(n, k, l, _u64(g), _u64(c))
+    assert np.array_equal(_u64(out), want)
+    words = L.fhe_tggsw_prepared_words(n, k, l)
+    assert words == 2 * (k + 1) * l * (k + 1) * n
+    prep = torch.empty(words, dtype=torch.int64, device="cuda")
+    B._check(L.fhe_tggsw_prepare_dev(n, k, l, g.data_ptr(), prep.data_ptr(), st))
+    g.zero_()                                                                     # the prepared key stands alone
+    for nb in (batch, 1):
+        out2 = torch.empty((nb, k + 1, n), dtype=torch.int64, device="cuda")
+        B._check(L.fhe_tggsw_external_product_prepared_dev(n, k, l, prep.data_ptr(), c.data_ptr(), out2.data_ptr(), nb, st))
+        assert np.array_equal(_u64(out2), want[:nb])
+    assert L.fhe_tggsw_prepared_words(16384, 1, 64) == 0                          # two-prime shape: no prepared form
+    assert L.fhe_tggsw_prepare_dev(16384, 1, 64, prep.data_ptr(), prep.data_ptr(), st) == B.FHE_E_INVALID
+
+
+@pytest.mark.parametrize("q,n,k,l,batch", [(Q61, 4096, 1, 61, 3),     # the shape tools/bench_next.py times: 1 unit, 16 positions per thread
+                                           (Q61, 1024, 1, 61, 9),
+                                           (Q61, 1024, 2, 33, 2),     # k+1 = 3 output rows
+                                           (Q16, 256, 1, 16, 20),     # q = 65537 < 2^l: the saturation branch of Zq::decompose everywhere
+                                           (Q61, 2048, 2, 64, 1)])    # l = 64: `1 << l` wraps like a --release build
+def test_fused_key_switch(pkg, oracle, q, n, k, l, batch):
+    """GLWE::key_switch (gfhe/src/glwe.rs:126-137) with base-2 decomposition through digit_mac_kernel;
+    key in coefficients and key resident in the NTT domain (FHE_A_IS_EVALS) give the oracle's words."""
+    import torch
+
+    L, B = pkg.load_library(), pkg.binding
+    plan = pkg.Plan(q, n)
+    rng = np.random.default_rng(n + l + k)
+    glwe = rng.integers(0, q, (batch, k + 1, n), dtype=np.uint64)
+    glwe[0, 0, :4] = [0, 1, (1 << min(l, 62)) % q, q - 1]                         # both decompose branches
+    ksk = rng.integers(0, q, (k, l, k + 1, n), dtype=np.uint64)
+    dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
+    dglwe, dksk = dev(glwe), dev(ksk)
+    dout = torch.empty_like(dglwe)
+    B._check(L.fhe_glwe_key_switch_dev(plan.handle, k, 2, l, dglwe.data_ptr(), dksk.data_ptr(), dout.data_ptr(), batch, 0, None))
+    want = np.empty((batch, k + 1, n), dtype=np.uint64)
+    for i in range(batch):
+        oracle.glue("key_switch", q, n, k, 2, l, glwe[i], ksk, want[i])
+    assert np.array_equal(_u64(dout), want)
+    dKSK, dout2 = torch.empty_like(dksk), torch.empty_like(dout)
+    plan.forward_dev(dksk.data_ptr(), dKSK.data_ptr(), k * l * (k + 1))
+    B._check(L.fhe_glwe_key_switch_dev(plan.handle, k, 2, l, dglwe.data_ptr(), dKSK.data_ptr(), dout2.data_ptr(), batch,
+                                       B.FHE_A_IS_EVALS, None))
+    assert np.array_equal(_u64(dout2), want)
+
+
+def test_fused_and_unfused_digit_paths_agree_at_bench_sizes(pkg):
+    """FHE_DIGIT_MAC_FUSED=0 keeps round 1's materialised digit transforms + mac_rows_kernel; both forms
+    must produce identical words for 630 external products (N=1024) and 256 key switches (N=4096)."""
+    code = (
+        "import sys, hashlib, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import fhe_study_amd as pkg\n"
+        "L, B = pkg.load_library(), pkg.binding\n"
+        "rng = np.random.default_rng(1)\n"
+        "n, k, l, batch = 1024, 1, 64, 630\n"
+        "g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).cuda()\n"
+        "c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (batch, k + 1, n), dtype=np.int64)).cuda()\n"
+        "o = torch.empty_like(c)\n"
+        "B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), o.data_ptr(), batch, None))\n"
+        "print('ext', hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())\n"
+        "q, n, k, l, batch = pkg.Q61, 4096, 1, 61, 256\n"
+        "plan = pkg.Plan(q, n)\n"
+        "glwe = torch.from_numpy(rng.integers(0, q, (batch, k + 1, n), dtype=np.int64)).cuda()\n"
+        "ksk = torch.from_numpy(rng.integers(0, q, (k, l, k + 1, n), dtype=np.int64)).cuda()\n"
+        "o = torch.empty_like(glwe)\n"
+        "B._check(L.fhe_glwe_key_switch_dev(plan.handle, k, 2, l, glwe.data_ptr(), ksk.data_ptr(), o.data_ptr(), batch, 0, None))\n"
+        "print('ks', hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())\n" % ROOT)
+    outs = []
+    for fused in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FHE_DIGIT_MAC_FUSED=fused),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("ext", "ks"))])
+    assert len(outs[0]) == 2 and outs[0] == outs[1]

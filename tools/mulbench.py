@@ -8,7 +8,11 @@ import fhe_study_amd as pkg
 
 B = pkg.binding
 st = torch.cuda.current_stream().cuda_stream
-for log_n, batch in [(4, 1 << 20), (8, 1 << 18), (10, 1 << 17), (12, 1 << 15), (13, 1 << 14), (16, 4096)] + [(10, 1), (12, 1), (13, 1)]:
+sizes = [(4, 1 << 20), (8, 1 << 18), (10, 1 << 17), (12, 1 << 15), (13, 1 << 14), (14, 1 << 14), (16, 4096), (18, 1024)] + [(10, 1), (12, 1), (13, 1)]
+if len(sys.argv) > 1:   # tools/mulbench.py 14:16384 16:4096 ...
+    sizes = [tuple(int(x) for x in arg.split(":")) for arg in sys.argv[1:]]
+print(f"FHE_RQ_MUL_FUSED={os.environ.get('FHE_RQ_MUL_FUSED', '1')}", flush=True)
+for log_n, batch in sizes:
     q, n = pkg.Q61, 1 << log_n
     plan = pkg.Plan(q, n)
     a = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
@@ -24,4 +28,9 @@ for log_n, batch in [(4, 1 << 20), (8, 1 << 18), (10, 1 << 17), (12, 1 << 15), (
     for _ in range(reps): f()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"rq_mul n=2^{log_n} batch={batch}: {dt*1e6:10.1f} us  {batch/dt/1e6:8.3f} M products/s", flush=True)
+    B.kernel_timing_reset(); B.kernel_timing_enable(True)
+    f(); torch.cuda.synchronize()
+    kt = B.kernel_timing_read(); B.kernel_timing_enable(False)
+    ks = " ".join(f"{k}:{ms/c*1e3:.1f}us" + (f"x{c}" if c > 1 else "") for k, (ms, c) in kt.items())
+    print(f"rq_mul n=2^{log_n} batch={batch}: {dt*1e6:10.1f} us  {batch/dt/1e6:8.3f} M products/s  "
+          f"{batch*n*24/dt/1e12:.2f} TB/s alg (24n)  [{ks}]", flush=True)

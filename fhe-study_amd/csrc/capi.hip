@@ -196,22 +196,54 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
             i[k].w = plan->roots_inv[k];
             i[k].wp = shoup(plan->roots_inv[k], q);
         }
+        // tables for transforms of 0/1 polynomials (gadget digits): outcomes of the first stages per
+        // input bit pattern (ntt_rounds.hpp: round0_bits).  Needs roots[1..7]: n >= 8.
+        std::vector<u64> lut;
+        if (n >= 8) {
+            lut.assign(136, 0);
+            const u64 *r = plan->roots.data();
+            auto add = [&](u64 x, u64 y) { u64 s = x + y; return s >= q ? s - q : s; };
+            auto sub = [&](u64 x, u64 y) { return x >= y ? x - y : x + q - y; };
+            for (unsigned p = 0; p < 16; p++) {
+                const u64 x0 = p & 1, x1 = (p >> 1) & 1, x2 = (p >> 2) & 1, x3 = (p >> 3) & 1;   // registers c, c+4, c+8, c+12
+                const u64 a0 = add(x0, mulmod(r[1], x2, q)), a2 = sub(x0, mulmod(r[1], x2, q));   // stage 0: pairs (c, c+8), (c+4, c+12)
+                const u64 a1 = add(x1, mulmod(r[1], x3, q)), a3 = sub(x1, mulmod(r[1], x3, q));
+                u64 y[4];
+                y[0] = add(a0, mulmod(r[2], a1, q)); y[1] = sub(a0, mulmod(r[2], a1, q));         // stage 1: (c, c+4) with roots[2]
+                y[2] = add(a2, mulmod(r[3], a3, q)); y[3] = sub(a2, mulmod(r[3], a3, q));         //          (c+8, c+12) with roots[3]
+                for (int j = 0; j < 4; j++) {
+                    lut[4 * p + j] = y[j];
+                    lut[64 + 4 * p + j] = mulmod(r[4 + j], y[j], q);                              // stage 2's products
+                }
+            }
+            for (unsigned p = 0; p < 4; p++) {
+                const u64 x = p & 1, y = (p >> 1) & 1;
+                lut[128 + 2 * p] = add(x, mulmod(r[1], y, q));
+                lut[128 + 2 * p + 1] = sub(x, mulmod(r[1], y, q));
+            }
+        }
         fhe::Tw *df = nullptr, *di = nullptr;
+        u64 *dl = nullptr;
         hipError_t e = hipMalloc((void **)&df, n * sizeof(fhe::Tw));
         if (e == hipSuccess) e = hipMalloc((void **)&di, n * sizeof(fhe::Tw));
+        if (e == hipSuccess && !lut.empty()) e = hipMalloc((void **)&dl, lut.size() * sizeof(u64));
         if (e == hipSuccess) e = hipMemcpy(df, f.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(di, i.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
+        if (e == hipSuccess && dl) e = hipMemcpy(dl, lut.data(), lut.size() * sizeof(u64), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             if (df) (void)hipFree(df);
             if (di) (void)hipFree(di);
+            if (dl) (void)hipFree(dl);
             return hip_fail(e, "uploading the twiddle tables");
         }
         t.tw_fwd = df;
         t.tw_inv = di;
+        t.digit_lut = dl;
         t.ready = true;
     }
     dp->tw_fwd = t.tw_fwd;
     dp->tw_inv = t.tw_inv;
+    dp->digit_lut = t.digit_lut;
     dp->mod = plan->mod;
     dp->ninv = plan->ninv;
     dp->s_ninv = plan->s_ninv;
@@ -847,6 +879,7 @@ extern "C" int fhe_ntt_shutdown(void) {
         for (auto &t : p->dev) {
             if (t.tw_fwd) (void)hipFree(t.tw_fwd);
             if (t.tw_inv) (void)hipFree(t.tw_inv);
+            if (t.digit_lut) (void)hipFree(t.digit_lut);
             t = DeviceTables();
         }
     }

@@ -15,6 +15,7 @@ constexpr int kMaxDevices = 16;
 struct DeviceTables {
     fhe::Tw *tw_fwd = nullptr;
     fhe::Tw *tw_inv = nullptr;
+    fhe::u64 *digit_lut = nullptr;   // 136 words, n >= 8 (ntt_rounds.hpp: round0_bits)
     bool ready = false;
 };
 

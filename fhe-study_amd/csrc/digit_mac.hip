@@ -28,6 +28,8 @@
 #include "digit_mac.hpp"
 #include "ntt_rounds.hpp"
 
+#include <cstdlib>
+
 namespace fhe {
 
 template <int LP>
@@ -50,8 +52,10 @@ __device__ __forceinline__ u64 digit_of(u64 x, u32 l, u32 d) {
     return x >= sat ? 1ull : (x >> (l - 1u - d)) & 1ull;
 }
 
-template <int LP, int SRC, int NC>
-__global__ __launch_bounds__(256) void digit_mac_kernel(DigitMacArgs a) {
+// MW: waves per SIMD the register allocation must admit (2: up to 256 VGPRs, 3: 168).  Registers: 4 per
+// accumulator + the 16 coefficients + the round's temporaries.
+template <int LP, int SRC, int NC, int MW>
+__global__ __launch_bounds__(256, MW) void digit_mac_kernel(DigitMacArgs a) {
     using C = ContigCfg<LP>;
     using K = DigitMacCfg<LP>;
     constexpr int PPT = K::PPT, W = C::W;
@@ -65,7 +69,10 @@ __global__ __launch_bounds__(256) void digit_mac_kernel(DigitMacArgs a) {
     const u32 t_begin = part * a.tpp, t_end = min(a.T, t_begin + a.tpp);
     const Mod &m = a.mod;
     const u32 n = 1u << LP;
-    stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, 0u, 0u, tid);      // published by the first exchange's barrier
+    stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, 0u, 0u, tid);
+    u64 *llut = reinterpret_cast<u64 *>(ltw + C::LTW_N);          // digit tables: round 0 is look-ups (round0_bits)
+    for (u32 i = tid; i < (u32)kDigitLutWords; i += C::TH) llut[i] = a.lut[i];
+    __syncthreads();
     const u64 *__restrict__ ct = a.src + b * a.ct_stride;
 
     MacAcc acc[NC][PPT];
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void digit_mac_kernel(DigitMacArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = digit_of<SRC>(row[field_of<C::A0>(tf, k)], a.l, d);
         // FRESH = false: the tile was read by the previous step's multiply phase
-        fwd_rounds_contig<LP, true, true, 2, false>(v, lds, ltw, a.tw, 0u, 0u, w, tf, m);
+        fwd_rounds_contig<LP, true, true, 2, false, true>(v, lds, ltw, a.tw, 0u, 0u, w, tf, m, llut);
         // every thread rewrites exactly the slots it gathered in the last exchange: no barrier before
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[pad16(w * C::M + field_of<0>(tf, k))] = canon4(v[k], m);
@@ -160,9 +167,17 @@ static hipError_t launch_dm(const DigitMacArgs &a, hipStream_t st) {
     } else {
         const u64 grid = a.batch * a.parts;
         if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-        if (hipError_t e = allow_big_lds((const void *)digit_mac_kernel<LP, SRC, NC>, C::LDS_BYTES)) return e;
+        // 3 waves per SIMD up to 16 accumulators per thread (measured); FHE_DIGIT_MAC_WAVES=2|3 for A/B runs
+        static const int waves_env = [] { const char *e = getenv("FHE_DIGIT_MAC_WAVES"); return e ? atoi(e) : 0; }();
+        const int mw = waves_env == 2 || waves_env == 3 ? waves_env : (NC * DigitMacCfg<LP>::PPT <= 16 ? 3 : 2);
         KernelTimer kt(SRC == SRC_DIGITS ? "digit_mac_torus" : "digit_mac_zq", LP, st);
-        hipLaunchKernelGGL((digit_mac_kernel<LP, SRC, NC>), dim3((unsigned)grid), dim3(256), C::LDS_BYTES, st, a);
+        if (mw == 3) {
+            if (hipError_t e = allow_big_lds((const void *)digit_mac_kernel<LP, SRC, NC, 3>, C::LDS_BYTES_BITS)) return e;
+            hipLaunchKernelGGL((digit_mac_kernel<LP, SRC, NC, 3>), dim3((unsigned)grid), dim3(256), C::LDS_BYTES_BITS, st, a);
+        } else {
+            if (hipError_t e = allow_big_lds((const void *)digit_mac_kernel<LP, SRC, NC, 2>, C::LDS_BYTES_BITS)) return e;
+            hipLaunchKernelGGL((digit_mac_kernel<LP, SRC, NC, 2>), dim3((unsigned)grid), dim3(256), C::LDS_BYTES_BITS, st, a);
+        }
         return hipGetLastError();
     }
 }
@@ -190,11 +205,16 @@ uint32_t digit_mac_parts(u64 batch, uint32_t T, uint32_t log_n) {
 hipError_t launch_digit_mac(const DevicePlan &p, int src_kind, const u64 *src, u64 ct_stride, uint32_t rows, uint32_t l,
                             const u64 *key, uint32_t nc, u64 *partial, uint32_t parts, u64 batch, hipStream_t st) {
     const int L = p.log_n;
-    if (L < 8 || L > 12 || !p.wide || l == 0 || l > 64 || rows == 0 || parts == 0) return hipErrorNotSupported;
+    if (L < 8 || L > 12 || !p.wide || l == 0 || l > 64 || rows == 0 || parts == 0 || !p.digit_lut) return hipErrorNotSupported;
     if (src_kind == SRC_ZQBITS && p.mod.q < 3) return hipErrorNotSupported;
+    // Beyond 16 accumulators per thread (n = 4096 with 2 output rows, n = 2048 with 4) the kernel holds 2 waves
+    // per SIMD and measured slower than transform-then-accumulate (key switch, n = 4096: 0.60 vs 0.49 ms per 256):
+    // those shapes keep the two-kernel form.  FHE_DIGIT_MAC_MAXACC overrides the limit for A/B runs.
+    static const uint32_t max_acc = [] { const char *e = getenv("FHE_DIGIT_MAC_MAXACC"); return e ? (uint32_t)atoi(e) : 16u; }();
+    if (nc * ((1u << L) / 256u) > max_acc) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     DigitMacArgs a{};
-    a.src = src; a.key = key; a.out = partial; a.tw = p.tw_fwd; a.mod = p.mod;
+    a.src = src; a.key = key; a.out = partial; a.tw = p.tw_fwd; a.lut = p.digit_lut; a.mod = p.mod;
     a.batch = batch; a.ct_stride = ct_stride; a.l = l; a.T = rows * l; a.parts = parts;
     const uint32_t W = L >= 12 ? 1u : 1u << (12 - L);
     a.tpp = ((a.T + parts - 1) / parts + W - 1) / W * W;           // whole steps per part

@@ -13,6 +13,7 @@ struct DigitMacArgs {
     const u64 *key;     // [T][nc][n], NTT domain, canonical (shared by the batch)
     u64 *out;           // [batch][parts][nc][n] canonical partial sums, NTT domain
     const Tw *tw;
+    const u64 *lut;     // the plan's digit tables (DevicePlan::digit_lut)
     Mod mod;
     u64 batch, ct_stride;
     uint32_t l;         // digits per source row (beta = 2)

@@ -99,7 +99,15 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     // needed from round 1 on, so the barrier of the first exchange also publishes it.
     stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, s0, blk, tid);
 
-    fwd_rounds_contig<LP, WIDE, FINAL, kPassBound, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
+    if constexpr (SRC == SRC_DIGITS || SRC == SRC_ZQBITS) {
+        // inputs are bits: round 0 is table look-ups (round0_bits); the tables go to LDS first
+        u64 *llut = reinterpret_cast<u64 *>(ltw + C::LTW_N);
+        for (u32 i = tid; i < (u32)kDigitLutWords; i += C::TH) llut[i] = a.lut[i];
+        __syncthreads();
+        fwd_rounds_contig<LP, WIDE, FINAL, 2, true, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, llut);
+    } else {
+        fwd_rounds_contig<LP, WIDE, FINAL, kPassBound, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
+    }
     // transpose through LDS so the store is one contiguous slab per wave.  (Storing the 128
     // contiguous bytes a thread owns after the last round as 8 x 16 B straight from registers
     // was measured slower for the forward kernel: 4.91 ms vs 4.40 ms per 16384 polynomials;
@@ -333,7 +341,9 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     stage_twiddles<C::LTW_N, C::TH>(ltw_i, a.tw_inv, s0, blk, tid);   // that precede their first LDS use
     static_assert(C::NR >= 2, "two-pass sizes have LP >= 8");
 
-    auto operand = [&](const u64 *__restrict__ src, bool is_evals, u64 (&v)[16], auto fresh) {
+    // keep: the operand's evals are an output, so they must be canonical; otherwise they stay as the last
+    // stage left them (< 4q < 2^63): the variable x variable product reduces any 128-bit value
+    auto operand = [&](const u64 *__restrict__ src, bool is_evals, bool keep, u64 (&v)[16], auto fresh) {
         const u64 *__restrict__ p = src + ubase;
         if (is_evals) {
 #pragma unroll
@@ -346,8 +356,10 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
             fwd_rounds_contig<LP, WIDE, true, kPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
+            if (keep) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = canon4(v[k], m);   // the last stage left x', y' < 4q
+                for (int k = 0; k < 16; k++) v[k] = canon4(v[k], m);
+            }
         }
     };
     auto store_evals = [&](u64 *dst, const u64 (&v)[16]) {
@@ -358,9 +370,9 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     };
 
     u64 va[16], vb[16];
-    operand(a.in, a.flags & 1u, va, std::true_type{});
+    operand(a.in, a.flags & 1u, a.out3 != nullptr, va, std::true_type{});
     store_evals(a.out3, va);
-    operand(a.in2, a.flags & 2u, vb, std::false_type{});   // the tile may have been used by the first operand
+    operand(a.in2, a.flags & 2u, a.out4 != nullptr, vb, std::false_type{});   // the tile may have been used by the first operand
     store_evals(a.out4, vb);
 #pragma unroll
     for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
@@ -594,10 +606,11 @@ static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     const u64 grid = nb * groups;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>, C::LDS_BYTES)) return e;
+    constexpr size_t lds_bytes = (SRC == SRC_DIGITS || SRC == SRC_ZQBITS) ? C::LDS_BYTES_BITS : C::LDS_BYTES;
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>, lds_bytes)) return e;
     KernelTimer kt(SRC == SRC_DIGITS ? "ntt_fwd_digits" : SRC == SRC_ZQBITS ? "ntt_fwd_zqbits" : SRC == SRC_REDUCE ? "ntt_fwd_reduce" : (FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig"), LP, st);
     hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>), dim3((unsigned)grid), dim3(C::TH),
-                       C::LDS_BYTES, st, a);
+                       lds_bytes, st, a);
     return post_launch();
 }
 
@@ -818,13 +831,13 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
 hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
                                      hipStream_t st) {
     const int L = p.log_n;
-    if (L < 4 || L > kMaxSinglePassLog || !p.wide || l == 0 || l > 64) return hipErrorNotSupported;
+    if (L < 4 || L > kMaxSinglePassLog || !p.wide || l == 0 || l > 64 || !p.digit_lut) return hipErrorNotSupported;
     if (rows == 0) return hipSuccess;
     PassArgs a{};
     a.tw = p.tw_fwd;
     a.mod = p.mod;
     a.log_n = p.log_n;
-    a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l;
+    a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l; a.lut = p.digit_lut;
     switch (L) {
 #define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, SRC_DIGITS>(a, st);
         CONTIG_CASES(X)
@@ -836,13 +849,13 @@ hipError_t launch_ntt_forward_digits(const DevicePlan &p, const u64 *in, u64 *ou
 hipError_t launch_ntt_forward_zqbits(const DevicePlan &p, const u64 *in, u64 *out, u64 rows, uint32_t l,
                                      uint32_t grp, u64 gstride, hipStream_t st) {
     const int L = p.log_n;
-    if (L < 4 || L > kMaxSinglePassLog || !p.wide || l == 0 || l > 64 || grp == 0 || p.mod.q < 3) return hipErrorNotSupported;
+    if (L < 4 || L > kMaxSinglePassLog || !p.wide || l == 0 || l > 64 || grp == 0 || p.mod.q < 3 || !p.digit_lut) return hipErrorNotSupported;
     if (rows == 0) return hipSuccess;
     PassArgs a{};
     a.tw = p.tw_fwd;
     a.mod = p.mod;
     a.log_n = p.log_n;
-    a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l; a.src_grp = grp; a.src_gstride = gstride;
+    a.in = in; a.out = out; a.batch = rows * l; a.digit_l = l; a.src_grp = grp; a.src_gstride = gstride; a.lut = p.digit_lut;
     switch (L) {
 #define X(LP_) case LP_: return launch_fwd_contig<LP_, true, true, SRC_ZQBITS>(a, st);
         CONTIG_CASES(X)

@@ -18,6 +18,7 @@ constexpr int kMaxLog = 20;
 struct DevicePlan {
     const Tw *tw_fwd = nullptr;
     const Tw *tw_inv = nullptr;
+    const u64 *digit_lut = nullptr;   // tables for transforms of 0/1 polynomials (ntt_rounds.hpp: round0_bits)
     Mod mod{};
     Tw ninv{};    // n^-1                     (ntt.rs:27-30)
     Tw s_ninv{};  // roots_inv[1] * n^-1      (last GS stage folded with ntt.rs:100-102)
@@ -45,6 +46,7 @@ struct PassArgs {
     const Tw *tw_inv;    // inverse table (tw holds the forward one)
     u64 *out3, *out4;    // evals of the two operands, or nullptr
     uint32_t flags;      // bit 0 / 1: operand in / in2 already holds NTT-domain values
+    const u64 *lut;      // SRC_DIGITS / SRC_ZQBITS: the plan's digit tables (DevicePlan::digit_lut)
 };
 
 // what a forward kernel's load does besides loading

@@ -33,15 +33,17 @@ constexpr int fwd_bound_out(int R, int bin) {
     return b;
 }
 constexpr int kPassBound = 6;   // bound (in q) of what a forward strided pass hands to the contiguous pass
-template <int R, bool WIDE, int BIN = 6, bool TIGHT_LAST = false, bool END6 = false>
+// I0: the round's first I0 stages have been done by other means (the table look-ups of round0_bits):
+// run stages I0 .. R-1, BIN being the bound of what enters stage I0.
+template <int R, bool WIDE, int BIN = 6, bool TIGHT_LAST = false, bool END6 = false, int I0 = 0>
 __device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
                                           const Mod &m) {
     static_assert(BIN >= 1 && BIN <= 8, "input bound out of range");
 #pragma unroll
-    for (int i = 0; i < R; i++) {
+    for (int i = I0; i < R; i++) {
         const int span = 8 >> i;
         constexpr int kNone = 0;
-        const int bin_i = fwd_bound_out(i, BIN);                 // bound of this stage's inputs
+        const int bin_i = fwd_bound_out(i - I0, BIN);            // bound of this stage's inputs
         const bool corr = fwd_stage_needs_csub(bin_i) || (END6 && i == R - 1 && bin_i > 4);
         const bool tight = TIGHT_LAST && i == R - 1;             // bring x below 2q: x' and y' < 4q
 #ifdef FHE_ABLATE_NO_BUTTERFLIES   // timing-only build: memory pattern without the arithmetic
@@ -189,6 +191,62 @@ __device__ __forceinline__ void round_inv_sel(u64 (&v)[16], const Tw *__restrict
     else round_inv<R, FOLD>(v, tw, T0, m, ninv, s_ninv);
 }
 
+// ---- round 0 of a transform whose inputs are BITS (gadget digits, base 2) -------------------------
+// The first stages of the transform of a 0/1 polynomial need no multiplication at all: stages 0 and 1
+// act on the four registers {c, c+4, c+8, c+12} of a thread, whose 4 input bits select one of 16
+// possible outcomes — a table look-up (Y); stage 2 then adds / subtracts w * Y[..], which is again one
+// of 16 values per twiddle (WY).  Per thread that replaces 24 of the round's Shoup butterflies by 16
+// (R0 = 2) or 16 + 16 modular additions' worth of LDS reads.  Tables per plan, built on the host
+// (capi.hip: build_digit_lut), staged into LDS by the digit kernels:
+//   [0,64)    Y[p][j]    j-th output of stages 0,1 on the bit pattern p = x_c + 2 x_{c+4} + 4 x_{c+8} + 8 x_{c+12}
+//   [64,128)  WY[p][j]   roots[4+j] * Y[p][j]  (stage 2's twiddle for registers with k >> 2 = j)
+//   [128,136) Y1[p][h]   stage 0 alone on a pair: p = x + 2y -> (x + W0 y, x - W0 y)   (passes with R0 = 1)
+// All entries canonical, so the stages that follow start from bound 1.
+constexpr int kDigitLutWords = 136;
+
+template <int R0, bool WIDE, bool TIGHT>
+__device__ __forceinline__ void round0_bits(u64 (&v)[16], const u64 *lut, const Tw *__restrict__ gtw, const Mod &m) {
+    if constexpr (R0 == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 p = (u32)v[k] + 2u * (u32)v[k + 8];
+            const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(lut + 128 + 2 * p);
+            v[k] = y.x;
+            v[k + 8] = y.y;
+        }
+    } else {
+        u32 p[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) p[c] = (u32)v[c] + 2u * (u32)v[c + 4] + 4u * (u32)v[c + 8] + 8u * (u32)v[c + 12];
+        if constexpr (R0 == 2) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(lut + 4 * p[c]);
+                const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(lut + 4 * p[c] + 2);
+                v[c] = lo.x; v[c + 4] = lo.y; v[c + 8] = hi.x; v[c + 12] = hi.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                u64 a[4], b[4];
+                const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(lut + 4 * p[c]);
+                const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(lut + 4 * p[c] + 2);
+                const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(lut + 64 + 4 * p[c + 2]);
+                const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(lut + 64 + 4 * p[c + 2] + 2);
+                a[0] = a0.x; a[1] = a0.y; a[2] = a1.x; a[3] = a1.y;
+                b[0] = b0.x; b[1] = b0.y; b[2] = b1.x; b[3] = b1.y;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u64 s = a[j] + b[j];                       // both < q < 2^63
+                    v[c + 4 * j] = s >= m.q ? s - m.q : s;
+                    v[c + 2 + 4 * j] = a[j] >= b[j] ? a[j] - b[j] : a[j] + m.q - b[j];
+                }
+            }
+            if constexpr (R0 == 4) round_fwd<4, WIDE, 1, TIGHT, false, 3>(v, gtw, 1u, m);
+        }
+    }
+}
+
 // field value of register k for a thread whose non-register field bits are tf,
 // register window = field bits [A, A+4)
 template <int A>
@@ -265,6 +323,7 @@ struct ContigCfg {
     static constexpr int LTW_N = 1 << LTW_LOG;
     static constexpr size_t DATA_BYTES = (size_t)(TILE + TILE / 16) * 8;
     static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)LTW_N * sizeof(Tw);
+    static constexpr size_t LDS_BYTES_BITS = LDS_BYTES + (size_t)kDigitLutWords * 8;   // + the digit tables (BITS kernels)
     // window base of round j >= 1
     static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
     static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
@@ -293,18 +352,22 @@ __device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u
 // that do not fit it; s0 / blk place the block in the transform (0, 0: the pass is the transform).
 // BIN: bound (in q) of the inputs; TIGHT: this pass holds the transform's last stage, which then
 // leaves x', y' < 4q.  FRESH: nobody has read the LDS tile since the last barrier.
-template <int LP, bool WIDE, bool TIGHT, int BIN, bool FRESH>
+// BITS: the inputs are 0/1 and the pass is the whole transform (s0 = blk = 0): round 0 by table
+// look-up (round0_bits; `lut` = the plan's digit tables in LDS, already published).
+template <int LP, bool WIDE, bool TIGHT, int BIN, bool FRESH, bool BITS = false>
 __device__ __forceinline__ void fwd_rounds_contig(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
-                                                  u32 w, u32 tf, const Mod &m) {
+                                                  u32 w, u32 tf, const Mod &m, const u64 *lut = nullptr) {
     using C = ContigCfg<LP>;
     auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
     auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
         return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
     };
-    constexpr int B0 = BIN, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1), B3 = fwd_bound_out(4, B2);
+    constexpr int B0 = BIN, B1 = BITS ? (C::R0 == 4 ? fwd_bound_out(1, 1) : 1) : fwd_bound_out(C::R0, B0),
+                  B2 = fwd_bound_out(4, B1), B3 = fwd_bound_out(4, B2);
     // Round 0's twiddles are the same for the whole workgroup (H = 0): read from the global
     // table at a wave-uniform address (scalar loads, SGPR operands).
-    round_fwd<C::R0, WIDE, B0, TIGHT && C::NR == 1>(v, gtw, (1u << s0) + blk, m);
+    if constexpr (BITS) round0_bits<C::R0, WIDE, TIGHT && C::NR == 1>(v, lut, gtw, m);
+    else round_fwd<C::R0, WIDE, B0, TIGHT && C::NR == 1>(v, gtw, (1u << s0) + blk, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         constexpr bool L = C::in_lds(1);

@@ -19,9 +19,11 @@ def shard_range(batch, world, rank):
 
 def all_gather_rows(local_rows, batch, group=None):
     """local_rows: (b1-b0, n) int64 tensor of this rank's shard → (batch, n) on every rank.
-    Shards are padded to ceil(B/G) rows so that one all_gather_into_tensor moves them
-    (a single large collective per call: xGMI links are per-peer, so fewer/larger is
-    better than per-row traffic)."""
+    ONE all_gather_into_tensor per call (xGMI links are per-peer: fewer, larger collectives).
+    A full shard (every rank when batch % world == 0 — config 5: 8192 rows, 4 GiB per rank) is
+    sent as it is, no copy; only a rank whose block is short (the ragged tail: 77 of 79 rows
+    at 630 over 8) stages its rows in a ceil(B/G)-row buffer, because the collective needs
+    equal counts."""
     world = dist.get_world_size(group)
     per = -(-batch // world)
     n = local_rows.shape[1]

@@ -392,3 +392,43 @@ def test_fused_and_unfused_digit_paths_agree_at_bench_sizes(pkg):
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("ext", "ks"))])
     assert len(outs[0]) == 2 and outs[0] == outs[1]
+
+
+def test_two_devices_from_two_host_threads(pkg, oracle):
+    """INTEGRATION.md §5 as a C caller would do it: one host thread per device, hipSetDevice, the block
+    of fhe_shard_range, shared plan, per-device tables.  Needs two GPUs: skipped on a one-GPU box."""
+    import threading
+
+    import torch
+
+    B = pkg.binding
+    world = B.device_count()
+    if world < 2:
+        pytest.skip("needs >= 2 HIP devices (fhe_ntt_device_count() < 2)")
+    world = min(world, 8)
+    q, n, batch = Q61, 65536, 5 * world + 1
+    plan = pkg.Plan(q, n)                                   # shared by every thread
+    a = oracle.fill_synthetic(q, 0x5EED, 0, batch * n).reshape(batch, n)
+    want = oracle.ntt(q, n, a).reshape(batch, n)
+    got, errs = [None] * world, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(r)                        # hipSetDevice for this host thread
+            b0, b1 = B.shard_range(batch, world, r)
+            B._check(pkg.load_library().fhe_ntt_plan_prepare(plan.handle))
+            x = torch.from_numpy(a[b0:b1].view(np.int64).copy()).to(f"cuda:{r}")
+            y = torch.empty_like(x)
+            plan.forward_dev(x.data_ptr(), y.data_ptr(), b1 - b0, torch.cuda.current_stream(r).cuda_stream)
+            torch.cuda.synchronize(r)
+            got[r] = _u64(y).reshape(b1 - b0, n)
+        except Exception as e:                              # noqa: BLE001 - reported below
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert np.array_equal(np.concatenate(got), want)

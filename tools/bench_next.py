@@ -40,18 +40,22 @@ def bfv(n=8192, q=65537, t=2, batch=256):
           f"{batch/dt:,.0f} ct-mul/s   (oracle schoolbook, 1 core: {1/cpu:.2f} ct-mul/s)  parity={ok}")
 
 
-def extprod(n=1024, k=1, l=64, batch=630):
+def extprod(n=1024, k=1, l=64, batch=630, prepared=False):
     rng = np.random.default_rng(2)
     g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).to(dev)
     c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (batch, k + 1, n), dtype=np.int64)).to(dev)
     out = torch.empty_like(c)
     f = lambda: B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), out.data_ptr(), batch, st))
+    if prepared:   # the key in its resident form (fhe_tggsw_prepare_dev once, then every product batch)
+        prep = torch.empty(L.fhe_tggsw_prepared_words(n, k, l), dtype=torch.int64, device=dev)
+        B._check(L.fhe_tggsw_prepare_dev(n, k, l, g.data_ptr(), prep.data_ptr(), st))
+        f = lambda: B._check(L.fhe_tggsw_external_product_prepared_dev(n, k, l, prep.data_ptr(), c.data_ptr(), out.data_ptr(), batch, st))
     dt = timeit(f)
     t0 = time.perf_counter()
     w = O.external_product(n, k, l, g.cpu().numpy().view(np.uint64), c[:1].cpu().numpy().view(np.uint64))
     cpu = time.perf_counter() - t0
     ok = np.array_equal(out[0].cpu().numpy().view(np.uint64), w[0])
-    print(f"TGGSW x TGLWE external product  N={n} k={k} l={l}  batch={batch}: {dt*1e3:.2f} ms  "
+    print(f"TGGSW x TGLWE external product{' (prepared key)' if prepared else ''}  N={n} k={k} l={l}  batch={batch}: {dt*1e3:.3f} ms  "
           f"{batch/dt:,.0f} products/s   (oracle schoolbook, 1 core: {1/cpu:.2f}/s)  parity={ok}")
 
 
@@ -76,7 +80,7 @@ def key_switch(n=4096, k=1, beta=2, l=61, batch=256, q=pkg.Q61, resident_key=Fal
     cpu = time.perf_counter() - t0
     ok = np.array_equal(out[0].cpu().numpy().view(np.uint64), want)
     print(f"GLWE key switch  N={n} k={k} beta={beta} l={l} q~2^{q.bit_length()} batch={batch}"
-          f"{' (key resident in NTT domain)' if resident_key else ''}: {dt*1e3:.2f} ms  {batch/dt:,.0f} switches/s   "
+          f"{' (key resident in NTT domain)' if resident_key else ''}: {dt*1e3:.3f} ms  {batch/dt:,.0f} switches/s   "
           f"(oracle, NTT products on 1 core: {1/cpu:.1f}/s)  parity={ok}")
 
 
@@ -84,10 +88,14 @@ if __name__ == "__main__":
     bfv()
     bfv(batch=2048)          # same work per ciphertext; launch gaps amortised
     extprod()
+    extprod(prepared=True)
     key_switch()
     key_switch(resident_key=True)
     key_switch(batch=1)
     key_switch(batch=1, resident_key=True)
     B.kernel_timing_reset(); B.kernel_timing_enable(True)
-    extprod(batch=630)
+    extprod(batch=630, prepared=True)
+    print({k: (round(v[0], 3), v[1]) for k, v in B.kernel_timing_read().items()})
+    B.kernel_timing_reset()
+    key_switch(resident_key=True)
     print({k: (round(v[0], 3), v[1]) for k, v in B.kernel_timing_read().items()})

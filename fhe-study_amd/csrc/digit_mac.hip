@@ -32,14 +32,27 @@
 
 namespace fhe {
 
-template <int LP>
+// Workgroup shape.  The multiply phase gives every thread M/TH coefficient positions of all NC output
+// rows: NC * M/TH accumulators of 128 bits (4 VGPRs each) live across the whole digit loop, next to the
+// 16 coefficients and the temporaries of the transform rounds.  Measured at n = 1024, NC = 4 (630 external
+// products): 256 threads = 16 accumulators = 192 VGPRs = 2 waves per SIMD: 548 us; forced into 168 VGPRs
+// (3 waves, 21 spilled): 584 us.  So the workgroup grows instead: TH = NC * M / 8 threads (256 .. 1024)
+// keep 8 accumulators per thread, the kernel fits 128 VGPRs and a SIMD holds 4 waves.  More threads also
+// mean more units — digit polynomials transformed side by side — per step: W = TH / (M/16).
+template <int LP, int NC>
 struct DigitMacCfg {
     using C = ContigCfg<LP>;
-    static constexpr int TH = 256;
-    static constexpr int PPT = C::M / TH;               // coefficient positions a thread owns in the multiply phase
+    static constexpr int M = C::M, TPB = C::TPB;
+    static constexpr int TH_WANT = (NC <= 2 ? 2 : 4) * M / 8;     // a power of two
+    static constexpr int TH = TH_WANT < 256 ? 256 : (TH_WANT > 1024 ? 1024 : TH_WANT);
+    static constexpr int W = TH / TPB;                  // units (digit polynomials) per step
+    static constexpr int PPT = M / TH;                  // coefficient positions a thread owns in the multiply phase
+    static constexpr int ACC = NC * PPT;
     static constexpr int CHUNK = 32;                    // terms between reductions of an accumulator
-    static_assert(LP >= 8 && LP <= 12, "tile of 4096 coefficients, 256 threads");
-    static_assert(C::TH == TH, "one workgroup shape");
+    static constexpr size_t DATA_BYTES = (size_t)(W * M + W * M / 16) * 8;      // the padded tile of pad16()
+    static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)C::LTW_N * sizeof(Tw) + (size_t)kDigitLutWords * 8;
+    static_assert(LP >= 8 && LP <= 12, "256 .. 4096 coefficients");
+    static_assert(TH % TPB == 0 && M % TH == 0, "whole units, whole positions");
 };
 
 // digit d (0 = most significant) of a source word
@@ -52,26 +65,24 @@ __device__ __forceinline__ u64 digit_of(u64 x, u32 l, u32 d) {
     return x >= sat ? 1ull : (x >> (l - 1u - d)) & 1ull;
 }
 
-// MW: waves per SIMD the register allocation must admit (2: up to 256 VGPRs, 3: 168).  Registers: 4 per
-// accumulator + the 16 coefficients + the round's temporaries.
-template <int LP, int SRC, int NC, int MW>
-__global__ __launch_bounds__(256, MW) void digit_mac_kernel(DigitMacArgs a) {
+template <int LP, int SRC, int NC>
+__global__ __launch_bounds__((DigitMacCfg<LP, NC>::TH), 4) void digit_mac_kernel(DigitMacArgs a) {
     using C = ContigCfg<LP>;
-    using K = DigitMacCfg<LP>;
-    constexpr int PPT = K::PPT, W = C::W;
-    static_assert(NC * PPT <= 32, "accumulators must fit the register file");
+    using K = DigitMacCfg<LP, NC>;
+    constexpr int PPT = K::PPT, W = K::W, TH = K::TH;
+    static_assert(K::ACC <= 8, "accumulators must fit the register file");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
-    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + K::DATA_BYTES);
     const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
     const u64 b = blockIdx.x / a.parts;
     const u32 part = blockIdx.x % a.parts;
     const u32 t_begin = part * a.tpp, t_end = min(a.T, t_begin + a.tpp);
     const Mod &m = a.mod;
     const u32 n = 1u << LP;
-    stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, 0u, 0u, tid);
+    stage_twiddles<C::LTW_N, TH>(ltw, a.tw, 0u, 0u, tid);
     u64 *llut = reinterpret_cast<u64 *>(ltw + C::LTW_N);          // digit tables: round 0 is look-ups (round0_bits)
-    for (u32 i = tid; i < (u32)kDigitLutWords; i += C::TH) llut[i] = a.lut[i];
+    for (u32 i = tid; i < (u32)kDigitLutWords; i += TH) llut[i] = a.lut[i];
     __syncthreads();
     const u64 *__restrict__ ct = a.src + b * a.ct_stride;
 
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(256, MW) void digit_mac_kernel(DigitMacArgs a) {
         __syncthreads();
         // ---- multiply-accumulate: W transforms x NC key rows at this thread's PPT positions ----
         const u32 nu = min((u32)W, t_end - t0);
-#pragma unroll
+#pragma unroll 4
         for (int u = 0; u < W; u++) {
             if ((u32)u < nu) {
                 u64 x[PPT];
@@ -153,6 +164,88 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const u64 *__restrict__ 
     }
 }
 
+// ---- the tail: add the parts, inverse transform, finish — one kernel ---------------------------------
+// Row R = (ciphertext b, output row c) of the accumulated sums: S[b][c] = sum_p partial[b][p][c] (canonical
+// adds in the load), the LP inverse stages with the n^-1 scaling folded in, then
+//   EPI_KS     out[b][c] = (c < k ? 0 : glwe[b][c]) - S[b][c]  mod q      GLWE::key_switch's tail, glwe.rs:129-136
+//   EPI_TORUS  out[b][c] = lift(S[b][c]) + (lift(S[b][k1 + c]) << 32)      the two 32-bit key halves recombined
+//              mod 2^64, lift = the centred representative mod P1 (zr_combine32_kernel); the two rows meet
+//              through the LDS tile, so a workgroup must hold whole ciphertexts: W % nc == 0.
+// Replaces sum_parts_kernel + ntt_inv_contig_kernel + ks_tail_kernel / zr_combine32_kernel.
+enum : int { EPI_KS = 0, EPI_TORUS = 1 };
+
+template <int LP, int EPI>
+__global__ __launch_bounds__(256) void digit_tail_kernel(DigitTailArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u64 rows = a.batch * a.nc;
+    const u64 R0 = (u64)blockIdx.x * C::W;
+    const u32 live = (u32)min((u64)C::W, rows - R0);
+    const bool active = w < live;
+    const u64 R = R0 + (active ? w : 0u);                       // idle units redo the first row and store nothing
+    const u64 b = R / a.nc;
+    const u32 c = (u32)(R - b * a.nc);
+    const u32 n = 1u << LP;
+    const Mod &m = a.mod;
+    stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, 0u, 0u, tid);
+
+    // window [0,4): 16 consecutive NTT-domain values per thread, summed over the parts
+    u64 v[16];
+    {
+        const u64 *__restrict__ src = a.partial + ((b * a.parts) * a.nc + c) * (u64)n + tf * 16u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(src + 2 * j);
+            v[2 * j] = x.x;
+            v[2 * j + 1] = x.y;
+        }
+        for (u32 p = 1; p < a.parts; p++) {
+            const u64 *__restrict__ sp = src + (u64)p * a.nc * n;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(sp + 2 * j);
+                u64 s0 = v[2 * j] + x.x, s1 = v[2 * j + 1] + x.y;
+                v[2 * j] = s0 >= m.q ? s0 - m.q : s0;
+                v[2 * j + 1] = s1 >= m.q ? s1 - m.q : s1;
+            }
+        }
+    }
+    __syncthreads();                                             // the twiddle tile
+    inv_rounds_contig<LP, true, true, true>(v, lds, ltw, a.tw, 0u, 0u, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (EPI == EPI_KS) {
+        if (active) {
+            const u64 base = (b * a.nc + c) * (u64)n;
+            const bool body = c >= a.k;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 pos = field_of<C::A0>(tf, k);
+                const u64 y = canon2(v[k], m);
+                const u64 x = body ? a.src[base + pos] : 0ull;
+                a.out[base + pos] = x >= y ? x - y : x + m.q - y;
+            }
+        }
+    } else {
+        // natural positions into the tile (the last exchange was gathered from it by every thread: barrier first)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[pad16(w * C::M + field_of<C::A0>(tf, k))] = canon2(v[k], m);
+        __syncthreads();
+        const u32 k1 = a.nc / 2;
+        const u32 cts = live / a.nc;                              // whole ciphertexts in this workgroup
+        const u64 b0 = R0 / a.nc;
+        for (u32 e = tid; e < cts * k1 * n; e += 256) {
+            const u32 j = e & (n - 1), cc = (e >> LP) % k1, bb = (e >> LP) / k1;
+            u64 lo = lds[pad16((bb * a.nc + cc) * C::M + j)], hi = lds[pad16((bb * a.nc + k1 + cc) * C::M + j)];
+            if (lo >= a.half1) lo -= m.q;                          // centred lift, two's complement
+            if (hi >= a.half1) hi -= m.q;
+            a.out[((b0 + bb) * k1 + cc) * (u64)n + j] = lo + (hi << 32);
+        }
+    }
+}
+
 static inline unsigned dm_ew_grid(u64 count) {
     u64 g = (count + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -161,23 +254,15 @@ static inline unsigned dm_ew_grid(u64 count) {
 
 template <int LP, int SRC, int NC>
 static hipError_t launch_dm(const DigitMacArgs &a, hipStream_t st) {
-    using C = ContigCfg<LP>;
-    if constexpr (NC * DigitMacCfg<LP>::PPT > 32) {
+    using K = DigitMacCfg<LP, NC>;
+    if constexpr (K::ACC > 8) {      // n = 4096 with 4 output rows: 16 accumulators at 1024 threads spill 100 VGPRs
         return hipErrorNotSupported;
     } else {
         const u64 grid = a.batch * a.parts;
         if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-        // 3 waves per SIMD up to 16 accumulators per thread (measured); FHE_DIGIT_MAC_WAVES=2|3 for A/B runs
-        static const int waves_env = [] { const char *e = getenv("FHE_DIGIT_MAC_WAVES"); return e ? atoi(e) : 0; }();
-        const int mw = waves_env == 2 || waves_env == 3 ? waves_env : (NC * DigitMacCfg<LP>::PPT <= 16 ? 3 : 2);
+        if (hipError_t e = allow_big_lds((const void *)digit_mac_kernel<LP, SRC, NC>, K::LDS_BYTES)) return e;
         KernelTimer kt(SRC == SRC_DIGITS ? "digit_mac_torus" : "digit_mac_zq", LP, st);
-        if (mw == 3) {
-            if (hipError_t e = allow_big_lds((const void *)digit_mac_kernel<LP, SRC, NC, 3>, C::LDS_BYTES_BITS)) return e;
-            hipLaunchKernelGGL((digit_mac_kernel<LP, SRC, NC, 3>), dim3((unsigned)grid), dim3(256), C::LDS_BYTES_BITS, st, a);
-        } else {
-            if (hipError_t e = allow_big_lds((const void *)digit_mac_kernel<LP, SRC, NC, 2>, C::LDS_BYTES_BITS)) return e;
-            hipLaunchKernelGGL((digit_mac_kernel<LP, SRC, NC, 2>), dim3((unsigned)grid), dim3(256), C::LDS_BYTES_BITS, st, a);
-        }
+        hipLaunchKernelGGL((digit_mac_kernel<LP, SRC, NC>), dim3((unsigned)grid), dim3(K::TH), K::LDS_BYTES, st, a);
         return hipGetLastError();
     }
 }
@@ -194,9 +279,20 @@ static hipError_t launch_dm_lp(int lp, const DigitMacArgs &a, hipStream_t st) {
     return hipErrorNotSupported;
 }
 
-uint32_t digit_mac_parts(u64 batch, uint32_t T, uint32_t log_n) {
+// units per step of the kernel that (log_n, nc) selects; 0: no fused kernel for this shape
+static uint32_t dm_units(uint32_t log_n, uint32_t nc) {
+    if (log_n < 8 || log_n > 12 || nc < 2 || nc > 4) return 0;
+    const uint32_t M = 1u << log_n, tpb = M / 16;
+    uint32_t th = (nc <= 2 ? 2u : 4u) * M / 8;
+    th = th < 256 ? 256 : (th > 1024 ? 1024 : th);
+    if (nc * (M / th) > 8) return 0;
+    return th / tpb;
+}
+
+uint32_t digit_mac_parts(u64 batch, uint32_t T, uint32_t log_n, uint32_t nc) {
     // enough workgroups to fill 256 CUs several times over, but at least two steps per workgroup
-    const uint32_t W = log_n >= 12 ? 1u : 1u << (12 - log_n);
+    const uint32_t W = dm_units(log_n, nc);
+    if (!W) return 1;
     uint32_t parts = 1;
     while (parts < 8 && batch * parts < 2048 && (T / (parts * 2)) >= 2 * W) parts *= 2;
     return parts;
@@ -207,16 +303,12 @@ hipError_t launch_digit_mac(const DevicePlan &p, int src_kind, const u64 *src, u
     const int L = p.log_n;
     if (L < 8 || L > 12 || !p.wide || l == 0 || l > 64 || rows == 0 || parts == 0 || !p.digit_lut) return hipErrorNotSupported;
     if (src_kind == SRC_ZQBITS && p.mod.q < 3) return hipErrorNotSupported;
-    // Beyond 16 accumulators per thread (n = 4096 with 2 output rows, n = 2048 with 4) the kernel holds 2 waves
-    // per SIMD and measured slower than transform-then-accumulate (key switch, n = 4096: 0.60 vs 0.49 ms per 256):
-    // those shapes keep the two-kernel form.  FHE_DIGIT_MAC_MAXACC overrides the limit for A/B runs.
-    static const uint32_t max_acc = [] { const char *e = getenv("FHE_DIGIT_MAC_MAXACC"); return e ? (uint32_t)atoi(e) : 16u; }();
-    if (nc * ((1u << L) / 256u) > max_acc) return hipErrorNotSupported;
+    const uint32_t W = dm_units((uint32_t)L, nc);
+    if (!W) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     DigitMacArgs a{};
     a.src = src; a.key = key; a.out = partial; a.tw = p.tw_fwd; a.lut = p.digit_lut; a.mod = p.mod;
     a.batch = batch; a.ct_stride = ct_stride; a.l = l; a.T = rows * l; a.parts = parts;
-    const uint32_t W = L >= 12 ? 1u : 1u << (12 - L);
     a.tpp = ((a.T + parts - 1) / parts + W - 1) / W * W;           // whole steps per part
     if (src_kind == SRC_DIGITS) {
         if (nc == 2) return launch_dm_lp<SRC_DIGITS, 2>(L, a, st);
@@ -226,6 +318,47 @@ hipError_t launch_digit_mac(const DevicePlan &p, int src_kind, const u64 *src, u
         if (nc == 3) return launch_dm_lp<SRC_ZQBITS, 3>(L, a, st);
     }
     return hipErrorNotSupported;
+}
+
+template <int EPI>
+static hipError_t launch_tail_lp(int lp, const DigitTailArgs &a, hipStream_t st) {
+    const u64 rows = a.batch * a.nc;
+    switch (lp) {
+#define X(LP_)                                                                                              \
+    case LP_: {                                                                                             \
+        using C = ContigCfg<LP_>;                                                                           \
+        if (EPI == EPI_TORUS && (C::W % a.nc) != 0) return hipErrorNotSupported;                            \
+        const u64 grid = (rows + C::W - 1) / C::W;                                                          \
+        if (grid > 0x7fffffffull) return hipErrorInvalidValue;                                              \
+        if (hipError_t e = allow_big_lds((const void *)digit_tail_kernel<LP_, EPI>, C::LDS_BYTES)) return e; \
+        KernelTimer kt(EPI == EPI_KS ? "digit_tail_ks" : "digit_tail_torus", LP_, st);                       \
+        hipLaunchKernelGGL((digit_tail_kernel<LP_, EPI>), dim3((unsigned)grid), dim3(256), C::LDS_BYTES, st, a); \
+        return hipGetLastError();                                                                           \
+    }
+        X(8) X(9) X(10) X(11) X(12)
+#undef X
+    }
+    return hipErrorNotSupported;
+}
+
+hipError_t launch_digit_tail_ks(const DevicePlan &p, const u64 *partial, uint32_t parts, uint32_t k, const u64 *glwe, u64 *out,
+                                u64 batch, hipStream_t st) {
+    if (p.log_n < 8 || p.log_n > 12 || !p.wide) return hipErrorNotSupported;
+    if (batch == 0) return hipSuccess;
+    DigitTailArgs a{};
+    a.partial = partial; a.src = glwe; a.out = out; a.tw = p.tw_inv; a.mod = p.mod; a.ninv = p.ninv; a.s_ninv = p.s_ninv;
+    a.batch = batch; a.parts = parts; a.nc = k + 1; a.k = k;
+    return launch_tail_lp<EPI_KS>(p.log_n, a, st);
+}
+
+hipError_t launch_digit_tail_torus(const DevicePlan &p, const u64 *partial, uint32_t parts, uint32_t k1, u64 half1, u64 *out,
+                                   u64 batch, hipStream_t st) {
+    if (p.log_n < 8 || p.log_n > 12 || !p.wide) return hipErrorNotSupported;
+    if (batch == 0) return hipSuccess;
+    DigitTailArgs a{};
+    a.partial = partial; a.out = out; a.tw = p.tw_inv; a.mod = p.mod; a.ninv = p.ninv; a.s_ninv = p.s_ninv;
+    a.batch = batch; a.parts = parts; a.nc = 2 * k1; a.k = k1; a.half1 = half1;
+    return launch_tail_lp<EPI_TORUS>(p.log_n, a, st);
 }
 
 hipError_t launch_sum_parts(const u64 *partial, u64 *out, u64 batch, uint32_t parts, u64 row_words, u64 q, hipStream_t st) {

@@ -390,8 +390,8 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     // Base 2 at 2^8 <= n <= 2^12: decomposition, digit transforms and the multiply-accumulate against the
     // key are ONE kernel (digit_mac.hip): RHS[b][c] = sum_t KSK[t][c] (.) NTT(digit_t(b)), nothing else stored.
     static const bool fused_on = [] { const char *e = getenv("FHE_DIGIT_MAC_FUSED"); return !(e && e[0] == '0'); }();
-    if (beta == 2 && fused_on && dp.wide && dp.log_n >= 8 && dp.log_n <= 12 && (k1 == 2 || k1 == 3) && k1 * (n / 256) <= 32) {
-        const u32 parts = fhe::digit_mac_parts(batch, T, dp.log_n);
+    if (beta == 2 && fused_on && dp.wide && dp.log_n >= 8 && dp.log_n <= 12 && (k1 == 2 || k1 == 3)) {
+        const u32 parts = fhe::digit_mac_parts(batch, T, dp.log_n, k1);
         // [key transforms: T*k1 rows] [rhs: batch*k1 rows] [partial sums: parts*batch*k1 rows]
         if ((rc = fhe_workspace_get(1, ((u64)T * k1 + (u64)(parts + 1) * batch * k1) * n * 8, st, &w)) != FHE_OK) return rc;
         u64 *KEY = (u64 *)w, *RHS = KEY + (u64)T * k1 * n, *PART = parts > 1 ? RHS + batch * k1 * n : RHS;
@@ -399,6 +399,11 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
         if (!(flags & FHE_A_IS_EVALS)) { if ((rc = fwd(plan, dp, key, KEY, (u64)T * k1, st)) != FHE_OK) return rc; key = KEY; }
         hipError_t e = fhe::launch_digit_mac(dp, fhe::SRC_ZQBITS, (const u64 *)d_glwe, (u64)k1 * n, k, l, key, k1, PART, parts, batch, st);
         if (e == hipSuccess) {
+            // sum of the parts, the k+1 inverse transforms and (0, b) - rhs (glwe.rs:129-136) in one kernel
+            e = fhe::launch_digit_tail_ks(dp, PART, parts, k, (const u64 *)d_glwe, (u64 *)d_out, batch, st);
+            if (e == hipSuccess) return FHE_OK;
+            if (e != hipErrorNotSupported) return fhe_hip_fail(e, "digit_tail_kernel");
+            (void)hipGetLastError();
             if (parts > 1 && (e = fhe::launch_sum_parts(PART, RHS, batch, parts, (u64)k1 * n, plan->q, st)) != hipSuccess)
                 return fhe_hip_fail(e, "sum_parts_kernel");
             if ((rc = inv(plan, dp, RHS, RHS, batch * k1, st)) != FHE_OK) return rc;

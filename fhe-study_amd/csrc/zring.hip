@@ -563,12 +563,18 @@ extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, u
     // Fused form: digit extraction, forward transform and multiply-accumulate in one kernel
     // (digit_mac.hip); the digit transforms never reach memory.  R[b][half][c] = sum_t G2[t][half][c] * NTT(digit_t(b)).
     static const bool fused_on = [] { const char *e = getenv("FHE_DIGIT_MAC_FUSED"); return !(e && e[0] == '0'); }();
-    const u32 parts = fhe::digit_mac_parts(batch, (u32)T, z1.dp[0].log_n);
+    const u32 parts = fhe::digit_mac_parts(batch, (u32)T, z1.dp[0].log_n, 2 * k1);
     if (fused_on) {
         if ((rc = fhe_workspace_get(1, ((u64)parts + 1) * 2 * orows * n * 8, st, &wsv)) != FHE_OK) return rc;
         u64 *R = (u64 *)wsv, *PART = parts > 1 ? R + 2 * orows * n : R;
         hipError_t e = fhe::launch_digit_mac(z1.dp[0], fhe::SRC_DIGITS, (const u64 *)d_tglwe, (u64)k1 * n, k1, l, G2, 2 * k1, PART, parts, batch, st);
         if (e == hipSuccess) {
+            // sum of the parts, the 2(k+1) inverse transforms and the recombination of the halves: one kernel
+            // where a workgroup holds whole ciphertexts (4096/n >= 2(k+1) rows), three otherwise
+            e = fhe::launch_digit_tail_torus(z1.dp[0], PART, parts, k1, z1.cc.half1, (u64 *)d_out, batch, st);
+            if (e == hipSuccess) return FHE_OK;
+            if (e != hipErrorNotSupported) return fhe_hip_fail(e, "digit_tail_kernel");
+            (void)hipGetLastError();
             if (parts > 1 && (e = fhe::launch_sum_parts(PART, R, batch, parts, 2ull * k1 * n, z1.cc.m[0].q, st)) != hipSuccess)
                 return fhe_hip_fail(e, "sum_parts_kernel");
             if ((rc = z_inverse(z1, 0, R, R, 2 * orows, st)) != FHE_OK) return rc;

@@ -32,22 +32,25 @@
 
 namespace fhe {
 
-// Workgroup shape.  The multiply phase gives every thread M/TH coefficient positions of all NC output
-// rows: NC * M/TH accumulators of 128 bits (4 VGPRs each) live across the whole digit loop, next to the
-// 16 coefficients and the temporaries of the transform rounds.  Measured at n = 1024, NC = 4 (630 external
-// products): 256 threads = 16 accumulators = 192 VGPRs = 2 waves per SIMD: 548 us; forced into 168 VGPRs
-// (3 waves, 21 spilled): 584 us.  So the workgroup grows instead: TH = NC * M / 8 threads (256 .. 1024)
-// keep 8 accumulators per thread, the kernel fits 128 VGPRs and a SIMD holds 4 waves.  More threads also
-// mean more units — digit polynomials transformed side by side — per step: W = TH / (M/16).
+// Workgroup shape: 256 threads = W = 4096/n units (digit polynomials transformed side by side per step); in the
+// multiply phase every thread owns PPT = n/256 coefficient positions of all NC output rows: NC * PPT accumulators of
+// 128 bits (4 VGPRs each) live across the whole digit loop, next to the 16 coefficients and the temporaries of the
+// transform rounds.  Measured (630 external products, n = 1024, NC = 4: 16 accumulators):
+//   256 threads, 192 VGPRs, 2 waves per SIMD                                   548 us   <- this form
+//   the same forced into 168 VGPRs (3 waves per SIMD, 21 registers spilled)     584 us
+//   512 threads, 8 accumulators, 128 VGPRs (4 waves per SIMD, 25 spilled)       626 us
+//   transform kernel + separate multiply-accumulate kernel (round 1's form)     330 + ~200 us
+// and with 32 accumulators (n = 4096, NC = 2: key switching) the fused kernel is SLOWER than the two-kernel form
+// (0.52-0.56 vs 0.46 ms per 256 ciphertexts), so shapes beyond 16 accumulators keep the two kernels.
 template <int LP, int NC>
 struct DigitMacCfg {
     using C = ContigCfg<LP>;
     static constexpr int M = C::M, TPB = C::TPB;
-    static constexpr int TH_WANT = (NC <= 2 ? 2 : 4) * M / 8;     // a power of two
-    static constexpr int TH = TH_WANT < 256 ? 256 : (TH_WANT > 1024 ? 1024 : TH_WANT);
+    static constexpr int TH = 256;
     static constexpr int W = TH / TPB;                  // units (digit polynomials) per step
     static constexpr int PPT = M / TH;                  // coefficient positions a thread owns in the multiply phase
     static constexpr int ACC = NC * PPT;
+    static constexpr int MAX_ACC = 16;
     static constexpr int CHUNK = 32;                    // terms between reductions of an accumulator
     static constexpr size_t DATA_BYTES = (size_t)(W * M + W * M / 16) * 8;      // the padded tile of pad16()
     static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)C::LTW_N * sizeof(Tw) + (size_t)kDigitLutWords * 8;
@@ -66,11 +69,11 @@ __device__ __forceinline__ u64 digit_of(u64 x, u32 l, u32 d) {
 }
 
 template <int LP, int SRC, int NC>
-__global__ __launch_bounds__((DigitMacCfg<LP, NC>::TH), 4) void digit_mac_kernel(DigitMacArgs a) {
+__global__ __launch_bounds__((DigitMacCfg<LP, NC>::TH)) void digit_mac_kernel(DigitMacArgs a) {
     using C = ContigCfg<LP>;
     using K = DigitMacCfg<LP, NC>;
     constexpr int PPT = K::PPT, W = K::W, TH = K::TH;
-    static_assert(K::ACC <= 8, "accumulators must fit the register file");
+    static_assert(K::ACC <= K::MAX_ACC, "accumulators must fit the register file");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + K::DATA_BYTES);
@@ -107,7 +110,7 @@ __global__ __launch_bounds__((DigitMacCfg<LP, NC>::TH), 4) void digit_mac_kernel
         __syncthreads();
         // ---- multiply-accumulate: W transforms x NC key rows at this thread's PPT positions ----
         const u32 nu = min((u32)W, t_end - t0);
-#pragma unroll 4
+#pragma unroll
         for (int u = 0; u < W; u++) {
             if ((u32)u < nu) {
                 u64 x[PPT];
@@ -255,7 +258,7 @@ static inline unsigned dm_ew_grid(u64 count) {
 template <int LP, int SRC, int NC>
 static hipError_t launch_dm(const DigitMacArgs &a, hipStream_t st) {
     using K = DigitMacCfg<LP, NC>;
-    if constexpr (K::ACC > 8) {      // n = 4096 with 4 output rows: 16 accumulators at 1024 threads spill 100 VGPRs
+    if constexpr (K::ACC > K::MAX_ACC) {
         return hipErrorNotSupported;
     } else {
         const u64 grid = a.batch * a.parts;
@@ -282,11 +285,9 @@ static hipError_t launch_dm_lp(int lp, const DigitMacArgs &a, hipStream_t st) {
 // units per step of the kernel that (log_n, nc) selects; 0: no fused kernel for this shape
 static uint32_t dm_units(uint32_t log_n, uint32_t nc) {
     if (log_n < 8 || log_n > 12 || nc < 2 || nc > 4) return 0;
-    const uint32_t M = 1u << log_n, tpb = M / 16;
-    uint32_t th = (nc <= 2 ? 2u : 4u) * M / 8;
-    th = th < 256 ? 256 : (th > 1024 ? 1024 : th);
-    if (nc * (M / th) > 8) return 0;
-    return th / tpb;
+    const uint32_t M = 1u << log_n;
+    if (nc * (M / 256) > 16) return 0;
+    return 4096 / M;
 }
 
 uint32_t digit_mac_parts(u64 batch, uint32_t T, uint32_t log_n, uint32_t nc) {

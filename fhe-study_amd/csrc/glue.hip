@@ -176,8 +176,10 @@ static int ew_call(const fhe_ntt_plan *plan, const void *a, const void *b, void 
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     const u64 count = batch * plan->n;
+    { fhe::KernelTimer kt_("ew", 0, (hipStream_t)stream);
     hipLaunchKernelGGL((fhe::ew_kernel<OP>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (const u64 *)a,
                        (const u64 *)b, (u64 *)c, count, plan->mod, s);
+    }
     LAUNCH_OK(who);
     return FHE_OK;
 }
@@ -200,7 +202,9 @@ extern "C" int fhe_rq_mod_switch_dev(uint64_t q, uint64_t p, const void *d_a, vo
     if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mod_switch_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("mod_switch", 0, (hipStream_t)st);
     hipLaunchKernelGGL(fhe::mod_switch_kernel, dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)p);
+    }
     LAUNCH_OK("mod_switch_kernel");
     return FHE_OK;
 }
@@ -210,7 +214,9 @@ extern "C" int fhe_rq_mul_div_round_dev(uint64_t q, uint64_t num, uint64_t den, 
     if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mul_div_round_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("rq_mul_div_round", 0, (hipStream_t)st);
     hipLaunchKernelGGL(fhe::rq_mul_div_round_kernel, dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)num, (u64)den);
+    }
     LAUNCH_OK("rq_mul_div_round_kernel");
     return FHE_OK;
 }
@@ -220,7 +226,9 @@ extern "C" int fhe_rq_remodule_dev(uint64_t p, const void *d_a, void *d_c, size_
     if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_remodule_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("ewf", 0, (hipStream_t)st);
     hipLaunchKernelGGL((fhe::ewf_kernel<fhe::EwF::Remodule>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)p, (u64)0, 0.0);
+    }
     LAUNCH_OK("ewf_kernel<Remodule>");
     return FHE_OK;
 }
@@ -230,7 +238,9 @@ extern "C" int fhe_rq_mul_by_f64_dev(uint64_t q, double s, const void *d_a, void
     if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_mul_by_f64_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("ewf", 0, (hipStream_t)st);
     hipLaunchKernelGGL((fhe::ewf_kernel<fhe::EwF::MulF64>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)0, s);
+    }
     LAUNCH_OK("ewf_kernel<MulF64>");
     return FHE_OK;
 }
@@ -241,7 +251,9 @@ extern "C" int fhe_rq_div_round_dev(uint64_t q, uint64_t s, const void *d_a, voi
     if (!d_a || !d_c) return fhe_fail(FHE_E_NULL, "fhe_rq_div_round_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("ewf", 0, (hipStream_t)st);
     hipLaunchKernelGGL((fhe::ewf_kernel<fhe::EwF::DivRound>), dim3(fhe_ew_grid(count)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_c, (u64)count, (u64)q, (u64)s, 0.0);
+    }
     LAUNCH_OK("ewf_kernel<DivRound>");
     return FHE_OK;
 }
@@ -271,7 +283,9 @@ extern "C" int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsig
     if (!d_a || !d_out) return fhe_fail(FHE_E_NULL, "fhe_rq_decompose_dev: NULL buffer");
     int dev, rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("decompose", 0, (hipStream_t)st);
     hipLaunchKernelGGL(fhe::decompose_kernel, dim3(fhe_ew_grid(rows * n)), dim3(256), 0, (hipStream_t)st, (const u64 *)d_a, (u64 *)d_out, (u64)rows, (u32)n, (u64)q, (u32)beta, (u32)l, (u32)1, (u64)n);
+    }
     LAUNCH_OK("decompose_kernel");
     return FHE_OK;
 }
@@ -306,7 +320,9 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     if (!b_ev) { if ((rc = fwd(plan, dp, B, WB, rows, st)) != FHE_OK) return rc; B = WB; }
     u64 *C = out_ev ? (u64 *)d_c : WC;
     // T = k terms, nc = 1 output row, "G" = A per batch element
+    { fhe::KernelTimer kt_("mac_rows", 0, st);
     hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, 1, n))), dim3(256), 0, st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
+    }
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_c, batch, st);
 }
@@ -332,7 +348,9 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     if (!p_ev) { if ((rc = fwd(plan, dp, P, WP, batch, st)) != FHE_OK) return rc; P = WP; }
     u64 *C = out_ev ? (u64 *)d_out : WC;
     // T = 1, nc = rows: out[b][c] = A[b][c] * P[b]
+    { fhe::KernelTimer kt_("mac_rows", 0, st);
     hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, rows, n))), dim3(256), 0, st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
+    }
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_out, total, st);
 }
@@ -346,7 +364,9 @@ static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const 
     int rc;
     if (!key_is_evals) { if ((rc = fwd(plan, dp, d_key, WK, (u64)T * nc, st)) != FHE_OK) return rc; K = WK; }
     if (!v_is_evals) { if ((rc = fwd(plan, dp, d_v, WV, batch * T, st)) != FHE_OK) return rc; V = WV; }
+    { fhe::KernelTimer kt_("mac_rows", 0, st);
     hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, nc, n))), dim3(256), 0, st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
+    }
     LAUNCH_OK("mac_rows_kernel");
     return out_evals ? FHE_OK : inv(plan, dp, d_out, d_out, batch * nc, st);
 }
@@ -407,7 +427,9 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
             if (parts > 1 && (e = fhe::launch_sum_parts(PART, RHS, batch, parts, (u64)k1 * n, plan->q, st)) != hipSuccess)
                 return fhe_hip_fail(e, "sum_parts_kernel");
             if ((rc = inv(plan, dp, RHS, RHS, batch * k1, st)) != FHE_OK) return rc;
+            { fhe::KernelTimer kt_("ks_tail", 0, st);
             hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(fhe_ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
+            }
             LAUNCH_OK("ks_tail_kernel");
             return FHE_OK;
         }
@@ -428,12 +450,23 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
         else (void)hipGetLastError();
     }
     if (!dec_is_evals) {
+        { fhe::KernelTimer kt_("decompose", 0, st);
         hipLaunchKernelGGL(fhe::decompose_kernel, dim3(fhe_ew_grid(batch * k * n)), dim3(256), 0, st, (const u64 *)d_glwe, DEC, (u64)batch * k, (u32)n, (u64)plan->q, (u32)beta, (u32)l, (u32)k, (u64)k1 * n);
+        }
         LAUNCH_OK("decompose_kernel");
     }
     // ksk viewed as [T = k*l][k1][n]; DEC as [batch][T][n]
+    if (dp.wide && dp.log_n >= 8 && dp.log_n <= 12) {
+        // sums left in the NTT domain; inverse transforms and (0, b) - rhs in one kernel (digit_mac.hip)
+        if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, flags & FHE_A_IS_EVALS, DEC, dec_is_evals, RHS, true, T, k1, batch, WS, st)) != FHE_OK) return rc;
+        hipError_t e = fhe::launch_digit_tail_ks(dp, RHS, 1, k, (const u64 *)d_glwe, (u64 *)d_out, batch, st);
+        if (e == hipSuccess) return FHE_OK;
+        return fhe_hip_fail(e, "digit_tail_kernel");
+    }
     if ((rc = keyed_mac(plan, dp, (const u64 *)d_ksk, flags & FHE_A_IS_EVALS, DEC, dec_is_evals, RHS, false, T, k1, batch, WS, st)) != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("ks_tail", 0, st);
     hipLaunchKernelGGL(fhe::ks_tail_kernel, dim3(fhe_ew_grid(batch * k1 * n)), dim3(256), 0, st, (const u64 *)d_glwe, (const u64 *)RHS, (u64 *)d_out, (u64)batch, (u32)n, (u32)k, (u64)plan->q);
+    }
     LAUNCH_OK("ks_tail_kernel");
     return FHE_OK;
 }

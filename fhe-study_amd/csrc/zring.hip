@@ -320,7 +320,9 @@ static int z_forward_src(const ZCtx &z, int k, const u64 *src, u64 *out, u64 row
                                                   fhe_batch_tile_for(z.plan[k]), st);
     if (e == hipSuccess) return FHE_OK;
     if (e != hipErrorNotSupported) return fhe_hip_fail(e, "zring reducing forward NTT");
+    { fhe::KernelTimer kt_("zr_reduce_pad", 0, st);
     hipLaunchKernelGGL(fhe::zr_reduce_pad_kernel, dim3(fhe_ew_grid(rows * n)), dim3(256), 0, st, src, out, rows, (u32)n_src, (u32)n, z.cc.m[k]);
+    }
     LAUNCH_OK("zr_reduce_pad_kernel");
     return z_forward(z, k, out, out, rows, st);
 }
@@ -332,6 +334,7 @@ static int z_inverse(const ZCtx &z, int k, const u64 *in, u64 *out, u64 rows, hi
 static int z_crt(const ZCtx &z, bool is_signed, const u64 *r1, const u64 *r2, const u64 *r3, u64 *out,
                  u64 count, hipStream_t st) {
     const unsigned g = fhe_ew_grid(count);
+    fhe::KernelTimer kt_("zr_crt", z.K, st);
 #define CRT_CASE(K_, S_) hipLaunchKernelGGL((fhe::zr_crt_kernel<K_, S_>), dim3(g), dim3(256), 0, st, r1, r2, r3, out, count, z.cc)
     if (z.K == 1) { if (is_signed) CRT_CASE(1, true); else CRT_CASE(1, false); }
     else if (z.K == 2) { if (is_signed) CRT_CASE(2, true); else CRT_CASE(2, false); }
@@ -345,6 +348,7 @@ static int z_crt(const ZCtx &z, bool is_signed, const u64 *r1, const u64 *r2, co
 static int z_crt_mdr(const ZCtx &z, const u64 *r1, const u64 *r2, const u64 *r3, const u64 *addend, u64 *out,
                      u64 rows, u64 n, u64 q, u64 num, u64 den, hipStream_t st) {
     const unsigned g = fhe_ew_grid(rows * n);
+    fhe::KernelTimer kt_("zr_crt_mdr", z.K, st);
 #define MDR_CASE(K_) hipLaunchKernelGGL((fhe::zr_crt_mdr_kernel<K_>), dim3(g), dim3(256), 0, st, r1, r2, r3, addend, out, rows, (u32)n, q, num, den, z.cc)
     if (z.K == 1) MDR_CASE(1); else if (z.K == 2) MDR_CASE(2); else MDR_CASE(3);
 #undef MDR_CASE
@@ -401,8 +405,10 @@ extern "C" int fhe_mul_div_round_dev(uint64_t q, uint64_t n, const void *d_v, ui
     int dev;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("zr_mul_div_round", 0, (hipStream_t)hip_stream);
     hipLaunchKernelGGL(fhe::zr_mul_div_round_kernel, dim3(fhe_ew_grid(batch * n)), dim3(256), 0, (hipStream_t)hip_stream,
                        (const u64 *)d_v, (u64 *)d_out, (u64)batch, (u32)n, (u64)q, (u64)num, (u64)den);
+    }
     LAUNCH_OK("zr_mul_div_round_kernel");
     return FHE_OK;
 }
@@ -431,7 +437,9 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
     for (int k = 0; k < z.K; k++) {
         if ((rc = z_forward_src(z, k, (const u64 *)d_ab, AB, 4 * batch, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 3 * (u64)k * words;
+        { fhe::KernelTimer kt_("zr_tensor", 0, st);
         hipLaunchKernelGGL(fhe::zr_tensor_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)AB, Rk, words, z.cc.m[k]);
+        }
         LAUNCH_OK("zr_tensor_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 3 * batch, st)) != FHE_OK) return rc;
     }
@@ -464,7 +472,9 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
         if ((rc = z_forward_src(z, k, c2, X, batch, n, st)) != FHE_OK) return rc;
         if ((rc = z_forward_src(z, k, (const u64 *)d_rlk, Y, 2, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 2 * (u64)k * words;
+        { fhe::KernelTimer kt_("zr_mul_bcast", 0, st);
         hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, (const u64 *)Y, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
+        }
         LAUNCH_OK("zr_mul_bcast_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 2 * batch, st)) != FHE_OK) return rc;
     }
@@ -539,7 +549,9 @@ extern "C" int fhe_tggsw_prepare_dev(uint64_t n, unsigned k, unsigned l, const v
     hipStream_t st = (hipStream_t)hip_stream;
     const u32 k1 = k + 1;
     const u64 T = (u64)k1 * l, grows = T * k1;
+    { fhe::KernelTimer kt_("zr_split32", 0, st);
     hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, (u64 *)d_prepared, T, k1, (u32)n);
+    }
     LAUNCH_OK("zr_split32_kernel");
     return z_forward(z1, 0, (const u64 *)d_prepared, (u64 *)d_prepared, 2 * grows, st);          // halves are < 2^32 < P1
 }
@@ -578,7 +590,9 @@ extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, u
             if (parts > 1 && (e = fhe::launch_sum_parts(PART, R, batch, parts, 2ull * k1 * n, z1.cc.m[0].q, st)) != hipSuccess)
                 return fhe_hip_fail(e, "sum_parts_kernel");
             if ((rc = z_inverse(z1, 0, R, R, 2 * orows, st)) != FHE_OK) return rc;
+            { fhe::KernelTimer kt_("zr_combine32", 0, st);
             hipLaunchKernelGGL(fhe::zr_combine32_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)R, (u64 *)d_out, (u64)batch, k1, (u32)n, z1.cc.p1, z1.cc.half1);
+            }
             LAUNCH_OK("zr_combine32_kernel");
             return FHE_OK;
         }
@@ -590,10 +604,18 @@ extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, u
     u64 *D = (u64 *)wsv, *R = D + drows * n;
     hipError_t e = fhe::launch_ntt_forward_digits(z1.dp[0], (const u64 *)d_tglwe, D, orows, (u32)l, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "digit forward NTT");
+    { fhe::KernelTimer kt_("mac_rows", 0, st);
     hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, 2 * k1, n))), dim3(256), 0, st, G2, (const u64 *)D, R, (u64)batch, (u32)n, (u32)T, 2 * k1, (u64)0, z1.cc.m[0]);
+    }
     LAUNCH_OK("mac_rows_kernel");
+    e = fhe::launch_digit_tail_torus(z1.dp[0], R, 1, k1, z1.cc.half1, (u64 *)d_out, batch, st);     // inverse + recombination
+    if (e == hipSuccess) return FHE_OK;
+    if (e != hipErrorNotSupported) return fhe_hip_fail(e, "digit_tail_kernel");
+    (void)hipGetLastError();
     if ((rc = z_inverse(z1, 0, R, R, 2 * orows, st)) != FHE_OK) return rc;
+    { fhe::KernelTimer kt_("zr_combine32", 0, st);
     hipLaunchKernelGGL(fhe::zr_combine32_kernel, dim3(fhe_ew_grid(orows * n)), dim3(256), 0, st, (const u64 *)R, (u64 *)d_out, (u64)batch, k1, (u32)n, z1.cc.p1, z1.cc.half1);
+    }
     LAUNCH_OK("zr_combine32_kernel");
     return FHE_OK;
 }
@@ -638,7 +660,9 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
         hipError_t e = fhe::launch_ntt_forward_digits(z.dp[kk], (const u64 *)d_tglwe, D, orows, (u32)l, st);
         if (e == hipErrorNotSupported) {
             if (!digits_done) {
+                { fhe::KernelTimer kt_("zr_digits", 0, st);
                 hipLaunchKernelGGL(fhe::zr_digits_kernel, dim3(fhe_ew_grid(drows * n)), dim3(256), 0, st, (const u64 *)d_tglwe, Dg, (u64)orows, (u32)n, (u32)l);
+                }
                 LAUNCH_OK("zr_digits_kernel");
                 digits_done = true;
             }
@@ -648,7 +672,9 @@ extern "C" int fhe_tggsw_external_product_dev(uint64_t n, unsigned k, unsigned l
         }
         u64 *Rk = R + (u64)kk * orows * n;
         // out[b][c] = sum_{i<k1,d<l} G[i][d][c] * D[b][i][d]  (tggsw.rs:57-59,145): T = k1*l terms, k1 rows
+        { fhe::KernelTimer kt_("mac_rows", 0, st);
         hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, k1, n))), dim3(256), 0, st, (const u64 *)G, (const u64 *)D, Rk, (u64)batch, (u32)n, (u32)(k1 * l), (u32)k1, (u64)0, z.cc.m[kk]);
+        }
         LAUNCH_OK("mac_rows_kernel");
         if ((rc = z_inverse(z, kk, Rk, Rk, orows, st)) != FHE_OK) return rc;
     }
@@ -681,7 +707,9 @@ extern "C" int fhe_tglwe_mul_tn_dev(uint64_t n, unsigned k, const void *d_tglwe,
         if ((rc = z_forward_src(z, kk, (const u64 *)d_p, P, batch, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + (u64)kk * rows * n;
         // T = 1 term, nc = k+1 rows, "key" = the ciphertext itself (per batch element)
+        { fhe::KernelTimer kt_("mac_rows", 0, st);
         hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, k1, n))), dim3(256), 0, st, (const u64 *)A, (const u64 *)P, Rk, (u64)batch, (u32)n, (u32)1, k1, (u64)k1 * n, z.cc.m[kk]);
+        }
         LAUNCH_OK("mac_rows_kernel");
         if ((rc = z_inverse(z, kk, Rk, Rk, rows, st)) != FHE_OK) return rc;
     }
@@ -712,7 +740,9 @@ extern "C" int fhe_tglev_mul_dev(uint64_t n, unsigned k, unsigned l, const void 
         if ((rc = z_forward_src(z, kk, (const u64 *)d_tglev, G, grows, n, st)) != FHE_OK) return rc;
         if ((rc = z_forward_src(z, kk, (const u64 *)d_v, V, vrows, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + (u64)kk * orows * n;
+        { fhe::KernelTimer kt_("mac_rows", 0, st);
         hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, k1, n))), dim3(256), 0, st, (const u64 *)G, (const u64 *)V, Rk, (u64)batch, (u32)n, (u32)l, k1, (u64)0, z.cc.m[kk]);
+        }
         LAUNCH_OK("mac_rows_kernel");
         if ((rc = z_inverse(z, kk, Rk, Rk, orows, st)) != FHE_OK) return rc;
     }

@@ -99,3 +99,6 @@ if __name__ == "__main__":
     B.kernel_timing_reset()
     key_switch(resident_key=True)
     print({k: (round(v[0], 3), v[1]) for k, v in B.kernel_timing_read().items()})
+    B.kernel_timing_reset()
+    bfv(batch=2048)
+    print({k: (round(v[0], 3), v[1]) for k, v in B.kernel_timing_read().items()})

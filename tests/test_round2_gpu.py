@@ -432,3 +432,24 @@ def test_two_devices_from_two_host_threads(pkg, oracle):
         t.join()
     assert not errs, errs
     assert np.array_equal(np.concatenate(got), want)
+
+
+def test_fused_external_product_large_batch_single_part(pkg, oracle):
+    """A batch that fills the chip by itself is not split into parts (one workgroup per ciphertext walks all
+    its digits; the tail kernel then reads the sums directly): first and last 24 products against the oracle."""
+    import torch
+
+    L, B = pkg.load_library(), pkg.binding
+    n, k, l, batch = 256, 1, 8, 2100
+    rng = np.random.default_rng(2100)
+    g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).cuda()
+    c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (batch, k + 1, n), dtype=np.int64)).cuda()
+    out = torch.empty_like(c)
+    B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), out.data_ptr(), batch, None))
+    rows = list(range(24)) + list(range(batch - 24, batch))
+    want = oracle.external_product(n, k, l, _u64(g), _u64(c[rows]))
+    assert np.array_equal(_u64(out[rows]), want)
+    # every product is the same function of its ciphertext: reversing the batch reverses the outputs
+    out2 = torch.empty_like(c)
+    B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.flip(0).contiguous().data_ptr(), out2.data_ptr(), batch, None))
+    assert torch.equal(out2.flip(0), out)

@@ -447,53 +447,111 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
     return z_crt_mdr(z, R, R + 3 * words, R + 6 * words, nullptr, (u64 *)d_c, 3 * batch, n, q, t, q, st);
 }
 
-// d_rlk: [rlk0 | rlk1], each n words mod pq (one key for the whole batch).
-// d_c: [c0 | c1 | c2] as produced by fhe_bfv_tensor_dev.  d_out: [o0 | o1], each batch x n.
-extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, const void *d_c,
-                                       void *d_out, size_t batch, void *hip_stream) {
-    int rc = check_pow2_n(n, "fhe_bfv_relinearize_dev");
+// The relinearisation key in the form the products consume: for each of the K CRT primes, NTT_k(rlk0 mod P_k) and
+// NTT_k(rlk1 mod P_k) zero-padded to 2n — K x 2 rows of 2n words.  A key relinearises every product of a
+// computation (bfv/src/lib.rs:87-90 passes the same rlk to each RLWE::mul), so it is prepared once.
+static int bfv_relin_ctx(ZCtx *z, uint64_t q, uint64_t n, uint64_t pq, const char *who) {
+    int rc = check_pow2_n(n, who);
     if (rc != FHE_OK) return rc;
-    if (q < 2 || (q >> 63) || pq < q || (pq >> 63)) return fhe_fail(FHE_E_BAD_Q, "fhe_bfv_relinearize_dev: need 2 <= q <= pq < 2^63");
-    if (batch == 0) return FHE_OK;
-    if (!d_rlk || !d_c || !d_out) return fhe_fail(FHE_E_NULL, "fhe_bfv_relinearize_dev: NULL buffer");
-    REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_c); REQUIRE_ALIGNED(d_out);
-    const u64 n2 = 2 * n, p = pq / q;
+    if (q < 2 || (q >> 63) || pq < q || (pq >> 63)) return fhe_fail(FHE_E_BAD_Q, "%s: need 2 <= q <= pq < 2^63", who);
+    return zctx_init(z, 2 * n, primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false));
+}
+
+extern "C" size_t fhe_bfv_rlk_prepared_words(uint64_t q, uint64_t n, uint64_t pq) {
+    if (n < 2 || (n & (n - 1)) || n > (1ull << 19) || q < 2 || (q >> 63) || pq < q || (pq >> 63)) return 0;
+    const int K = primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false);
+    return K >= 1 && K <= 3 ? (size_t)K * 2 * 2 * n : 0;
+}
+
+extern "C" int fhe_bfv_rlk_prepare_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, void *d_prepared, void *hip_stream) {
     ZCtx z;
-    rc = zctx_init(&z, n2, primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false));
+    int rc = bfv_relin_ctx(&z, q, n, pq, "fhe_bfv_rlk_prepare_dev");
     if (rc != FHE_OK) return rc;
-    hipStream_t st = (hipStream_t)hip_stream;
+    if (!d_rlk || !d_prepared) return fhe_fail(FHE_E_NULL, "fhe_bfv_rlk_prepare_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_prepared);
+    for (int k = 0; k < z.K; k++)
+        if ((rc = z_forward_src(z, k, (const u64 *)d_rlk, (u64 *)d_prepared + (u64)k * 4 * n, 2, n, (hipStream_t)hip_stream)) != FHE_OK) return rc;
+    return FHE_OK;
+}
+
+// the products against a prepared key: d_prep as fhe_bfv_rlk_prepare_dev leaves it
+static int bfv_relinearize_with(const ZCtx &z, uint64_t q, uint64_t n, uint64_t pq, const u64 *d_prep, const void *d_c, void *d_out,
+                                size_t batch, hipStream_t st) {
+    const u64 n2 = 2 * n, p = pq / q;
     const u64 words = batch * n2, bn = batch * n;
     void *wsv = nullptr;
-    rc = fhe_workspace_get(1, (1 + 2 * (size_t)z.K) * words * 8 + 2 * n2 * 8, st, &wsv);
+    int rc = fhe_workspace_get(1, (1 + 2 * (size_t)z.K) * words * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
-    u64 *X = (u64 *)wsv, *R = X + words, *Y = R + 2 * (u64)z.K * words;
+    u64 *X = (u64 *)wsv, *R = X + words;
     const u64 *c2 = (const u64 *)d_c + 2 * bn;
     for (int k = 0; k < z.K; k++) {
         if ((rc = z_forward_src(z, k, c2, X, batch, n, st)) != FHE_OK) return rc;
-        if ((rc = z_forward_src(z, k, (const u64 *)d_rlk, Y, 2, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 2 * (u64)k * words;
         { fhe::KernelTimer kt_("zr_mul_bcast", 0, st);
-        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, (const u64 *)Y, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, d_prep + (u64)k * 2 * n2, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
         }
         LAUNCH_OK("zr_mul_bcast_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 2 * batch, st)) != FHE_OK) return rc;
     }
     // (c0, c1) + mul_div_round(crt(..), 1, p): recombination, scaling, fold and the final add in one kernel
-    (void)bn;
     return z_crt_mdr(z, R, R + 2 * words, R + 4 * words, (const u64 *)d_c, (u64 *)d_out, 2 * batch, n, q, 1, p, st);
+}
+
+extern "C" int fhe_bfv_relinearize_prepared_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_prepared, const void *d_c,
+                                                void *d_out, size_t batch, void *hip_stream) {
+    ZCtx z;
+    int rc = bfv_relin_ctx(&z, q, n, pq, "fhe_bfv_relinearize_prepared_dev");
+    if (rc != FHE_OK) return rc;
+    if (batch == 0) return FHE_OK;
+    if (!d_prepared || !d_c || !d_out) return fhe_fail(FHE_E_NULL, "fhe_bfv_relinearize_prepared_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_prepared); REQUIRE_ALIGNED(d_c); REQUIRE_ALIGNED(d_out);
+    return bfv_relinearize_with(z, q, n, pq, (const u64 *)d_prepared, d_c, d_out, batch, (hipStream_t)hip_stream);
+}
+
+// d_rlk: [rlk0 | rlk1], each n words mod pq (one key for the whole batch).
+// d_c: [c0 | c1 | c2] as produced by fhe_bfv_tensor_dev.  d_out: [o0 | o1], each batch x n.
+extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, const void *d_c,
+                                       void *d_out, size_t batch, void *hip_stream) {
+    ZCtx z;
+    int rc = bfv_relin_ctx(&z, q, n, pq, "fhe_bfv_relinearize_dev");
+    if (rc != FHE_OK) return rc;
+    if (batch == 0) return FHE_OK;
+    if (!d_rlk || !d_c || !d_out) return fhe_fail(FHE_E_NULL, "fhe_bfv_relinearize_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_c); REQUIRE_ALIGNED(d_out);
+    // the key prepared on the fly, in workspace slot 0 behind the tensor result that fhe_bfv_mul_dev keeps there
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t kw = (size_t)z.K * 4 * n, tensor_words = 3 * batch * n;
+    void *w0 = nullptr;
+    if ((rc = fhe_workspace_get(0, (tensor_words + kw) * 8, st, &w0)) != FHE_OK) return rc;
+    u64 *prep = (u64 *)w0 + tensor_words;
+    for (int k = 0; k < z.K; k++)
+        if ((rc = z_forward_src(z, k, (const u64 *)d_rlk, prep + (u64)k * 4 * n, 2, n, st)) != FHE_OK) return rc;
+    return bfv_relinearize_with(z, q, n, pq, prep, d_c, d_out, batch, st);
+}
+
+static int bfv_mul_common(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, bool prepared, const void *d_ab,
+                          void *d_out, size_t batch, void *hip_stream) {
+    if (batch == 0) return FHE_OK;
+    // the tensor result lives in workspace slot 0 (both stages use slot 1); a stream-ordered
+    // allocation per call cost up to 2 ms at 2048 ciphertexts whenever the pool had trimmed itself.
+    // Sized for the on-the-fly key as well, so that fhe_bfv_relinearize_dev's request does not move it.
+    const size_t kw = 3 * 4 * (size_t)n;
+    void *c = nullptr;
+    int rc = fhe_workspace_get(0, (3 * batch * n + kw) * 8, (hipStream_t)hip_stream, &c);
+    if (rc != FHE_OK) return rc;
+    rc = fhe_bfv_tensor_dev(q, n, t, d_ab, c, batch, hip_stream);
+    if (rc != FHE_OK) return rc;
+    return prepared ? fhe_bfv_relinearize_prepared_dev(q, n, pq, d_rlk, c, d_out, batch, hip_stream)
+                    : fhe_bfv_relinearize_dev(q, n, pq, d_rlk, c, d_out, batch, hip_stream);
 }
 
 extern "C" int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, const void *d_ab,
                                void *d_out, size_t batch, void *hip_stream) {
-    if (batch == 0) return FHE_OK;
-    // the tensor result lives in workspace slot 0 (both stages use slot 1); a stream-ordered
-    // allocation per call cost up to 2 ms at 2048 ciphertexts whenever the pool had trimmed itself
-    void *c = nullptr;
-    int rc = fhe_workspace_get(0, 3 * batch * n * 8, (hipStream_t)hip_stream, &c);
-    if (rc != FHE_OK) return rc;
-    rc = fhe_bfv_tensor_dev(q, n, t, d_ab, c, batch, hip_stream);
-    if (rc == FHE_OK) rc = fhe_bfv_relinearize_dev(q, n, pq, d_rlk, c, d_out, batch, hip_stream);
-    return rc;
+    return bfv_mul_common(q, n, t, pq, d_rlk, false, d_ab, d_out, batch, hip_stream);
+}
+extern "C" int fhe_bfv_mul_prepared_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_prepared, const void *d_ab,
+                                        void *d_out, size_t batch, void *hip_stream) {
+    return bfv_mul_common(q, n, t, pq, d_prepared, true, d_ab, d_out, batch, hip_stream);
 }
 
 // ---- TFHE: Tn x Tn -----------------------------------------------------------------------------

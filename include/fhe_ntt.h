@@ -196,6 +196,15 @@ int fhe_bfv_mul(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const uint64_t 
                 uint64_t *out, size_t batch);
 int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, const void *d_ab,
                     void *d_out, size_t batch, void *hip_stream);
+/* Resident relinearisation key: rlk reduced modulo each CRT prime and forward-transformed, built once per key
+ * (fhe_bfv_rlk_prepared_words words; 0 = invalid parameters) and reused by every later product — the same words
+ * as the plain entry points produce. */
+size_t fhe_bfv_rlk_prepared_words(uint64_t q, uint64_t n, uint64_t pq);
+int fhe_bfv_rlk_prepare_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, void *d_prepared, void *hip_stream);
+int fhe_bfv_relinearize_prepared_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_prepared, const void *d_c,
+                                     void *d_out, size_t batch, void *hip_stream);
+int fhe_bfv_mul_prepared_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_prepared, const void *d_ab,
+                             void *d_out, size_t batch, void *hip_stream);
 
 /* Tn x Tn, arith/src/ring_torus.rs:251-298 (naive_poly_mul): negacyclic product of
  * coefficient vectors mod 2^64. */

@@ -453,3 +453,33 @@ def test_fused_external_product_large_batch_single_part(pkg, oracle):
     out2 = torch.empty_like(c)
     B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.flip(0).contiguous().data_ptr(), out2.data_ptr(), batch, None))
     assert torch.equal(out2.flip(0), out)
+
+
+@pytest.mark.parametrize("q,n,p,t,batch", [(Q16, 16, Q16 * Q16, 2, 5), (Q16, 8192, Q16 * Q16, 2, 3), (Q61, 64, 1 << 1, 4, 2)])
+def test_bfv_multiply_with_a_resident_relinearisation_key(pkg, oracle, q, n, p, t, batch):
+    """fhe_bfv_rlk_prepare_dev once, then fhe_bfv_mul_prepared_dev / fhe_bfv_relinearize_prepared_dev: the words of
+    the plain entry points and of the oracle's schoolbook (bfv/src/lib.rs:59-90,251-271), for several batches."""
+    import torch
+
+    L, B = pkg.load_library(), pkg.binding
+    pq = p * q
+    rng = np.random.default_rng(n + batch)
+    ab = rng.integers(0, q, (4, batch, n), dtype=np.uint64)
+    rlk = rng.integers(0, pq, (2, n), dtype=np.uint64)
+    dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
+    dab, drlk = dev(ab), dev(rlk)
+    words = L.fhe_bfv_rlk_prepared_words(q, n, pq)
+    assert words in (4 * n, 8 * n, 12 * n)
+    prep = torch.empty(words, dtype=torch.int64, device="cuda")
+    B._check(L.fhe_bfv_rlk_prepare_dev(q, n, pq, drlk.data_ptr(), prep.data_ptr(), None))
+    plain = torch.empty((2, batch, n), dtype=torch.int64, device="cuda")
+    B._check(L.fhe_bfv_mul_dev(q, n, t, pq, drlk.data_ptr(), dab.data_ptr(), plain.data_ptr(), batch, None))
+    drlk.zero_()                                            # the prepared key stands alone
+    for nb in (batch, 1):
+        sub = dev(ab[:, :nb].copy())
+        out = torch.empty((2, nb, n), dtype=torch.int64, device="cuda")
+        B._check(L.fhe_bfv_mul_prepared_dev(q, n, t, pq, prep.data_ptr(), sub.data_ptr(), out.data_ptr(), nb, None))
+        assert torch.equal(out, plain[:, :nb])
+    w0, w1 = oracle.bfv_mul(q, n, t, pq, rlk[0], rlk[1], ab[0, :1], ab[1, :1], ab[2, :1], ab[3, :1])
+    assert np.array_equal(_u64(plain[0, 0]), w0[0]) and np.array_equal(_u64(plain[1, 0]), w1[0])
+    assert L.fhe_bfv_rlk_prepared_words(q, 3, pq) == 0

@@ -230,6 +230,31 @@ __device__ __forceinline__ void bf_v11(u64& x, u64& y, u64 w, u64 wp, const Q& c
   x = s;
 }
 
+// v12: SPLIT MULTIPLICAND.  y = y1*2^32 + y0, so y*w = y0*w + y1*w2 with w2 = w*2^32 mod q, and each 32-bit
+// half gets its own Shoup quotient from a 32-bit companion (p = floor(w*2^32/q), p2 = floor(w2*2^32/q)): two
+// v_mul_hi_u32, no 64-bit mulhi, no zero-extension moves.  Each half lands in [0,2q): t in [0,4q), so (q < 2^61)
+// every stage brings x below 4q first and all values stay below 8q <= 2^64:  x' = u + t,  y' = u - t + 4q.
+struct T12 { u32 w0, w1, v0, v1, p, p2; };   // w, w2 = w*2^32 mod q, the two 32-bit companions
+__device__ __forceinline__ void bf_v12(u64& x, u64& y, const T12& t, const Q& c) {
+  const u64 u = csub32(x, c.neg4q);
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), n0 = (u32)c.nq, n1 = (u32)(c.nq >> 32);
+  const u32 qa = mulhi32(y0, t.p), qb = mulhi32(y1, t.p2);
+  u64 acc, H;
+  asm("v_mad_u64_u32 %0, vcc, %3, %5, %2\n\t"      // acc = y0*w0 + u
+      "v_mad_u64_u32 %1, vcc, %3, %6, 0\n\t"       // H   = y0*w1
+      "v_mad_u64_u32 %0, vcc, %4, %7, %0\n\t"      // acc += y1*v0
+      "v_mad_u64_u32 %1, vcc, %4, %8, %1\n\t"      // H   += y1*v1
+      "v_mad_u64_u32 %0, vcc, %9, %11, %0\n\t"     // acc += qa*n0
+      "v_mad_u64_u32 %1, vcc, %9, %12, %1\n\t"     // H   += qa*n1
+      "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"    // acc += qb*n0
+      "v_mad_u64_u32 %1, vcc, %10, %12, %1"          // H   += qb*n1
+      : "=&v"(acc), "=&v"(H)
+      : "v"(u), "v"(y0), "v"(y1), "v"(t.w0), "v"(t.w1), "v"(t.v0), "v"(t.v1), "v"(qa), "v"(qb), "v"(n0), "v"(n1) : "vcc");
+  const u64 s = pack((u32)acc, add32((u32)(acc >> 32), (u32)H));
+  y = add64(shl1add64(u, c.q4p1), ~s);
+  x = s;
+}
+
 template <int V>
 __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
   u64 x[4], y[4];
@@ -271,6 +296,18 @@ __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
   for (int j = 0; j < 4; j++) { p[threadIdx.x + 64 * j] = x[j]; p[threadIdx.x + 64 * j + 256] = y[j]; }
 }
 
+__global__ void k12(u64* p, Q c, T12 t, int iters) {
+  u64 x[4], y[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { x[j] = p[threadIdx.x + 64 * j] % c.q; y[j] = p[threadIdx.x + 64 * j + 256] % c.q; }
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) bf_v12(x[j], y[j], t, c);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { p[threadIdx.x + 64 * j] = x[j]; p[threadIdx.x + 64 * j + 256] = y[j]; }
+}
+
 static u64 href(u64 x, u64 y, u64 w, u64 q, int iters, u64* yo) {  // canonical reference
   for (int i = 0; i < iters; i++) {
     u64 t = (u64)(((u128)y * w) % q);
@@ -301,7 +338,7 @@ int main() {
   std::vector<u64> h(512), o(512);
   for (int i = 0; i < 512; i++) h[i] = (0x9E3779B97F4A7C15ull * (i + 1)) ^ (0xD1B54A32D192ED03ull * (i + 7));
   const char* names[] = {"v0 compiler", "v1 chain+not", "v2 chain+signcsub", "v3 wide csub/2", "v4 wide mul_lo", "v5 no-mov mulhi+pack", "v6 no-mov pack only", "v7 shift-zext mulhi", "v8 fused chains (prod)", "v9 v8+cmp32", "v10 v9+mad-by-1 mulhi", "v11 approx qh, csub/1"};
-  for (int v = 6; v < 12; v++) {
+  for (int v = 8; v < 12; v++) {
     // correctness at 6 iterations (even, so v3/v4 pairs are whole)
     hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
     int it = 6;
@@ -322,6 +359,36 @@ int main() {
       for (int r = 0; r < 4; r++) {
         hipEventRecord(e0);
         launch(v, blocks, threads, p, c, w, wp, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
+      }
+      double bf = (double)blocks * threads * 4 * iters;
+      printf("   wpS=%d %8.3f ms  %8.1f Gbfly/s  %6.1f cyc/bfly-wave/SIMD(nominal clk)\n", wpS, best, bf / best * 1e-6,
+             best * 1e-3 * clk / ((double)iters * 4 * wpS));
+    }
+  }
+  {  // v12
+    const u64 w2 = (u64)((((u128)w) << 32) % q);
+    T12 t{(u32)w, (u32)(w >> 32), (u32)w2, (u32)(w2 >> 32), (u32)((((u128)w) << 32) / q), (u32)((((u128)w2) << 32) / q)};
+    hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
+    int it = 6;
+    k12<<<1, 64>>>(p, c, t, it);
+    hipMemcpy(o.data(), p, 512 * 8, hipMemcpyDeviceToHost);
+    int bad = 0; u64 mx = 0;
+    for (int tt = 0; tt < 64; tt++) for (int j = 0; j < 4; j++) {
+      u64 yo, xo = href(h[tt + 64 * j] % q, h[tt + 64 * j + 256] % q, w, q, it, &yo);
+      u64 gx = o[tt + 64 * j], gy = o[tt + 64 * j + 256];
+      if (gx % q != xo || gy % q != yo) bad++;
+      if (gx > mx) mx = gx; if (gy > mx) mx = gy;
+    }
+    printf("%-20s correctness: %s (max value / q = %.3f)\n", "v12 split multiplicand", bad ? "FAIL" : "ok", (double)mx / (double)q);
+    for (int wpS : {2, 4, 8}) {
+      int blocks = cus * wpS, threads = 256, iters = 2000;
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      float best = 1e30f;
+      for (int r = 0; r < 4; r++) {
+        hipEventRecord(e0);
+        k12<<<blocks, threads>>>(p, c, t, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
       }

@@ -388,36 +388,6 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     }
 }
 
-// ---------------------------------------------------------------------------
-// STRIDED pass: the first LA stages of a forward transform (last LA of an
-// inverse), on the (2^LA rows) x (2^LB columns) view of one polynomial.
-// Workgroup tile = all 2^LA rows x CW adjacent columns; lanes run along columns,
-// so every global access is a CW*8-byte contiguous run and LDS needs no padding.
-// ---------------------------------------------------------------------------
-template <int LA, int CW>
-struct StridedCfg {
-    static constexpr int F = 1 << LA;
-    static constexpr int TPF = F / 16;
-    static constexpr int TH = TPF * CW;
-    static constexpr int NR = (LA + 3) / 4;
-    static constexpr int R0 = LA - 4 * (NR - 1);
-    static constexpr int A0 = LA - 4;
-    static constexpr size_t DATA_BYTES = (size_t)F * CW * 8;
-    static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)F * sizeof(Tw);  // + the 2^LA twiddles
-    static constexpr int a_of(int j) { return j == 0 ? A0 : LA - R0 - 4 * j; }
-    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
-};
-
-template <int CW, int AF, int AT, bool FIRST>
-__device__ __forceinline__ void exchange_strided(u64 (&v)[16], u64 *lds, u32 c, u32 tf) {
-    if (!FIRST) __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; k++) lds[field_of<AF>(tf, k) * CW + c] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = lds[field_of<AT>(tf, k) * CW + c];
-}
-
 // RSRC: the input rows are 2^src_log_n arbitrary words, reduced mod q and zero-padded in the load
 // (see SRC_REDUCE above).
 template <int LA, int CW, bool WIDE, bool RSRC = false>
@@ -688,8 +658,6 @@ static hipError_t strided_dispatch(int la, const PassArgs &a, hipStream_t st, un
     return hipErrorInvalidValue;
 }
 
-// pass split for n >= 2^14: LB = max(8, L-8) contiguous stages, LA = L-LB in 6..8
-static inline int contig_bits(int L) { return L <= kMaxSinglePassLog ? L : (L - 8 > 8 ? L - 8 : 8); }
 
 hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
                               u64 batch_tile, hipStream_t st) {
@@ -948,6 +916,19 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// the CONTIGUOUS pass of a two-pass inverse transform alone (n >= 2^14): leaves the lazy intermediate (< 4q for
+// q < 2^61, < 2q otherwise) for a strided last pass the caller runs itself (zring.hip fuses its epilogue there)
+hipError_t launch_ntt_inverse_first_pass(const DevicePlan &p, const u64 *in, u64 *out, u64 batch, hipStream_t st) {
+    const int L = p.log_n;
+    if (L <= kMaxSinglePassLog || L > kMaxLog) return hipErrorNotSupported;
+    if (batch == 0) return hipSuccess;
+    PassArgs a{};
+    a.tw = p.tw_inv; a.mod = p.mod; a.ninv = p.ninv; a.s_ninv = p.s_ninv; a.log_n = p.log_n;
+    a.in = in; a.out = out; a.batch = batch;
+    return p.wide ? inv_contig_dispatch<true>(contig_bits(L), false, false, a, st)
+                  : inv_contig_dispatch<false>(contig_bits(L), false, false, a, st);
 }
 
 static inline unsigned ew_grid(u64 count) {

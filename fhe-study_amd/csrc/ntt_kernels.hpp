@@ -78,6 +78,8 @@ hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *ou
                                      uint32_t src_log_n, u64 batch_tile, hipStream_t st);
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st);
+// Two-pass sizes only: the contiguous (first) pass of the inverse transform, without the strided last pass.
+hipError_t launch_ntt_inverse_first_pass(const DevicePlan &p, const u64 *in, u64 *out, u64 batch, hipStream_t st);
 // c = a * b in Z_q[X]/(X^n+1) for single-pass sizes (16 <= n <= 2^13) in ONE kernel: both forward
 // transforms, the pointwise product and the inverse transform of a polynomial stay in registers /
 // LDS.  evals_* may be nullptr.  Returns hipErrorNotSupported for other sizes.

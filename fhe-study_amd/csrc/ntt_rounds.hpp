@@ -423,6 +423,39 @@ __device__ __forceinline__ void inv_rounds_contig(u64 (&v)[16], u64 *lds, const 
     round_inv_sel<C::R0, FOLD, WIDE, (C::NR == 1 ? BF : BN)>(v, TW(C::in_lds(0)), T0(C::in_lds(0), 0, 0), m, ninv, s_ninv);
 }
 
+// ---------------------------------------------------------------------------
+// STRIDED pass: the first LA stages of a forward transform (last LA of an
+// inverse), on the (2^LA rows) x (2^LB columns) view of one polynomial.
+// Workgroup tile = all 2^LA rows x CW adjacent columns; lanes run along columns,
+// so every global access is a CW*8-byte contiguous run and LDS needs no padding.
+// ---------------------------------------------------------------------------
+template <int LA, int CW>
+struct StridedCfg {
+    static constexpr int F = 1 << LA;
+    static constexpr int TPF = F / 16;
+    static constexpr int TH = TPF * CW;
+    static constexpr int NR = (LA + 3) / 4;
+    static constexpr int R0 = LA - 4 * (NR - 1);
+    static constexpr int A0 = LA - 4;
+    static constexpr size_t DATA_BYTES = (size_t)F * CW * 8;
+    static constexpr size_t LDS_BYTES = DATA_BYTES + (size_t)F * sizeof(Tw);  // + the 2^LA twiddles
+    static constexpr int a_of(int j) { return j == 0 ? A0 : LA - R0 - 4 * j; }
+    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
+};
+
+template <int CW, int AF, int AT, bool FIRST>
+__device__ __forceinline__ void exchange_strided(u64 (&v)[16], u64 *lds, u32 c, u32 tf) {
+    if (!FIRST) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[field_of<AF>(tf, k) * CW + c] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = lds[field_of<AT>(tf, k) * CW + c];
+}
+
+// pass split for n >= 2^14: LB = max(8, L-8) contiguous stages, LA = L-LB in 6..8
+static inline int contig_bits(int L) { return L <= kMaxSinglePassLog ? L : (L - 8 > 8 ? L - 8 : 8); }
+
 // dynamic LDS above 64 KiB must be opted into per kernel
 static inline hipError_t allow_big_lds(const void *fn, size_t bytes) {
     if (bytes <= 65536) return hipSuccess;

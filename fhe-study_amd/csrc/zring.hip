@@ -21,6 +21,7 @@
 
 #include "capi_internal.hpp"
 #include "digit_mac.hpp"
+#include "ntt_rounds.hpp"
 #include "zq_device.hpp"
 #include "mac_kernel.hpp"
 
@@ -239,6 +240,55 @@ __global__ __launch_bounds__(256) void zr_crt_mdr_kernel(const u64 *__restrict__
     }
 }
 
+// The LAST pass of a two-pass inverse transform modulo ONE prime with mul_div_round + from_vec_f64 + the X^n+1 fold
+// as its epilogue (single-prime products: the residue IS the integer): a thread of the strided pass ends up holding
+// rows f and f + F/2 of its column, i.e. coefficients j and j + n of the 2n-word convolution — exactly the pair the
+// fold subtracts — so the scaled, rounded, folded Z_q words are formed in registers and the 2n-word integers are
+// never written (BFV tensor at N = 8192: one kernel and 0.8 GB of traffic less per 2048 ciphertext pairs).
+template <int LA, int CW>
+__global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void zr_inv_strided_mdr_kernel(PassArgs a, u64 *__restrict__ outq, u64 q,
+                                                                                      double numf, double denf) {
+    using C = StridedCfg<LA, CW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    const u32 tid = threadIdx.x, c = tid % CW, tf = tid / CW;
+    const u32 lb = a.log_n - LA;
+    const u32 lcg = lb - __builtin_ctz(CW);
+    const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
+    const u64 poly = (u64)(blockIdx.x >> lcg);
+    const u64 *__restrict__ pin = a.in + (poly << a.log_n) + (u64)cg * CW;
+    const Mod &m = a.mod;
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
+    constexpr int ALAST = C::a_of(C::NR - 1);
+    u64 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<ALAST>(tf, k) << lb) + c) * 8u);
+    for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
+    __syncthreads();
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        round_inv_sel<4, false, true, 4>(v, ltw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        exchange_strided<CW, A, C::a_of(1), true>(v, lds, c, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        round_inv_sel<4, false, true, 4>(v, ltw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        exchange_strided<CW, A, C::A0, (C::NR <= 2)>(v, lds, c, tf);
+    }
+    round_inv_sel<C::R0, true, true, 4>(v, ltw, 1u, m, a.ninv, a.s_ninv);
+    // register k holds row (k << A0) | tf: k and k + 8 are rows f and f + F/2 = coefficients j and j + n
+    const u32 nq = 1u << (a.log_n - 1);                            // n: words per output polynomial
+    u64 *__restrict__ po = outq + poly * nq + (u64)cg * CW + c;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u32 f = ((u32)k << C::A0) | tf;
+        const long long lo = (long long)canon2(v[k], m), hi = (long long)canon2(v[k + 8], m);
+        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
+        const u64 zh = zq_from_f64(q, round((numf * (double)hi) / denf));   // slot 2n-1 of a (2n-1)-term convolution is 0
+        po[(u64)f << lb] = zl >= zh ? zl - zh : (q + zl) - zh;    // Zq::sub, zq.rs:259-276
+    }
+}
+
 // Zq::add over whole polynomials (c0 + &r0, bfv/src/lib.rs:269)
 __global__ __launch_bounds__(256) void zr_rq_add_kernel(const u64 *__restrict__ a, const u64 *__restrict__ b,
                                                         u64 *__restrict__ c, u64 count, u64 q) {
@@ -356,6 +406,37 @@ static int z_crt_mdr(const ZCtx &z, const u64 *r1, const u64 *r2, const u64 *r3,
     return FHE_OK;
 }
 
+// inverse transform (two-pass sizes, one prime) whose last pass scales, rounds and folds: rows x 2n residues in
+// (NTT domain), rows x n words of Z_q out.  hipErrorNotSupported: the caller takes z_inverse + z_crt_mdr.
+static hipError_t z_inverse_mdr(const ZCtx &z, u64 *r, u64 *out, u64 rows, u64 q, u64 num, u64 den, hipStream_t st) {
+    const fhe::DevicePlan &dp = z.dp[0];
+    const int L = dp.log_n;
+    if (z.K != 1 || !dp.wide || L <= fhe::kMaxSinglePassLog) return hipErrorNotSupported;
+    hipError_t e = fhe::launch_ntt_inverse_first_pass(dp, r, r, rows, st);
+    if (e != hipSuccess) return e;
+    fhe::PassArgs a{};
+    a.tw = dp.tw_inv; a.mod = dp.mod; a.ninv = dp.ninv; a.s_ninv = dp.s_ninv; a.log_n = dp.log_n; a.in = r; a.batch = rows;
+    const int LA = L - fhe::contig_bits(L);
+    fhe::KernelTimer kt_("zr_inv_strided_mdr", LA, st);
+#define MDR_PASS(LA_, CW_)                                                                                              \
+    {                                                                                                                   \
+        using C = fhe::StridedCfg<LA_, CW_>;                                                                            \
+        const u64 grid = ((1ull << (L - LA_)) / CW_) * rows;                                                            \
+        if (grid > 0x7fffffffull) return hipErrorInvalidValue;                                                          \
+        if ((e = fhe::allow_big_lds((const void *)fhe::zr_inv_strided_mdr_kernel<LA_, CW_>, C::LDS_BYTES)) != hipSuccess) return e; \
+        hipLaunchKernelGGL((fhe::zr_inv_strided_mdr_kernel<LA_, CW_>), dim3((unsigned)grid), dim3(C::TH), C::LDS_BYTES, st, a, out, q, \
+                           (double)num, (double)den);                                                                   \
+    }
+    switch (LA) {
+        case 6: MDR_PASS(6, 128) break;
+        case 7: MDR_PASS(7, 64) break;
+        case 8: MDR_PASS(8, 32) break;
+        default: return hipErrorNotSupported;
+    }
+#undef MDR_PASS
+    return hipGetLastError();
+}
+
 static unsigned bits_of(u64 x) { unsigned b = 0; while (x) { b++; x >>= 1; } return b; }
 static unsigned ceil_log2(u64 x) { return x <= 1 ? 0 : bits_of(x - 1); }
 
@@ -441,6 +522,12 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
         hipLaunchKernelGGL(fhe::zr_tensor_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)AB, Rk, words, z.cc.m[k]);
         }
         LAUNCH_OK("zr_tensor_kernel");
+        if (z.K == 1) {   // one prime: scale by t/q, round, reduce and fold in the inverse's last pass
+            hipError_t e = z_inverse_mdr(z, Rk, (u64 *)d_c, 3 * batch, q, t, q, st);
+            if (e == hipSuccess) return FHE_OK;
+            if (e != hipErrorNotSupported) return fhe_hip_fail(e, "zr_inv_strided_mdr_kernel");
+            (void)hipGetLastError();
+        }
         if ((rc = z_inverse(z, k, Rk, Rk, 3 * batch, st)) != FHE_OK) return rc;
     }
     // recombine, scale by t/q, round, reduce, fold — in one kernel (the integers are never stored)

@@ -240,6 +240,43 @@ __global__ __launch_bounds__(256) void zr_crt_mdr_kernel(const u64 *__restrict__
     }
 }
 
+// Relinearisation with ONE prime: the key words (< pq < 2^63) are split at bit h into halves below 2^h, so that a product
+// c2 * half summed over n terms stays below the prime and both half-products are exact integers; the product modulo 2^64
+// — all the reference's `as i64` keeps — is lo + (hi << h).  Key rows laid out [rlk0_lo | rlk0_hi | rlk1_lo | rlk1_hi].
+__global__ __launch_bounds__(256) void zr_split_h_kernel(const u64 *__restrict__ key, u64 *__restrict__ out, u64 rows, u32 n, u32 h) {
+    const u64 total = rows * n, stride = (u64)gridDim.x * 256;
+    const u64 mask = (1ull << h) - 1ull;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 r = i / n, j = i - r * n, v = key[i];
+        out[(2 * r) * n + j] = v & mask;
+        out[(2 * r + 1) * n + j] = v >> h;
+    }
+}
+// out[o][b][j] = addend[o][b][j] + fold(from_f64(round(num * V / den))),  V = (lo + (hi << h)) as i64 taken from the
+// half-product rows R[2o][b] (lo) and R[2o+1][b] (hi), each 2n words: mul_div_round + from_vec_f64 + fold + Zq::add as
+// zr_crt_mdr_kernel does them, with the recombination of the halves in place of Garner's.
+__global__ __launch_bounds__(256) void zr_split_mdr_kernel(const u64 *__restrict__ R, const u64 *__restrict__ addend,
+                                                           u64 *__restrict__ out, u64 batch, u32 n, u32 h, u64 q, u64 num, u64 den) {
+    const u64 per = batch * n, total = 2 * per, stride = (u64)gridDim.x * 256;
+    const double numf = (double)num, denf = (double)den;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const u64 o = i / per, bj = i - o * per, b = bj / n;
+        const u32 j = (u32)(bj - b * n);
+        const u64 il = ((2 * o) * batch + b) * 2 * n + j, ih = ((2 * o + 1) * batch + b) * 2 * n + j;
+        const long long lo = (long long)(R[il] + (R[ih] << h));
+        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
+        u64 zh = 0;
+        if (j != n - 1) {
+            const long long hi = (long long)(R[il + n] + (R[ih + n] << h));
+            zh = zq_from_f64(q, round((numf * (double)hi) / denf));
+        }
+        u64 v = zl >= zh ? zl - zh : (q + zl) - zh;   // Zq::sub, zq.rs:259-276
+        v += addend[i];
+        if (v >= q) v -= q;                            // Zq::add, zq.rs:219-231
+        out[i] = v;
+    }
+}
+
 // The LAST pass of a two-pass inverse transform modulo ONE prime with mul_div_round + from_vec_f64 + the X^n+1 fold
 // as its epilogue (single-prime products: the residue IS the integer): a thread of the strided pass ends up holding
 // rows f and f + F/2 of its column, i.e. coefficients j and j + n of the 2n-word convolution — exactly the pair the
@@ -537,40 +574,80 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
 // The relinearisation key in the form the products consume: for each of the K CRT primes, NTT_k(rlk0 mod P_k) and
 // NTT_k(rlk1 mod P_k) zero-padded to 2n — K x 2 rows of 2n words.  A key relinearises every product of a
 // computation (bfv/src/lib.rs:87-90 passes the same rlk to each RLWE::mul), so it is prepared once.
-static int bfv_relin_ctx(ZCtx *z, uint64_t q, uint64_t n, uint64_t pq, const char *who) {
+// Two forms: the key split at bit h into two halves and ONE prime (h > 0: one forward transform of c2 per ciphertext
+// instead of two, no Garner step) whenever a half-product fits the prime: bits(q-1) + h + log2 n <= 60 with
+// h = ceil(bits(pq-1) / 2); otherwise K primes and the whole key.  Either way 4 or 2K key rows of 2n words.
+static unsigned relin_split_bits(uint64_t q, uint64_t n, uint64_t pq) {
+    const unsigned h = (bits_of(pq - 1) + 1) / 2;
+    return (h >= 1 && bits_of(q - 1) + h + ceil_log2(n) <= 60) ? h : 0;
+}
+static int bfv_relin_ctx(ZCtx *z, unsigned *h, uint64_t q, uint64_t n, uint64_t pq, const char *who) {
     int rc = check_pow2_n(n, who);
     if (rc != FHE_OK) return rc;
     if (q < 2 || (q >> 63) || pq < q || (pq >> 63)) return fhe_fail(FHE_E_BAD_Q, "%s: need 2 <= q <= pq < 2^63", who);
-    return zctx_init(z, 2 * n, primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false));
+    *h = relin_split_bits(q, n, pq);
+    return zctx_init(z, 2 * n, *h ? 1 : primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false));
 }
 
 extern "C" size_t fhe_bfv_rlk_prepared_words(uint64_t q, uint64_t n, uint64_t pq) {
     if (n < 2 || (n & (n - 1)) || n > (1ull << 19) || q < 2 || (q >> 63) || pq < q || (pq >> 63)) return 0;
+    if (relin_split_bits(q, n, pq)) return (size_t)4 * 2 * n;
     const int K = primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false);
     return K >= 1 && K <= 3 ? (size_t)K * 2 * 2 * n : 0;
 }
 
-extern "C" int fhe_bfv_rlk_prepare_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, void *d_prepared, void *hip_stream) {
-    ZCtx z;
-    int rc = bfv_relin_ctx(&z, q, n, pq, "fhe_bfv_rlk_prepare_dev");
-    if (rc != FHE_OK) return rc;
-    if (!d_rlk || !d_prepared) return fhe_fail(FHE_E_NULL, "fhe_bfv_rlk_prepare_dev: NULL buffer");
-    REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_prepared);
+// prepared key into `prep` (fhe_bfv_rlk_prepared_words words); `scratch` = 4n words for the split form
+static int bfv_rlk_prepare(const ZCtx &z, unsigned h, uint64_t n, const u64 *d_rlk, u64 *prep, u64 *scratch, hipStream_t st) {
+    int rc;
+    if (h) {
+        { fhe::KernelTimer kt_("zr_split_h", 0, st);
+        hipLaunchKernelGGL(fhe::zr_split_h_kernel, dim3(fhe_ew_grid(2 * n)), dim3(256), 0, st, d_rlk, scratch, (u64)2, (u32)n, (u32)h);
+        }
+        LAUNCH_OK("zr_split_h_kernel");
+        return z_forward_src(z, 0, scratch, prep, 4, n, st);
+    }
     for (int k = 0; k < z.K; k++)
-        if ((rc = z_forward_src(z, k, (const u64 *)d_rlk, (u64 *)d_prepared + (u64)k * 4 * n, 2, n, (hipStream_t)hip_stream)) != FHE_OK) return rc;
+        if ((rc = z_forward_src(z, k, d_rlk, prep + (u64)k * 4 * n, 2, n, st)) != FHE_OK) return rc;
     return FHE_OK;
 }
 
+extern "C" int fhe_bfv_rlk_prepare_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, void *d_prepared, void *hip_stream) {
+    ZCtx z;
+    unsigned h = 0;
+    int rc = bfv_relin_ctx(&z, &h, q, n, pq, "fhe_bfv_rlk_prepare_dev");
+    if (rc != FHE_OK) return rc;
+    if (!d_rlk || !d_prepared) return fhe_fail(FHE_E_NULL, "fhe_bfv_rlk_prepare_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_prepared);
+    hipStream_t st = (hipStream_t)hip_stream;
+    void *scratch = nullptr;
+    if (h && (rc = fhe_workspace_get(1, 4 * n * 8, st, &scratch)) != FHE_OK) return rc;
+    return bfv_rlk_prepare(z, h, n, (const u64 *)d_rlk, (u64 *)d_prepared, (u64 *)scratch, st);
+}
+
 // the products against a prepared key: d_prep as fhe_bfv_rlk_prepare_dev leaves it
-static int bfv_relinearize_with(const ZCtx &z, uint64_t q, uint64_t n, uint64_t pq, const u64 *d_prep, const void *d_c, void *d_out,
-                                size_t batch, hipStream_t st) {
+static int bfv_relinearize_with(const ZCtx &z, unsigned h, uint64_t q, uint64_t n, uint64_t pq, const u64 *d_prep, const void *d_c,
+                                void *d_out, size_t batch, hipStream_t st) {
     const u64 n2 = 2 * n, p = pq / q;
     const u64 words = batch * n2, bn = batch * n;
+    const unsigned sets = h ? 4 : 2 * (unsigned)z.K;          // product rows per ciphertext
     void *wsv = nullptr;
-    int rc = fhe_workspace_get(1, (1 + 2 * (size_t)z.K) * words * 8, st, &wsv);
+    int rc = fhe_workspace_get(1, (1 + (size_t)sets) * words * 8, st, &wsv);
     if (rc != FHE_OK) return rc;
     u64 *X = (u64 *)wsv, *R = X + words;
     const u64 *c2 = (const u64 *)d_c + 2 * bn;
+    if (h) {   // one prime, key halves: rows [rlk0_lo | rlk0_hi | rlk1_lo | rlk1_hi] x batch
+        if ((rc = z_forward_src(z, 0, c2, X, batch, n, st)) != FHE_OK) return rc;
+        { fhe::KernelTimer kt_("zr_mul_bcast", 0, st);
+        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(4 * words)), dim3(256), 0, st, (const u64 *)X, d_prep, R, (u64)batch, (u32)n2, (u32)4, z.cc.m[0]);
+        }
+        LAUNCH_OK("zr_mul_bcast_kernel");
+        if ((rc = z_inverse(z, 0, R, R, 4 * batch, st)) != FHE_OK) return rc;
+        { fhe::KernelTimer kt_("zr_split_mdr", 0, st);
+        hipLaunchKernelGGL(fhe::zr_split_mdr_kernel, dim3(fhe_ew_grid(2 * bn)), dim3(256), 0, st, (const u64 *)R, (const u64 *)d_c, (u64 *)d_out, (u64)batch, (u32)n, (u32)h, (u64)q, (u64)1, (u64)p);
+        }
+        LAUNCH_OK("zr_split_mdr_kernel");
+        return FHE_OK;
+    }
     for (int k = 0; k < z.K; k++) {
         if ((rc = z_forward_src(z, k, c2, X, batch, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 2 * (u64)k * words;
@@ -587,12 +664,13 @@ static int bfv_relinearize_with(const ZCtx &z, uint64_t q, uint64_t n, uint64_t 
 extern "C" int fhe_bfv_relinearize_prepared_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_prepared, const void *d_c,
                                                 void *d_out, size_t batch, void *hip_stream) {
     ZCtx z;
-    int rc = bfv_relin_ctx(&z, q, n, pq, "fhe_bfv_relinearize_prepared_dev");
+    unsigned h = 0;
+    int rc = bfv_relin_ctx(&z, &h, q, n, pq, "fhe_bfv_relinearize_prepared_dev");
     if (rc != FHE_OK) return rc;
     if (batch == 0) return FHE_OK;
     if (!d_prepared || !d_c || !d_out) return fhe_fail(FHE_E_NULL, "fhe_bfv_relinearize_prepared_dev: NULL buffer");
     REQUIRE_ALIGNED(d_prepared); REQUIRE_ALIGNED(d_c); REQUIRE_ALIGNED(d_out);
-    return bfv_relinearize_with(z, q, n, pq, (const u64 *)d_prepared, d_c, d_out, batch, (hipStream_t)hip_stream);
+    return bfv_relinearize_with(z, h, q, n, pq, (const u64 *)d_prepared, d_c, d_out, batch, (hipStream_t)hip_stream);
 }
 
 // d_rlk: [rlk0 | rlk1], each n words mod pq (one key for the whole batch).
@@ -600,20 +678,21 @@ extern "C" int fhe_bfv_relinearize_prepared_dev(uint64_t q, uint64_t n, uint64_t
 extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, const void *d_c,
                                        void *d_out, size_t batch, void *hip_stream) {
     ZCtx z;
-    int rc = bfv_relin_ctx(&z, q, n, pq, "fhe_bfv_relinearize_dev");
+    unsigned h = 0;
+    int rc = bfv_relin_ctx(&z, &h, q, n, pq, "fhe_bfv_relinearize_dev");
     if (rc != FHE_OK) return rc;
     if (batch == 0) return FHE_OK;
     if (!d_rlk || !d_c || !d_out) return fhe_fail(FHE_E_NULL, "fhe_bfv_relinearize_dev: NULL buffer");
     REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_c); REQUIRE_ALIGNED(d_out);
     // the key prepared on the fly, in workspace slot 0 behind the tensor result that fhe_bfv_mul_dev keeps there
+    // (12n words of prepared key at most, then 4n words of scratch for the split)
     hipStream_t st = (hipStream_t)hip_stream;
-    const size_t kw = (size_t)z.K * 4 * n, tensor_words = 3 * batch * n;
+    const size_t tensor_words = 3 * batch * n;
     void *w0 = nullptr;
-    if ((rc = fhe_workspace_get(0, (tensor_words + kw) * 8, st, &w0)) != FHE_OK) return rc;
+    if ((rc = fhe_workspace_get(0, (tensor_words + 16 * n) * 8, st, &w0)) != FHE_OK) return rc;
     u64 *prep = (u64 *)w0 + tensor_words;
-    for (int k = 0; k < z.K; k++)
-        if ((rc = z_forward_src(z, k, (const u64 *)d_rlk, prep + (u64)k * 4 * n, 2, n, st)) != FHE_OK) return rc;
-    return bfv_relinearize_with(z, q, n, pq, prep, d_c, d_out, batch, st);
+    if ((rc = bfv_rlk_prepare(z, h, n, (const u64 *)d_rlk, prep, prep + 12 * n, st)) != FHE_OK) return rc;
+    return bfv_relinearize_with(z, h, q, n, pq, prep, d_c, d_out, batch, st);
 }
 
 static int bfv_mul_common(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, bool prepared, const void *d_ab,
@@ -622,7 +701,7 @@ static int bfv_mul_common(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const
     // the tensor result lives in workspace slot 0 (both stages use slot 1); a stream-ordered
     // allocation per call cost up to 2 ms at 2048 ciphertexts whenever the pool had trimmed itself.
     // Sized for the on-the-fly key as well, so that fhe_bfv_relinearize_dev's request does not move it.
-    const size_t kw = 3 * 4 * (size_t)n;
+    const size_t kw = 16 * (size_t)n;
     void *c = nullptr;
     int rc = fhe_workspace_get(0, (3 * batch * n + kw) * 8, (hipStream_t)hip_stream, &c);
     if (rc != FHE_OK) return rc;

@@ -94,15 +94,15 @@ __global__ __launch_bounds__(256) void zr_tensor_kernel(const u64 *__restrict__ 
     }
 }
 
-// c[r][b][j] = x[b][j] * y[r][j]   (one key polynomial y[r] against the whole batch)
+// c[r][b][j] = x[b][j] * y[r][j]   (key polynomials y[r] against the whole batch; x is read once for all rows)
 __global__ __launch_bounds__(256) void zr_mul_bcast_kernel(const u64 *__restrict__ x,
                                                            const u64 *__restrict__ y, u64 *__restrict__ c,
                                                            u64 batch, u32 n2, u32 rows, Mod m) {
-    const u64 per = batch * n2, total = per * rows, stride = (u64)gridDim.x * 256;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const u64 r = i / per, bj = i - r * per;
+    const u64 per = batch * n2, stride = (u64)gridDim.x * 256;
+    for (u64 bj = (u64)blockIdx.x * 256 + threadIdx.x; bj < per; bj += stride) {
         const u32 j = (u32)(bj % n2);
-        c[i] = mul_mod_var(x[bj], y[r * n2 + j], m);
+        const u64 xv = x[bj];
+        for (u32 r = 0; r < rows; r++) c[(u64)r * per + bj] = mul_mod_var(xv, y[(u64)r * n2 + j], m);
     }
 }
 
@@ -282,9 +282,35 @@ __global__ __launch_bounds__(256) void zr_split_mdr_kernel(const u64 *__restrict
 // rows f and f + F/2 of its column, i.e. coefficients j and j + n of the 2n-word convolution — exactly the pair the
 // fold subtracts — so the scaled, rounded, folded Z_q words are formed in registers and the 2n-word integers are
 // never written (BFV tensor at N = 8192: one kernel and 0.8 GB of traffic less per 2048 ciphertext pairs).
-template <int LA, int CW>
+// the strided last pass of an inverse transform on one column tile: load (lazy values of the contiguous pass), rounds;
+// leaves register k = row (k << A0) | tf of column c, below 2q.  FIRST: nobody has touched the LDS tile yet.
+template <int LA, int CW, bool FIRST>
+__device__ __forceinline__ void inv_strided_tile(u64 (&v)[16], const u64 *__restrict__ pin, u64 *lds, const Tw *ltw, u32 lb, u32 c, u32 tf,
+                                                 const Mod &m, const Tw ninv, const Tw s_ninv) {
+    using C = StridedCfg<LA, CW>;
+    constexpr int ALAST = C::a_of(C::NR - 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<ALAST>(tf, k) << lb) + c) * 8u);
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        round_inv_sel<4, false, true, 4>(v, ltw, (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        exchange_strided<CW, A, C::a_of(1), FIRST>(v, lds, c, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        round_inv_sel<4, false, true, 4>(v, ltw, (1u << LS) + (tf >> A), m, ninv, s_ninv);
+        exchange_strided<CW, A, C::A0, FIRST && (C::NR <= 2)>(v, lds, c, tf);
+    }
+    round_inv_sel<C::R0, true, true, 4>(v, ltw, 1u, m, ninv, s_ninv);
+}
+
+// DUAL = false: output polynomial `poly` = fold(mdr(intt(in[poly])))                       (tensor, one prime)
+// DUAL = true:  output (o, b) = addend + fold(mdr(intt(in[2o][b]) + (intt(in[2o+1][b]) << h)))   (relinearisation with the
+//               split key: the two half-products meet in one thread, the recombined integers are never written)
+template <int LA, int CW, bool DUAL>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void zr_inv_strided_mdr_kernel(PassArgs a, u64 *__restrict__ outq, u64 q,
-                                                                                      double numf, double denf) {
+                                                                                      double numf, double denf,
+                                                                                      const u64 *__restrict__ addend, u32 h, u64 batch) {
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -293,36 +319,37 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void zr_inv_strided_mdr_k
     const u32 lcg = lb - __builtin_ctz(CW);
     const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
     const u64 poly = (u64)(blockIdx.x >> lcg);
-    const u64 *__restrict__ pin = a.in + (poly << a.log_n) + (u64)cg * CW;
     const Mod &m = a.mod;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
-    constexpr int ALAST = C::a_of(C::NR - 1);
-    u64 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<ALAST>(tf, k) << lb) + c) * 8u);
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
     __syncthreads();
-    if constexpr (C::NR > 2) {
-        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv_sel<4, false, true, 4>(v, ltw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
-        exchange_strided<CW, A, C::a_of(1), true>(v, lds, c, tf);
+    u64 src = poly;
+    if (DUAL) { const u64 o = poly / batch, b = poly - o * batch; src = (2 * o) * batch + b; }
+    u64 v[16];
+    inv_strided_tile<LA, CW, true>(v, a.in + (src << a.log_n) + (u64)cg * CW, lds, ltw, lb, c, tf, m, a.ninv, a.s_ninv);
+    u64 lo[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo[k] = canon2(v[k], m);
+    if (DUAL) {
+        inv_strided_tile<LA, CW, false>(v, a.in + ((src + batch) << a.log_n) + (u64)cg * CW, lds, ltw, lb, c, tf, m, a.ninv, a.s_ninv);
+#pragma unroll
+        for (int k = 0; k < 16; k++) lo[k] += canon2(v[k], m) << h;       // modulo 2^64: what `as i64` keeps
     }
-    if constexpr (C::NR > 1) {
-        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv_sel<4, false, true, 4>(v, ltw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
-        exchange_strided<CW, A, C::A0, (C::NR <= 2)>(v, lds, c, tf);
-    }
-    round_inv_sel<C::R0, true, true, 4>(v, ltw, 1u, m, a.ninv, a.s_ninv);
     // register k holds row (k << A0) | tf: k and k + 8 are rows f and f + F/2 = coefficients j and j + n
     const u32 nq = 1u << (a.log_n - 1);                            // n: words per output polynomial
-    u64 *__restrict__ po = outq + poly * nq + (u64)cg * CW + c;
+    const u64 obase = poly * nq + (u64)cg * CW + c;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const u32 f = ((u32)k << C::A0) | tf;
-        const long long lo = (long long)canon2(v[k], m), hi = (long long)canon2(v[k + 8], m);
-        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
-        const u64 zh = zq_from_f64(q, round((numf * (double)hi) / denf));   // slot 2n-1 of a (2n-1)-term convolution is 0
-        po[(u64)f << lb] = zl >= zh ? zl - zh : (q + zl) - zh;    // Zq::sub, zq.rs:259-276
+        const u64 zl = zq_from_f64(q, round((numf * (double)(long long)lo[k]) / denf));
+        const u64 zh = zq_from_f64(q, round((numf * (double)(long long)lo[k + 8]) / denf));   // slot 2n-1 of a (2n-1)-term convolution is 0
+        u64 r = zl >= zh ? zl - zh : (q + zl) - zh;               // Zq::sub, zq.rs:259-276
+        const u64 idx = obase + ((u64)f << lb);
+        if (DUAL) {
+            r += addend[idx];
+            if (r >= q) r -= q;                                    // Zq::add, zq.rs:219-231
+        }
+        outq[idx] = r;
     }
 }
 
@@ -443,31 +470,36 @@ static int z_crt_mdr(const ZCtx &z, const u64 *r1, const u64 *r2, const u64 *r3,
     return FHE_OK;
 }
 
-// inverse transform (two-pass sizes, one prime) whose last pass scales, rounds and folds: rows x 2n residues in
-// (NTT domain), rows x n words of Z_q out.  hipErrorNotSupported: the caller takes z_inverse + z_crt_mdr.
-static hipError_t z_inverse_mdr(const ZCtx &z, u64 *r, u64 *out, u64 rows, u64 q, u64 num, u64 den, hipStream_t st) {
+// inverse transform (two-pass sizes, one prime) whose last pass scales, rounds and folds: residues in (NTT domain),
+// words of Z_q out.  Plain: `rows` polynomials of 2n -> rows x n.  Dual (addend != nullptr): the 4 x batch half-product
+// rows of the split-key relinearisation -> 2 x batch x n, recombined with shift h and added to `addend`.
+// hipErrorNotSupported: the caller takes z_inverse + the element-wise kernel.
+static hipError_t z_inverse_mdr(const ZCtx &z, u64 *r, u64 *out, u64 rows, u64 q, u64 num, u64 den, const u64 *addend, u32 h, u64 batch,
+                                hipStream_t st) {
     const fhe::DevicePlan &dp = z.dp[0];
     const int L = dp.log_n;
     if (z.K != 1 || !dp.wide || L <= fhe::kMaxSinglePassLog) return hipErrorNotSupported;
-    hipError_t e = fhe::launch_ntt_inverse_first_pass(dp, r, r, rows, st);
+    const bool dual = addend != nullptr;
+    hipError_t e = fhe::launch_ntt_inverse_first_pass(dp, r, r, dual ? 4 * batch : rows, st);
     if (e != hipSuccess) return e;
     fhe::PassArgs a{};
     a.tw = dp.tw_inv; a.mod = dp.mod; a.ninv = dp.ninv; a.s_ninv = dp.s_ninv; a.log_n = dp.log_n; a.in = r; a.batch = rows;
     const int LA = L - fhe::contig_bits(L);
-    fhe::KernelTimer kt_("zr_inv_strided_mdr", LA, st);
-#define MDR_PASS(LA_, CW_)                                                                                              \
+    const u64 outs = dual ? 2 * batch : rows;
+    fhe::KernelTimer kt_(dual ? "zr_inv_strided_mdr2" : "zr_inv_strided_mdr", LA, st);
+#define MDR_PASS(LA_, CW_, DUAL_)                                                                                       \
     {                                                                                                                   \
         using C = fhe::StridedCfg<LA_, CW_>;                                                                            \
-        const u64 grid = ((1ull << (L - LA_)) / CW_) * rows;                                                            \
+        const u64 grid = ((1ull << (L - LA_)) / CW_) * outs;                                                            \
         if (grid > 0x7fffffffull) return hipErrorInvalidValue;                                                          \
-        if ((e = fhe::allow_big_lds((const void *)fhe::zr_inv_strided_mdr_kernel<LA_, CW_>, C::LDS_BYTES)) != hipSuccess) return e; \
-        hipLaunchKernelGGL((fhe::zr_inv_strided_mdr_kernel<LA_, CW_>), dim3((unsigned)grid), dim3(C::TH), C::LDS_BYTES, st, a, out, q, \
-                           (double)num, (double)den);                                                                   \
+        if ((e = fhe::allow_big_lds((const void *)fhe::zr_inv_strided_mdr_kernel<LA_, CW_, DUAL_>, C::LDS_BYTES)) != hipSuccess) return e; \
+        hipLaunchKernelGGL((fhe::zr_inv_strided_mdr_kernel<LA_, CW_, DUAL_>), dim3((unsigned)grid), dim3(C::TH), C::LDS_BYTES, st, a, out, q, \
+                           (double)num, (double)den, addend, h, batch);                                                 \
     }
     switch (LA) {
-        case 6: MDR_PASS(6, 128) break;
-        case 7: MDR_PASS(7, 64) break;
-        case 8: MDR_PASS(8, 32) break;
+        case 6: if (dual) MDR_PASS(6, 128, true) else MDR_PASS(6, 128, false) break;
+        case 7: if (dual) MDR_PASS(7, 64, true) else MDR_PASS(7, 64, false) break;
+        case 8: if (dual) MDR_PASS(8, 32, true) else MDR_PASS(8, 32, false) break;
         default: return hipErrorNotSupported;
     }
 #undef MDR_PASS
@@ -560,7 +592,7 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
         }
         LAUNCH_OK("zr_tensor_kernel");
         if (z.K == 1) {   // one prime: scale by t/q, round, reduce and fold in the inverse's last pass
-            hipError_t e = z_inverse_mdr(z, Rk, (u64 *)d_c, 3 * batch, q, t, q, st);
+            hipError_t e = z_inverse_mdr(z, Rk, (u64 *)d_c, 3 * batch, q, t, q, nullptr, 0, batch, st);
             if (e == hipSuccess) return FHE_OK;
             if (e != hipErrorNotSupported) return fhe_hip_fail(e, "zr_inv_strided_mdr_kernel");
             (void)hipGetLastError();
@@ -638,9 +670,13 @@ static int bfv_relinearize_with(const ZCtx &z, unsigned h, uint64_t q, uint64_t 
     if (h) {   // one prime, key halves: rows [rlk0_lo | rlk0_hi | rlk1_lo | rlk1_hi] x batch
         if ((rc = z_forward_src(z, 0, c2, X, batch, n, st)) != FHE_OK) return rc;
         { fhe::KernelTimer kt_("zr_mul_bcast", 0, st);
-        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(4 * words)), dim3(256), 0, st, (const u64 *)X, d_prep, R, (u64)batch, (u32)n2, (u32)4, z.cc.m[0]);
+        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)X, d_prep, R, (u64)batch, (u32)n2, (u32)4, z.cc.m[0]);
         }
         LAUNCH_OK("zr_mul_bcast_kernel");
+        // (the dual form of zr_inv_strided_mdr_kernel — both halves' last passes in one kernel that recombines, scales,
+        // rounds, folds and adds (c0, c1) — is available through z_inverse_mdr(.., addend, h, ..) but measured slower than
+        // the inverse + element-wise kernel below: 833 vs 382 + 411 us per 2048 ciphertexts; the f64 division sits badly
+        // in a VALU-bound pass when it serves two transforms instead of one)
         if ((rc = z_inverse(z, 0, R, R, 4 * batch, st)) != FHE_OK) return rc;
         { fhe::KernelTimer kt_("zr_split_mdr", 0, st);
         hipLaunchKernelGGL(fhe::zr_split_mdr_kernel, dim3(fhe_ew_grid(2 * bn)), dim3(256), 0, st, (const u64 *)R, (const u64 *)d_c, (u64 *)d_out, (u64)batch, (u32)n, (u32)h, (u64)q, (u64)1, (u64)p);
@@ -652,7 +688,7 @@ static int bfv_relinearize_with(const ZCtx &z, unsigned h, uint64_t q, uint64_t 
         if ((rc = z_forward_src(z, k, c2, X, batch, n, st)) != FHE_OK) return rc;
         u64 *Rk = R + 2 * (u64)k * words;
         { fhe::KernelTimer kt_("zr_mul_bcast", 0, st);
-        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(2 * words)), dim3(256), 0, st, (const u64 *)X, d_prep + (u64)k * 2 * n2, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
+        hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)X, d_prep + (u64)k * 2 * n2, Rk, (u64)batch, (u32)n2, (u32)2, z.cc.m[k]);
         }
         LAUNCH_OK("zr_mul_bcast_kernel");
         if ((rc = z_inverse(z, k, Rk, Rk, 2 * batch, st)) != FHE_OK) return rc;

@@ -304,13 +304,10 @@ __device__ __forceinline__ void inv_strided_tile(u64 (&v)[16], const u64 *__rest
     round_inv_sel<C::R0, true, true, 4>(v, ltw, 1u, m, ninv, s_ninv);
 }
 
-// DUAL = false: output polynomial `poly` = fold(mdr(intt(in[poly])))                       (tensor, one prime)
-// DUAL = true:  output (o, b) = addend + fold(mdr(intt(in[2o][b]) + (intt(in[2o+1][b]) << h)))   (relinearisation with the
-//               split key: the two half-products meet in one thread, the recombined integers are never written)
-template <int LA, int CW, bool DUAL>
+// output polynomial `poly` = fold(from_f64(round(num * intt(in[poly]) / den))): see above
+template <int LA, int CW>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void zr_inv_strided_mdr_kernel(PassArgs a, u64 *__restrict__ outq, u64 q,
-                                                                                      double numf, double denf,
-                                                                                      const u64 *__restrict__ addend, u32 h, u64 batch) {
+                                                                                      double numf, double denf) {
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -323,33 +320,18 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void zr_inv_strided_mdr_k
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
     __syncthreads();
-    u64 src = poly;
-    if (DUAL) { const u64 o = poly / batch, b = poly - o * batch; src = (2 * o) * batch + b; }
     u64 v[16];
-    inv_strided_tile<LA, CW, true>(v, a.in + (src << a.log_n) + (u64)cg * CW, lds, ltw, lb, c, tf, m, a.ninv, a.s_ninv);
-    u64 lo[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) lo[k] = canon2(v[k], m);
-    if (DUAL) {
-        inv_strided_tile<LA, CW, false>(v, a.in + ((src + batch) << a.log_n) + (u64)cg * CW, lds, ltw, lb, c, tf, m, a.ninv, a.s_ninv);
-#pragma unroll
-        for (int k = 0; k < 16; k++) lo[k] += canon2(v[k], m) << h;       // modulo 2^64: what `as i64` keeps
-    }
+    inv_strided_tile<LA, CW, true>(v, a.in + (poly << a.log_n) + (u64)cg * CW, lds, ltw, lb, c, tf, m, a.ninv, a.s_ninv);
     // register k holds row (k << A0) | tf: k and k + 8 are rows f and f + F/2 = coefficients j and j + n
     const u32 nq = 1u << (a.log_n - 1);                            // n: words per output polynomial
-    const u64 obase = poly * nq + (u64)cg * CW + c;
+    u64 *__restrict__ po = outq + poly * nq + (u64)cg * CW + c;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const u32 f = ((u32)k << C::A0) | tf;
-        const u64 zl = zq_from_f64(q, round((numf * (double)(long long)lo[k]) / denf));
-        const u64 zh = zq_from_f64(q, round((numf * (double)(long long)lo[k + 8]) / denf));   // slot 2n-1 of a (2n-1)-term convolution is 0
-        u64 r = zl >= zh ? zl - zh : (q + zl) - zh;               // Zq::sub, zq.rs:259-276
-        const u64 idx = obase + ((u64)f << lb);
-        if (DUAL) {
-            r += addend[idx];
-            if (r >= q) r -= q;                                    // Zq::add, zq.rs:219-231
-        }
-        outq[idx] = r;
+        const long long lo = (long long)canon2(v[k], m), hi = (long long)canon2(v[k + 8], m);
+        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
+        const u64 zh = zq_from_f64(q, round((numf * (double)hi) / denf));   // slot 2n-1 of a (2n-1)-term convolution is 0
+        po[(u64)f << lb] = zl >= zh ? zl - zh : (q + zl) - zh;    // Zq::sub, zq.rs:259-276
     }
 }
 
@@ -470,36 +452,34 @@ static int z_crt_mdr(const ZCtx &z, const u64 *r1, const u64 *r2, const u64 *r3,
     return FHE_OK;
 }
 
-// inverse transform (two-pass sizes, one prime) whose last pass scales, rounds and folds: residues in (NTT domain),
-// words of Z_q out.  Plain: `rows` polynomials of 2n -> rows x n.  Dual (addend != nullptr): the 4 x batch half-product
-// rows of the split-key relinearisation -> 2 x batch x n, recombined with shift h and added to `addend`.
-// hipErrorNotSupported: the caller takes z_inverse + the element-wise kernel.
-static hipError_t z_inverse_mdr(const ZCtx &z, u64 *r, u64 *out, u64 rows, u64 q, u64 num, u64 den, const u64 *addend, u32 h, u64 batch,
-                                hipStream_t st) {
+// inverse transform (two-pass sizes, one prime) whose last pass scales, rounds and folds: rows x 2n residues in
+// (NTT domain), rows x n words of Z_q out.  hipErrorNotSupported: the caller takes z_inverse + z_crt_mdr.
+// (For the split-key relinearisation a dual form of the kernel — both halves' last passes in one kernel that also
+// recombines and adds (c0, c1) — was measured slower than inverse + zr_split_mdr_kernel, 833 vs 382 + 411 us per
+// 2048 ciphertexts: the f64 division sits badly in a VALU-bound pass when it serves two transforms; not kept.)
+static hipError_t z_inverse_mdr(const ZCtx &z, u64 *r, u64 *out, u64 rows, u64 q, u64 num, u64 den, hipStream_t st) {
     const fhe::DevicePlan &dp = z.dp[0];
     const int L = dp.log_n;
     if (z.K != 1 || !dp.wide || L <= fhe::kMaxSinglePassLog) return hipErrorNotSupported;
-    const bool dual = addend != nullptr;
-    hipError_t e = fhe::launch_ntt_inverse_first_pass(dp, r, r, dual ? 4 * batch : rows, st);
+    hipError_t e = fhe::launch_ntt_inverse_first_pass(dp, r, r, rows, st);
     if (e != hipSuccess) return e;
     fhe::PassArgs a{};
     a.tw = dp.tw_inv; a.mod = dp.mod; a.ninv = dp.ninv; a.s_ninv = dp.s_ninv; a.log_n = dp.log_n; a.in = r; a.batch = rows;
     const int LA = L - fhe::contig_bits(L);
-    const u64 outs = dual ? 2 * batch : rows;
-    fhe::KernelTimer kt_(dual ? "zr_inv_strided_mdr2" : "zr_inv_strided_mdr", LA, st);
-#define MDR_PASS(LA_, CW_, DUAL_)                                                                                       \
+    fhe::KernelTimer kt_("zr_inv_strided_mdr", LA, st);
+#define MDR_PASS(LA_, CW_)                                                                                              \
     {                                                                                                                   \
         using C = fhe::StridedCfg<LA_, CW_>;                                                                            \
-        const u64 grid = ((1ull << (L - LA_)) / CW_) * outs;                                                            \
+        const u64 grid = ((1ull << (L - LA_)) / CW_) * rows;                                                            \
         if (grid > 0x7fffffffull) return hipErrorInvalidValue;                                                          \
-        if ((e = fhe::allow_big_lds((const void *)fhe::zr_inv_strided_mdr_kernel<LA_, CW_, DUAL_>, C::LDS_BYTES)) != hipSuccess) return e; \
-        hipLaunchKernelGGL((fhe::zr_inv_strided_mdr_kernel<LA_, CW_, DUAL_>), dim3((unsigned)grid), dim3(C::TH), C::LDS_BYTES, st, a, out, q, \
-                           (double)num, (double)den, addend, h, batch);                                                 \
+        if ((e = fhe::allow_big_lds((const void *)fhe::zr_inv_strided_mdr_kernel<LA_, CW_>, C::LDS_BYTES)) != hipSuccess) return e; \
+        hipLaunchKernelGGL((fhe::zr_inv_strided_mdr_kernel<LA_, CW_>), dim3((unsigned)grid), dim3(C::TH), C::LDS_BYTES, st, a, out, q, \
+                           (double)num, (double)den);                                                                   \
     }
     switch (LA) {
-        case 6: if (dual) MDR_PASS(6, 128, true) else MDR_PASS(6, 128, false) break;
-        case 7: if (dual) MDR_PASS(7, 64, true) else MDR_PASS(7, 64, false) break;
-        case 8: if (dual) MDR_PASS(8, 32, true) else MDR_PASS(8, 32, false) break;
+        case 6: MDR_PASS(6, 128) break;
+        case 7: MDR_PASS(7, 64) break;
+        case 8: MDR_PASS(8, 32) break;
         default: return hipErrorNotSupported;
     }
 #undef MDR_PASS
@@ -592,7 +572,7 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
         }
         LAUNCH_OK("zr_tensor_kernel");
         if (z.K == 1) {   // one prime: scale by t/q, round, reduce and fold in the inverse's last pass
-            hipError_t e = z_inverse_mdr(z, Rk, (u64 *)d_c, 3 * batch, q, t, q, nullptr, 0, batch, st);
+            hipError_t e = z_inverse_mdr(z, Rk, (u64 *)d_c, 3 * batch, q, t, q, st);
             if (e == hipSuccess) return FHE_OK;
             if (e != hipErrorNotSupported) return fhe_hip_fail(e, "zr_inv_strided_mdr_kernel");
             (void)hipGetLastError();
@@ -673,10 +653,6 @@ static int bfv_relinearize_with(const ZCtx &z, unsigned h, uint64_t q, uint64_t 
         hipLaunchKernelGGL(fhe::zr_mul_bcast_kernel, dim3(fhe_ew_grid(words)), dim3(256), 0, st, (const u64 *)X, d_prep, R, (u64)batch, (u32)n2, (u32)4, z.cc.m[0]);
         }
         LAUNCH_OK("zr_mul_bcast_kernel");
-        // (the dual form of zr_inv_strided_mdr_kernel — both halves' last passes in one kernel that recombines, scales,
-        // rounds, folds and adds (c0, c1) — is available through z_inverse_mdr(.., addend, h, ..) but measured slower than
-        // the inverse + element-wise kernel below: 833 vs 382 + 411 us per 2048 ciphertexts; the f64 division sits badly
-        // in a VALU-bound pass when it serves two transforms instead of one)
         if ((rc = z_inverse(z, 0, R, R, 4 * batch, st)) != FHE_OK) return rc;
         { fhe::KernelTimer kt_("zr_split_mdr", 0, st);
         hipLaunchKernelGGL(fhe::zr_split_mdr_kernel, dim3(fhe_ew_grid(2 * bn)), dim3(256), 0, st, (const u64 *)R, (const u64 *)d_c, (u64 *)d_out, (u64)batch, (u32)n, (u32)h, (u64)q, (u64)1, (u64)p);

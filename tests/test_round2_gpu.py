@@ -455,7 +455,9 @@ def test_fused_external_product_large_batch_single_part(pkg, oracle):
     assert torch.equal(out2.flip(0), out)
 
 
-@pytest.mark.parametrize("q,n,p,t,batch", [(Q16, 16, Q16 * Q16, 2, 5), (Q16, 8192, Q16 * Q16, 2, 3), (Q61, 64, 1 << 1, 4, 2)])
+@pytest.mark.parametrize("q,n,p,t,batch", [(Q16, 16, Q16 * Q16, 2, 5), (Q16, 8192, Q16 * Q16, 2, 3), (Q61, 64, 1 << 1, 4, 2),
+                                           (Q16, 16384, Q16 * Q16, 2, 1),     # 2n = 2^15: 7 strided stages in the fused last pass
+                                           (12289, 32768, 12289, 3, 1)])      # 2n = 2^16: 8 strided stages; another modulus / t
 def test_bfv_multiply_with_a_resident_relinearisation_key(pkg, oracle, q, n, p, t, batch):
     """fhe_bfv_rlk_prepare_dev once, then fhe_bfv_mul_prepared_dev / fhe_bfv_relinearize_prepared_dev: the words of
     the plain entry points and of the oracle's schoolbook (bfv/src/lib.rs:59-90,251-271), for several batches."""

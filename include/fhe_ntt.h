@@ -196,9 +196,11 @@ int fhe_bfv_mul(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const uint64_t 
                 uint64_t *out, size_t batch);
 int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, const void *d_ab,
                     void *d_out, size_t batch, void *hip_stream);
-/* Resident relinearisation key: rlk reduced modulo each CRT prime and forward-transformed, built once per key
- * (fhe_bfv_rlk_prepared_words words; 0 = invalid parameters) and reused by every later product — the same words
- * as the plain entry points produce. */
+/* Resident relinearisation key (RLWE::mul is called with the same `rlk` for every product of a computation,
+ * bfv/src/lib.rs:87-90; relinearize_204 :251-271): rlk in the form the products consume — split in two halves and
+ * transformed modulo one prime where the half-products fit, reduced and transformed per CRT prime otherwise — built
+ * once per key (fhe_bfv_rlk_prepared_words words; 0 = invalid parameters; the layout is opaque) and reused by every
+ * later call; same words as the plain entry points produce. */
 size_t fhe_bfv_rlk_prepared_words(uint64_t q, uint64_t n, uint64_t pq);
 int fhe_bfv_rlk_prepare_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_rlk, void *d_prepared, void *hip_stream);
 int fhe_bfv_relinearize_prepared_dev(uint64_t q, uint64_t n, uint64_t pq, const void *d_prepared, const void *d_c,

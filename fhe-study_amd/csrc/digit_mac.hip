@@ -39,7 +39,10 @@ namespace fhe {
 //   256 threads, 192 VGPRs, 2 waves per SIMD                                   548 us   <- this form
 //   the same forced into 168 VGPRs (3 waves per SIMD, 21 registers spilled)     584 us
 //   512 threads, 8 accumulators, 128 VGPRs (4 waves per SIMD, 25 spilled)       626 us
-//   transform kernel + separate multiply-accumulate kernel (round 1's form)     330 + ~200 us
+//   transform kernel + separate multiply-accumulate kernel (round 1's form)     349 + 356 us
+// Ablation of this form (tools/abl_digit_mac.py): 553 us = 317 us of transforms + 225 us of multiply-accumulate (no overlap:
+// both phases are VALU-bound; the 128-bit multiply-accumulate costs ~15 issue slots, ~60 cycles).  Requesting the key rows
+// one unit ahead (two register buffers, 228 VGPRs) changed nothing (565 us): the phase is not bound by L2 latency.
 // and with 32 accumulators (n = 4096, NC = 2: key switching) the fused kernel is SLOWER than the two-kernel form
 // (0.52-0.56 vs 0.46 ms per 256 ciphertexts), so shapes beyond 16 accumulators keep the two kernels.
 template <int LP, int NC>
@@ -103,13 +106,16 @@ __global__ __launch_bounds__((DigitMacCfg<LP, NC>::TH)) void digit_mac_kernel(Di
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = digit_of<SRC>(row[field_of<C::A0>(tf, k)], a.l, d);
         // FRESH = false: the tile was read by the previous step's multiply phase
+#ifndef FHE_DM_ABLATE_NTT     // timing-only builds (tools/abl_digit_mac.py): the kernel without its transform / its multiply phase
         fwd_rounds_contig<LP, true, true, 2, false, true>(v, lds, ltw, a.tw, 0u, 0u, w, tf, m, llut);
+#endif
         // every thread rewrites exactly the slots it gathered in the last exchange: no barrier before
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[pad16(w * C::M + field_of<0>(tf, k))] = canon4(v[k], m);
         __syncthreads();
         // ---- multiply-accumulate: W transforms x NC key rows at this thread's PPT positions ----
         const u32 nu = min((u32)W, t_end - t0);
+#ifndef FHE_DM_ABLATE_MAC
 #pragma unroll
         for (int u = 0; u < W; u++) {
             if ((u32)u < nu) {
@@ -135,6 +141,9 @@ __global__ __launch_bounds__((DigitMacCfg<LP, NC>::TH)) void digit_mac_kernel(Di
                 }
             }
         }
+#else
+        acc[0][0].mac(lds[pad16(j0)], 3);
+#endif
         pending += nu;
         if (pending + W > (u32)K::CHUNK) {                           // the next step could overflow 2^128
 #pragma unroll

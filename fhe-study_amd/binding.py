@@ -46,7 +46,7 @@ EXPORTS = [
     "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
-    "fhe_ntt_plan_prepare", "fhe_ntt_set_check_canonical", "fhe_shard_range",
+    "fhe_ntt_plan_prepare", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace",
     "fhe_tggsw_prepared_words", "fhe_tggsw_prepare_dev", "fhe_tggsw_external_product_prepared_dev",
     "fhe_bfv_rlk_prepared_words", "fhe_bfv_rlk_prepare_dev", "fhe_bfv_relinearize_prepared_dev", "fhe_bfv_mul_prepared_dev",
     # next rows: exact products over Z / mod 2^64 on top of the engine
@@ -218,6 +218,7 @@ def load_library():
     L.fhe_rq_div_round_dev.argtypes = [_u64, _u64, _vp, _vp, _sz, _vp]
     L.fhe_ntt_device_count.argtypes = []
     L.fhe_ntt_plan_prepare.argtypes = [_vp]
+    L.fhe_ntt_release_stream_workspace.argtypes = [_vp]
     L.fhe_ntt_set_check_canonical.argtypes = [_int]
     L.fhe_shard_range.argtypes = [_sz, _uint, _uint, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
     L.fhe_last_error.restype = ctypes.c_char_p

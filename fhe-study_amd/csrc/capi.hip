@@ -461,6 +461,25 @@ static void stage_free_all() {
     g_stage_idle_bytes = 0;
 }
 
+// A caller that creates and destroys streams hands their workspaces back here (after synchronising the stream and
+// before destroying it); without the call they live until fhe_ntt_shutdown().
+extern "C" int fhe_ntt_release_stream_workspace(void *hip_stream) {
+    int dev = 0;
+    int rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t tid = st == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0;
+    std::lock_guard<std::mutex> lk(g_ws_lock);
+    for (int slot = 0; slot < 2; slot++) {
+        auto it = g_ws.find(WsKey{slot, dev, st, tid});
+        if (it == g_ws.end()) continue;
+        if (it->second.ptr) (void)hipFree(it->second.ptr);
+        g_ws.erase(it);
+    }
+    return FHE_OK;
+}
+
 void fhe_workspace_free_all() {
     stage_free_all();
     std::lock_guard<std::mutex> lk(g_ws_lock);

@@ -323,6 +323,10 @@ int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, cons
  * needs them on one device, is the caller's (RCCL all-gather / hipMemcpyPeer). */
 int fhe_shard_range(size_t total, unsigned world, unsigned rank, size_t *begin, size_t *end);
 
+/* Library workspaces are kept per (device, stream) until fhe_ntt_shutdown(); a caller about to destroy a stream
+ * returns that stream's workspaces with this call (it synchronises the stream first). */
+int fhe_ntt_release_stream_workspace(void *hip_stream);
+
 int fhe_ntt_device_count(void);            /* HIP devices visible (0 if none) */
 const char *fhe_last_error(void);          /* thread-local, never NULL */
 const char *fhe_ntt_version(void);

@@ -162,6 +162,14 @@ def test_two_streams_share_no_workspace(pkg, oracle):
     for (_, _, _, dc, want), (_, _, eo, ewant) in zip(ops, ext):
         assert np.array_equal(_u64(dc), want)
         assert np.array_equal(_u64(eo), ewant)
+    # a stream about to be destroyed returns its workspaces; the library keeps working on it and on the other one
+    B._check(L.fhe_ntt_release_stream_workspace(s1.cuda_stream))
+    for (s, da, db, dc, want) in ops:
+        dc.zero_()
+        plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for (_, _, _, dc, want) in ops:
+        assert np.array_equal(_u64(dc), want)
 
 
 def test_opt_in_canonical_check_rejects_what_the_reference_cannot_construct(pkg, oracle):

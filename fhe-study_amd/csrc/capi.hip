@@ -891,6 +891,7 @@ extern "C" int fhe_ntt_shutdown(void) {
         g_timing.clear();
     }
     fhe_workspace_free_all();
+    fhe_ext32_free_all();
     std::lock_guard<std::mutex> lk(g_plans_lock);
     for (auto &kv : g_plans) {
         fhe_ntt_plan *p = kv.second.get();

@@ -43,6 +43,7 @@ fhe::u64 fhe_batch_tile_for(const fhe_ntt_plan *plan);
 // grow-only scratch per (slot, device, stream); slot 0 = fhe_rq_mul_dev / bfv tensor, slot 1 = zring, glue
 int fhe_workspace_get(int slot, size_t bytes, hipStream_t st, void **out);
 void fhe_workspace_free_all();
+void fhe_ext32_free_all();   // zring.hip: tables of the 30-bit-prime external product
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
 int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);
 void fhe_stage_release(void *ptr, size_t bytes, int dev);

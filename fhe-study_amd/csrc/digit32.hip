@@ -1,0 +1,474 @@
+// digit32.hip — the TGGSW x TGLWE external product on TWO 30-bit primes with 32-bit arithmetic.
+//
+// Why a second arithmetic: every kernel of the 61-bit engine is bound by the issue rate of 32-bit multiplies (ten per
+// Shoup butterfly; ~15 issue slots per 128-bit multiply-accumulate).  The external product's integers are
+// small — a half-sum  S = sum_t key_half[t] * digit_t  is below (k+1) l n 2^32 <= 2^58 in magnitude — so they are also
+// determined by their residues modulo two primes just below 2^30 (product 2^59.9995).  There a butterfly is 3 multiplies
+// (v_mul_hi_u32 + 2 v_mul_lo_u32, Harvey's lazy [0,4q) in one word) and a multiply-accumulate ONE v_mad_u64_u32 into a
+// 64-bit accumulator that is reduced every 16 terms.  Twice the transforms, a third of the multiplies each; the
+// accumulate phase shrinks from ~60 to ~6 cycles per term.
+//
+// What is computed is the reference's  TGGSW * TGLWE  (tfhe/src/tggsw.rs:45-62,139-149; Tn::decompose beta = 2,
+// ring_torus.rs:67-77, torus.rs:43-52) with the key words split in 32-bit halves exactly as in zring.hip's one-prime
+// form:  out[c] = lift(S_lo[c]) + (lift(S_hi[c]) << 32)  mod 2^64,  lift = the centred CRT lift from the two residues.
+//
+// Kernels (all single-pass sizes 2^8 <= n <= 2^10 with k = 1, the shape of BASELINE.json configs[3]; anything else keeps
+// the 61-bit path of zring.hip / digit_mac.hip):
+//   ntt32_fwd_key_kernel   key preparation: halves reduced mod p, forward transform, stored as u32
+//   digit_mac32_kernel     digit extraction -> forward transform modulo BOTH primes (round 0 by table look-up, as in
+//                          ntt_rounds.hpp round0_bits) -> multiply-accumulate against the key rows, per (ciphertext, part)
+//   digit_tail32_kernel    sum of the parts -> inverse transforms modulo both primes -> CRT lift -> lo + (hi << 32)
+// Index algebra, register windows and LDS exchanges are those of ntt_rounds.hpp (ContigCfg, field_of, pad16).
+#include "digit32.hpp"
+#include "ntt_rounds.hpp"
+
+namespace fhe {
+
+// ---- Z_p arithmetic in one 32-bit word, p < 2^30 ---------------------------------------------------------------
+
+__device__ __forceinline__ u32 csub_u32(u32 x, u32 m) { return min(x, x - m); }     // x - m if x >= m (x < 2m), else x
+// y * w mod p, lazily in [0, 2p), for ANY 32-bit y and w < p
+__device__ __forceinline__ u32 mul_shoup32(u32 y, Tw32 t, u32 p) { return y * t.w - __umulhi(y, t.wp) * p; }
+// Cooley-Tukey butterfly (ntt.rs:57-62), Harvey's lazy form: x, y in [0,4p) -> [0,4p)
+__device__ __forceinline__ void ct32(u32 &x, u32 &y, Tw32 t, u32 p, u32 p2) {
+    const u32 u = csub_u32(x, p2);
+    const u32 v = mul_shoup32(y, t, p);
+    x = u + v;
+    y = u - v + p2;
+}
+// Gentleman-Sande butterfly (ntt.rs:91-96): x, y in [0,2p) -> [0,2p)
+__device__ __forceinline__ void gs32(u32 &x, u32 &y, Tw32 t, u32 p, u32 p2) {
+    const u32 d = x - y + p2;
+    x = csub_u32(x + y, p2);
+    y = mul_shoup32(d, t, p);
+}
+__device__ __forceinline__ u32 canon4_32(u32 x, u32 p, u32 p2) { return csub_u32(csub_u32(x, p2), p); }
+
+template <int R, int I0 = 0>
+__device__ __forceinline__ void round_fwd32(u32 (&v)[16], const Tw32 *__restrict__ tw, u32 T0, u32 p, u32 p2) {
+#pragma unroll
+    for (int i = I0; i < R; i++) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            const Tw32 t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) ct32(v[g * 2 * span + l], v[g * 2 * span + l + span], t, p, p2);
+        }
+    }
+}
+template <int R>
+__device__ __forceinline__ void round_inv32(u32 (&v)[16], const Tw32 *__restrict__ tw, u32 T0, u32 p, u32 p2) {
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            const Tw32 t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) gs32(v[g * 2 * span + l], v[g * 2 * span + l + span], t, p, p2);
+        }
+    }
+}
+
+template <int LP, int AF, int AT, bool FIRST>
+__device__ __forceinline__ void exchange32(u32 (&v)[16], u32 *lds, u32 w, u32 tf) {
+    constexpr int M = 1 << LP;
+    if (!FIRST) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16(w * M + field_of<AF>(tf, k))] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
+}
+
+// round 0 on BITS by table look-up (see ntt_rounds.hpp round0_bits; tables per prime, built on the host)
+constexpr int kLut32Words = 136;
+template <int R0>
+__device__ __forceinline__ void round0_bits32(u32 (&v)[16], const u32 *lut, const Tw32 *__restrict__ gtw, u32 p, u32 p2) {
+    if constexpr (R0 == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 pt = v[k] + 2u * v[k + 8];
+            v[k] = lut[128 + 2 * pt];
+            v[k + 8] = lut[128 + 2 * pt + 1];
+        }
+    } else {
+        u32 pt[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) pt[c] = v[c] + 2u * v[c + 4] + 4u * v[c + 8] + 8u * v[c + 12];
+        if constexpr (R0 == 2) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint4 y = *reinterpret_cast<const uint4 *>(lut + 4 * pt[c]);
+                v[c] = y.x; v[c + 4] = y.y; v[c + 8] = y.z; v[c + 12] = y.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(lut + 4 * pt[c]);
+                const uint4 b = *reinterpret_cast<const uint4 *>(lut + 64 + 4 * pt[c + 2]);
+                const u32 av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    v[c + 4 * j] = csub_u32(av[j] + bv[j], p);
+                    v[c + 2 + 4 * j] = csub_u32(av[j] - bv[j] + p, p);
+                }
+            }
+            if constexpr (R0 == 4) round_fwd32<4, 3>(v, gtw, 1u, p, p2);
+        }
+    }
+}
+
+// the LP forward stages: window [LP-4, LP) -> window [0,4); BITS: round 0 by look-up; values end below 4p
+template <int LP, bool BITS, bool FRESH>
+__device__ __forceinline__ void fwd_rounds32(u32 (&v)[16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, const u32 *lut, u32 w, u32 tf,
+                                             u32 p, u32 p2) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool in_lds) -> const Tw32 * { return in_lds ? ltw : gtw; };
+    if constexpr (BITS) round0_bits32<C::R0>(v, lut, gtw, p, p2);
+    else round_fwd32<C::R0>(v, gtw, 1u, p, p2);
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        exchange32<LP, C::A0, A, FRESH>(v, lds, w, tf);
+        round_fwd32<4>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), p, p2);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        exchange32<LP, C::a_of(1), A, false>(v, lds, w, tf);
+        round_fwd32<4>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), p, p2);
+    }
+    static_assert(C::NR <= 3, "n <= 4096");
+}
+// the LP inverse stages: window [0,4) (canonical inputs) -> window [LP-4, LP), values below 2p, NOT yet scaled by n^-1
+template <int LP, bool FRESH>
+__device__ __forceinline__ void inv_rounds32(u32 (&v)[16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 w, u32 tf, u32 p, u32 p2) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool in_lds) -> const Tw32 * { return in_lds ? ltw : gtw; };
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        round_inv32<4>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), p, p2);
+        exchange32<LP, A, C::a_of(1), FRESH>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        round_inv32<4>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), p, p2);
+        exchange32<LP, A, C::A0, FRESH && (C::NR <= 2)>(v, lds, w, tf);
+    }
+    round_inv32<C::R0>(v, TW(C::in_lds(0)), 1u, p, p2);
+}
+
+template <int LP>
+struct Cfg32 {
+    using C = ContigCfg<LP>;
+    static constexpr int M = C::M, W = C::W, TH = 256, PPT = M / TH;
+    static constexpr size_t TILE_BYTES = (size_t)(W * M + W * M / 16) * 4;          // one padded tile of u32
+    static constexpr size_t TW_BYTES = (size_t)C::LTW_N * sizeof(Tw32);
+    // two tiles (one per prime), two twiddle tiles, two look-up tables
+    static constexpr size_t LDS_BYTES = 2 * TILE_BYTES + 2 * TW_BYTES + 2 * (size_t)kLut32Words * 4;
+    static_assert(LP >= 8 && LP <= 10, "n = 256 .. 1024");
+};
+
+__device__ __forceinline__ void stage_tw32(Tw32 *ltw, const Tw32 *__restrict__ tw, int count, u32 tid) {
+    for (u32 i = tid; i < (u32)count; i += 256) ltw[i] = tw[i];   // s0 = blk = 0: the local table is the head of the global one
+}
+
+// ---- key preparation: [rows][n] u64 words < 2^32  ->  [prime][rows][n] u32, NTT domain -------------------------
+template <int LP>
+__global__ __launch_bounds__(256) void ntt32_fwd_key_kernel(Ext32Args a) {
+    using C = ContigCfg<LP>;
+    using K = Cfg32<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *lds = reinterpret_cast<u32 *>(smem_raw);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES);
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u32 prime = blockIdx.y;
+    const u32 p = a.p[prime], p2 = 2u * p;
+    const Tw32 *gtw = a.tw_fwd[prime];
+    stage_tw32(ltw, gtw, C::LTW_N, tid);
+    const u64 row = (u64)blockIdx.x * C::W + w;
+    const bool live = row < a.rows;
+    const u64 *__restrict__ src = a.key64 + (live ? row : 0) * C::M;
+    u32 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u64 x = src[field_of<C::A0>(tf, k)];          // a 32-bit half: < 2^32 < 4p
+        u32 r = (u32)x;
+        r = csub_u32(r, p2);
+        v[k] = csub_u32(r, p);
+    }
+    fwd_rounds32<LP, false, true>(v, lds, ltw, gtw, nullptr, w, tf, p, p2);
+    if (live) {
+        u32 *__restrict__ dst = a.key32 + ((u64)prime * a.rows + row) * C::M + tf * 16u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint4 o;
+            o.x = canon4_32(v[4 * j], p, p2); o.y = canon4_32(v[4 * j + 1], p, p2);
+            o.z = canon4_32(v[4 * j + 2], p, p2); o.w = canon4_32(v[4 * j + 3], p, p2);
+            *reinterpret_cast<uint4 *>(dst + 4 * j) = o;
+        }
+    }
+}
+
+// x mod p for x < 2^64, p < 2^30 (Barrett with mu = floor(2^64 / p)): canonical
+__device__ __forceinline__ u32 reduce64_32(u64 x, u32 p, u64 mu) {
+    const u64 qh = __umul64hi(x, mu);
+    u32 r = (u32)(x - qh * p);          // in [0, 2p)
+    return csub_u32(r, p);
+}
+
+// ---- digits -> transforms modulo both primes -> multiply-accumulate ----------------------------------------------
+// key32 layout: [prime][t][c][n], t = row*l + digit, c < NC (NC = 2(k+1): half-major, then component).
+// out: partial sums [b][part][prime][c][n] u32 canonical.
+template <int LP, int NC>
+__global__ __launch_bounds__(256) void digit_mac32_kernel(Ext32Args a) {
+    using C = ContigCfg<LP>;
+    using K = Cfg32<LP>;
+    constexpr int PPT = K::PPT, W = K::W;
+    static_assert(2 * NC * PPT <= 32, "accumulators");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *tile[2] = {reinterpret_cast<u32 *>(smem_raw), reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES)};
+    Tw32 *ltw[2] = {reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES), reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES + K::TW_BYTES)};
+    u32 *llut[2] = {reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES),
+                    reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES) + kLut32Words};
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u64 b = blockIdx.x / a.parts;
+    const u32 part = blockIdx.x % a.parts;
+    const u32 t_begin = part * a.tpp, t_end = min(a.T, t_begin + a.tpp);
+    const u32 n = 1u << LP;
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+        stage_tw32(ltw[pr], a.tw_fwd[pr], C::LTW_N, tid);
+        for (u32 i = tid; i < (u32)kLut32Words; i += 256) llut[pr][i] = a.lut[pr][i];
+    }
+    __syncthreads();
+    const u64 *__restrict__ ct = a.src + b * a.ct_stride;
+
+    u64 acc[2][NC][PPT];
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int i = 0; i < PPT; i++) acc[pr][c][i] = 0;
+    u32 pending = 0;
+    const u32 j0 = tid * PPT;
+    for (u32 t0 = t_begin; t0 < t_end; t0 += W) {
+        const u32 t = t0 + w;
+        const u32 tt = t < t_end ? t : t_begin;               // idle units redo a valid digit, never multiplied
+        const u32 r = tt / a.l, d = tt - r * a.l;
+        const u64 *__restrict__ row = ct + (u64)r * n;
+        u32 bits[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) bits[k] = (u32)((row[field_of<C::A0>(tf, k)] >> (a.l - 1u - d)) & 1ull);
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            const u32 p = a.p[pr], p2 = 2u * p;
+            u32 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = bits[k];
+            // the tile of this prime was read by the previous step's multiply phase: barrier first (FRESH = false)
+            fwd_rounds32<LP, true, false>(v, tile[pr], ltw[pr], a.tw_fwd[pr], llut[pr], w, tf, p, p2);
+            // every thread rewrites exactly the slots it gathered in the last exchange
+#pragma unroll
+            for (int k = 0; k < 16; k++) tile[pr][pad16(w * C::M + field_of<0>(tf, k))] = canon4_32(v[k], p, p2);
+        }
+        __syncthreads();
+        const u32 nu = min((u32)W, t_end - t0);
+#pragma unroll
+        for (int u = 0; u < W; u++) {
+            if ((u32)u < nu) {
+#pragma unroll
+                for (int pr = 0; pr < 2; pr++) {
+                    u32 x[PPT];
+#pragma unroll
+                    for (int i = 0; i < PPT; i++) x[i] = tile[pr][pad16(u * C::M + j0 + i)];
+                    const u32 *__restrict__ g = a.key32 + (((u64)pr * a.T + (t0 + u)) * NC) * n + j0;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        u32 gv[PPT];
+                        if constexpr (PPT == 4) {
+                            const uint4 q4 = *reinterpret_cast<const uint4 *>(g + (u64)c * n);
+                            gv[0] = q4.x; gv[1] = q4.y; gv[2] = q4.z; gv[3] = q4.w;
+                        } else if constexpr (PPT == 2) {
+                            const uint2 q2 = *reinterpret_cast<const uint2 *>(g + (u64)c * n);
+                            gv[0] = q2.x; gv[1] = q2.y;
+                        } else {
+                            gv[0] = g[(u64)c * n];
+                        }
+#pragma unroll
+                        for (int i = 0; i < PPT; i++) acc[pr][c][i] += (u64)gv[i] * x[i];       // < 2^60 per term
+                    }
+                }
+            }
+        }
+        pending += nu;
+        if (pending + W > 15u) {                                  // 16 terms of 2^60 would reach 2^64: reduce first
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int i = 0; i < PPT; i++) acc[pr][c][i] = reduce64_32(acc[pr][c][i], a.p[pr], a.mu[pr]);
+            pending = 1;
+        }
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+        u32 *__restrict__ o = a.part32 + ((((b * a.parts + part) * 2 + pr) * NC) * (u64)n) + j0;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int i = 0; i < PPT; i++) o[(u64)c * n + i] = reduce64_32(acc[pr][c][i], a.p[pr], a.mu[pr]);
+    }
+}
+
+// ---- sum of parts -> inverse transforms (both primes) -> CRT lift -> lo + (hi << 32) ----------------------------------
+// One workgroup = W rows = W / NC ciphertexts; unit w = row (ciphertext, c); every thread runs BOTH primes for its 16
+// coefficients, lifts them and leaves the centred 64-bit integer in the (u64) tile, where the two halves of an output meet.
+template <int LP, int NC>
+__global__ __launch_bounds__(256) void digit_tail32_kernel(Ext32Args a) {
+    using C = ContigCfg<LP>;
+    using K = Cfg32<LP>;
+    static_assert(C::W % NC == 0, "whole ciphertexts per workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // LDS: a u64 tile for the lifted integers, overlaid at first by the two u32 exchange tiles, then the twiddle tiles
+    u64 *tile64 = reinterpret_cast<u64 *>(smem_raw);
+    constexpr size_t T64_BYTES = (size_t)(C::W * C::M + C::W * C::M / 16) * 8;
+    u32 *tile[2] = {reinterpret_cast<u32 *>(smem_raw), reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES)};
+    Tw32 *ltw[2] = {reinterpret_cast<Tw32 *>(smem_raw + T64_BYTES), reinterpret_cast<Tw32 *>(smem_raw + T64_BYTES + K::TW_BYTES)};
+    static_assert(2 * Cfg32<LP>::TILE_BYTES <= T64_BYTES, "the two u32 tiles fit under the u64 tile");
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u32 n = 1u << LP;
+    const u64 rows = a.batch * NC;
+    const u64 R0 = (u64)blockIdx.x * C::W;
+    const u32 live = (u32)min((u64)C::W, rows - R0);
+    const u64 R = R0 + (w < live ? w : 0u);
+    const u64 b = R / NC;
+    const u32 c = (u32)(R - b * NC);
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) stage_tw32(ltw[pr], a.tw_inv[pr], C::LTW_N, tid);
+    __syncthreads();
+    u32 res[2][16];
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+        const u32 p = a.p[pr], p2 = 2u * p;
+        u32 v[16];
+        {
+            const u32 *__restrict__ src = a.part32 + (((b * a.parts) * 2 + pr) * NC + c) * (u64)n + tf * 16u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(src + 4 * j);
+                v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+            }
+            for (u32 q = 1; q < a.parts; q++) {
+                const u32 *__restrict__ sp = src + (u64)q * 2 * NC * n;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(sp + 4 * j);
+                    v[4 * j] = csub_u32(v[4 * j] + x.x, p); v[4 * j + 1] = csub_u32(v[4 * j + 1] + x.y, p);
+                    v[4 * j + 2] = csub_u32(v[4 * j + 2] + x.z, p); v[4 * j + 3] = csub_u32(v[4 * j + 3] + x.w, p);
+                }
+            }
+        }
+        if (pr == 0) inv_rounds32<LP, true>(v, tile[pr], ltw[pr], a.tw_inv[pr], w, tf, p, p2);
+        else inv_rounds32<LP, true>(v, tile[pr], ltw[pr], a.tw_inv[pr], w, tf, p, p2);
+        const Tw32 ni = a.ninv[pr];
+#pragma unroll
+        for (int k = 0; k < 16; k++) res[pr][k] = csub_u32(mul_shoup32(v[k], ni, p), p);      // * n^-1, canonical
+    }
+    // CRT: S = rA + pA * ((rB - rA) * pA^-1 mod pB), centred into (-P/2, P/2]; then the halves meet in the u64 tile
+    const u32 pA = a.p[0], pB = a.p[1];
+    __syncthreads();                                               // the u32 tiles were gathered from by every thread
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 rA = res[0][k], rB = res[1][k];
+        const u32 rAb = csub_u32(rA, pB);                           // rA mod pB (pA - pB < pB)
+        const u32 diff = csub_u32(rB - rAb + pB, pB);
+        const u32 h = csub_u32(mul_shoup32(diff, a.crt, pB), pB);
+        u64 S = (u64)rA + (u64)pA * h;                              // in [0, pA * pB)
+        if (S >= a.halfP) S -= a.P;                                 // two's complement of the centred value
+        tile64[pad16(w * C::M + field_of<C::A0>(tf, k))] = S;
+    }
+    __syncthreads();
+    constexpr int K1 = NC / 2;
+    const u32 cts = live / NC;
+    const u64 b0 = R0 / NC;
+    for (u32 e = tid; e < cts * K1 * n; e += 256) {
+        const u32 j = e & (n - 1), cc = (e >> LP) % K1, bb = (e >> LP) / K1;
+        const u64 lo = tile64[pad16((bb * NC + cc) * C::M + j)], hi = tile64[pad16((bb * NC + K1 + cc) * C::M + j)];
+        a.out[((b0 + bb) * K1 + cc) * (u64)n + j] = lo + (hi << 32);
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------
+template <int LP>
+static hipError_t launch_key32_lp(const Ext32Args &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    using K = Cfg32<LP>;
+    const u64 grid = (a.rows + C::W - 1) / C::W;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)ntt32_fwd_key_kernel<LP>, K::LDS_BYTES)) return e;
+    KernelTimer kt("ntt32_fwd_key", LP, st);
+    hipLaunchKernelGGL((ntt32_fwd_key_kernel<LP>), dim3((unsigned)grid, 2), dim3(256), K::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+template <int LP>
+static hipError_t launch_mac32_lp(const Ext32Args &a, hipStream_t st) {
+    using K = Cfg32<LP>;
+    if constexpr (2 * 4 * K::PPT > 32) {
+        return hipErrorNotSupported;
+    } else {
+        const u64 grid = a.batch * a.parts;
+        if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+        if (hipError_t e = allow_big_lds((const void *)digit_mac32_kernel<LP, 4>, K::LDS_BYTES)) return e;
+        KernelTimer kt("digit_mac32", LP, st);
+        hipLaunchKernelGGL((digit_mac32_kernel<LP, 4>), dim3((unsigned)grid), dim3(256), K::LDS_BYTES, st, a);
+        return hipGetLastError();
+    }
+}
+template <int LP>
+static hipError_t launch_tail32_lp(const Ext32Args &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    using K = Cfg32<LP>;
+    constexpr size_t lds = (size_t)(C::W * C::M + C::W * C::M / 16) * 8 + 2 * K::TW_BYTES;
+    const u64 grid = (a.batch * 4 + C::W - 1) / C::W;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)digit_tail32_kernel<LP, 4>, lds)) return e;
+    KernelTimer kt("digit_tail32", LP, st);
+    hipLaunchKernelGGL((digit_tail32_kernel<LP, 4>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+bool ext32_shape_supported(u64 n, unsigned k, unsigned l) {
+    if (k != 1 || l < 1 || l > 64) return false;
+    if (n != 256 && n != 512 && n != 1024) return false;
+    return (u64)(k + 1) * l * n <= (1ull << 26);
+}
+
+hipError_t launch_ext32_key(const Ext32Args &a, int log_n, hipStream_t st) {
+    switch (log_n) {
+        case 8: return launch_key32_lp<8>(a, st);
+        case 9: return launch_key32_lp<9>(a, st);
+        case 10: return launch_key32_lp<10>(a, st);
+    }
+    return hipErrorNotSupported;
+}
+hipError_t launch_ext32_mac(const Ext32Args &a, int log_n, hipStream_t st) {
+    switch (log_n) {
+        case 8: return launch_mac32_lp<8>(a, st);
+        case 9: return launch_mac32_lp<9>(a, st);
+        case 10: return launch_mac32_lp<10>(a, st);
+    }
+    return hipErrorNotSupported;
+}
+hipError_t launch_ext32_tail(const Ext32Args &a, int log_n, hipStream_t st) {
+    switch (log_n) {
+        case 8: return launch_tail32_lp<8>(a, st);
+        case 9: return launch_tail32_lp<9>(a, st);
+        case 10: return launch_tail32_lp<10>(a, st);
+    }
+    return hipErrorNotSupported;
+}
+
+}  // namespace fhe

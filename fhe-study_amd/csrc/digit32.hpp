@@ -1,0 +1,42 @@
+// digit32.hpp — internal interface of the 30-bit-prime external product (digit32.hip).  Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ntt_kernels.hpp"
+
+namespace fhe {
+
+struct Tw32 { uint32_t w, wp; };                     // twiddle and floor(w * 2^32 / p)
+
+// the two primes: largest below 2^30 with p = 1 mod 2^15; product 2^59.9995 > 2 * 2^58
+constexpr uint32_t kExt32PrimeA = 0x3ffe8001u, kExt32PrimeB = 0x3ffc0001u;
+
+struct Ext32Args {
+    // key preparation
+    const u64 *key64;          // [rows][n] words below 2^32 (the split TGGSW)
+    uint32_t *key32;           // [prime][rows][n], NTT domain
+    u64 rows;
+    // product
+    const u64 *src;            // ciphertexts, source row r of ciphertext b at src + b*ct_stride + r*n
+    u64 ct_stride;
+    uint32_t *part32;          // [batch][parts][prime][NC][n] canonical partial sums
+    u64 *out;                  // [batch][k+1][n]
+    u64 batch;
+    uint32_t l, T, parts, tpp;
+    // per prime
+    const Tw32 *tw_fwd[2], *tw_inv[2];
+    const uint32_t *lut[2];
+    uint32_t p[2];
+    u64 mu[2];                 // floor(2^64 / p)
+    Tw32 ninv[2];              // n^-1 mod p
+    Tw32 crt;                  // pA^-1 mod pB
+    u64 P, halfP;              // pA * pB, ceil(P / 2)
+};
+
+bool ext32_shape_supported(u64 n, unsigned k, unsigned l);
+hipError_t launch_ext32_key(const Ext32Args &a, int log_n, hipStream_t st);
+hipError_t launch_ext32_mac(const Ext32Args &a, int log_n, hipStream_t st);
+hipError_t launch_ext32_tail(const Ext32Args &a, int log_n, hipStream_t st);
+
+}  // namespace fhe

@@ -17,10 +17,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "capi_internal.hpp"
 #include "digit_mac.hpp"
+#include "digit32.hpp"
 #include "ntt_rounds.hpp"
 #include "zq_device.hpp"
 #include "mac_kernel.hpp"
@@ -759,6 +761,105 @@ extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void
     return z_crt(z, true, R, R + words, R + 2 * words, (u64 *)d_out, words, st);
 }
 
+// ---- the 30-bit-prime form of the external product (digit32.hip): per (n, device) tables ---------------------------
+namespace {
+struct Ext32Tables {
+    fhe::Tw32 *fwd[2] = {nullptr, nullptr}, *inv[2] = {nullptr, nullptr};
+    uint32_t *lut[2] = {nullptr, nullptr};
+    fhe::Tw32 ninv[2]{};
+};
+std::mutex g_e32_lock;
+std::map<std::pair<u64, int>, Ext32Tables> g_e32;
+inline fhe::Tw32 tw32(u64 w, u64 p) { return fhe::Tw32{(uint32_t)w, (uint32_t)((w << 32) / p)}; }
+}  // namespace
+
+void fhe_ext32_free_all() {
+    std::lock_guard<std::mutex> lk(g_e32_lock);
+    for (auto &kv : g_e32)
+        for (int i = 0; i < 2; i++) {
+            if (kv.second.fwd[i]) (void)hipFree(kv.second.fwd[i]);
+            if (kv.second.inv[i]) (void)hipFree(kv.second.inv[i]);
+            if (kv.second.lut[i]) (void)hipFree(kv.second.lut[i]);
+        }
+    g_e32.clear();
+}
+
+// fills the per-prime fields of `a` (tables on the current device, built on first use from the same plans — psi by the
+// reference's search, roots[i] = psi^bitrev(i) — as every other transform of the library)
+static int ext32_tables(u64 n, fhe::Ext32Args *a) {
+    int dev = 0;
+    int rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    const u64 primes[2] = {fhe::kExt32PrimeA, fhe::kExt32PrimeB};
+    std::lock_guard<std::mutex> lk(g_e32_lock);
+    Ext32Tables &t = g_e32[std::make_pair(n, dev)];
+    if (!t.fwd[0]) {
+        for (int i = 0; i < 2; i++) {
+            const u64 p = primes[i];
+            const fhe_ntt_plan *plan = nullptr;
+            if ((rc = fhe_ntt_plan_get(p, n, &plan)) != FHE_OK) return rc;
+            std::vector<fhe::Tw32> f(n), v(n);
+            for (u64 k = 0; k < n; k++) { f[k] = tw32(plan->roots[k], p); v[k] = tw32(plan->roots_inv[k], p); }
+            // bit tables: as capi.hip builds them for the 61-bit plans (ntt_rounds.hpp: round0_bits)
+            std::vector<uint32_t> lut(136, 0);
+            const u64 *r = plan->roots.data();
+            auto add = [&](u64 x, u64 y) { u64 z = x + y; return z >= p ? z - p : z; };
+            auto sub = [&](u64 x, u64 y) { return x >= y ? x - y : x + p - y; };
+            auto mul = [&](u64 x, u64 y) { return (x * y) % p; };
+            for (unsigned pt = 0; pt < 16; pt++) {
+                const u64 x0 = pt & 1, x1 = (pt >> 1) & 1, x2 = (pt >> 2) & 1, x3 = (pt >> 3) & 1;
+                const u64 a0 = add(x0, mul(r[1], x2)), a2 = sub(x0, mul(r[1], x2));
+                const u64 a1 = add(x1, mul(r[1], x3)), a3 = sub(x1, mul(r[1], x3));
+                u64 y[4];
+                y[0] = add(a0, mul(r[2], a1)); y[1] = sub(a0, mul(r[2], a1));
+                y[2] = add(a2, mul(r[3], a3)); y[3] = sub(a2, mul(r[3], a3));
+                for (int j = 0; j < 4; j++) {
+                    lut[4 * pt + j] = (uint32_t)y[j];
+                    lut[64 + 4 * pt + j] = (uint32_t)mul(r[4 + j], y[j]);
+                }
+            }
+            for (unsigned pt = 0; pt < 4; pt++) {
+                const u64 x = pt & 1, y = (pt >> 1) & 1;
+                lut[128 + 2 * pt] = (uint32_t)add(x, mul(r[1], y));
+                lut[128 + 2 * pt + 1] = (uint32_t)sub(x, mul(r[1], y));
+            }
+            fhe::Tw32 *df = nullptr, *di = nullptr;
+            uint32_t *dl = nullptr;
+            hipError_t e = hipMalloc((void **)&df, n * sizeof(fhe::Tw32));
+            if (e == hipSuccess) e = hipMalloc((void **)&di, n * sizeof(fhe::Tw32));
+            if (e == hipSuccess) e = hipMalloc((void **)&dl, lut.size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(df, f.data(), n * sizeof(fhe::Tw32), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(di, v.data(), n * sizeof(fhe::Tw32), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(dl, lut.data(), lut.size() * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (df) (void)hipFree(df);
+                if (di) (void)hipFree(di);
+                if (dl) (void)hipFree(dl);
+                for (int j = 0; j < i; j++) { (void)hipFree(t.fwd[j]); (void)hipFree(t.inv[j]); (void)hipFree(t.lut[j]); }
+                t = Ext32Tables();
+                return fhe_hip_fail(e, "uploading the 30-bit tables");
+            }
+            t.fwd[i] = df; t.inv[i] = di; t.lut[i] = dl;
+            t.ninv[i] = tw32(plan->n_inv, p);
+        }
+    }
+    const u64 pA = primes[0], pB = primes[1];
+    for (int i = 0; i < 2; i++) {
+        a->tw_fwd[i] = t.fwd[i]; a->tw_inv[i] = t.inv[i]; a->lut[i] = t.lut[i];
+        a->p[i] = (uint32_t)primes[i];
+        a->mu[i] = ~0ull / primes[i];                 // floor(2^64 / p): p does not divide 2^64
+        a->ninv[i] = t.ninv[i];
+    }
+    a->crt = tw32(hpow(pA % pB, pB - 2, pB), pB);     // pA^-1 mod pB
+    a->P = pA * pB;
+    a->halfP = (a->P + 1) / 2;
+    return FHE_OK;
+}
+static bool ext32_on(u64 n, unsigned k, unsigned l) {
+    static const bool on = [] { const char *e = getenv("FHE_EXT32"); return !(e && e[0] == '0'); }();
+    return on && fhe::ext32_shape_supported(n, k, l);
+}
+
 // ---- TFHE: TGGSW x TGLWE external product -------------------------------------------------------
 static bool one_prime_form(u64 n, unsigned k, unsigned l) {
     return (u64)(k + 1) * l * n <= (1ull << 26) && n >= 16 && n <= (1ull << fhe::kMaxSinglePassLog);
@@ -785,6 +886,21 @@ extern "C" int fhe_tggsw_prepare_dev(uint64_t n, unsigned k, unsigned l, const v
     hipStream_t st = (hipStream_t)hip_stream;
     const u32 k1 = k + 1;
     const u64 T = (u64)k1 * l, grows = T * k1;
+    if (ext32_on(n, k, l)) {
+        // two 30-bit primes (digit32.hip): halves split into a scratch, transformed per prime into d_prepared as u32
+        // [prime][t][half][c][n] — the same number of bytes as the 61-bit form
+        fhe::Ext32Args a{};
+        if ((rc = ext32_tables(n, &a)) != FHE_OK) return rc;
+        void *scratch = nullptr;
+        if ((rc = fhe_workspace_get(1, 2 * grows * n * 8, st, &scratch)) != FHE_OK) return rc;
+        { fhe::KernelTimer kt_("zr_split32", 0, st);
+        hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, (u64 *)scratch, T, k1, (u32)n);
+        }
+        LAUNCH_OK("zr_split32_kernel");
+        a.key64 = (const u64 *)scratch; a.key32 = (uint32_t *)d_prepared; a.rows = 2 * grows;
+        hipError_t e = fhe::launch_ext32_key(a, (int)z1.dp[0].log_n, st);
+        return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "ntt32_fwd_key_kernel");
+    }
     { fhe::KernelTimer kt_("zr_split32", 0, st);
     hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, (u64 *)d_prepared, T, k1, (u32)n);
     }
@@ -808,6 +924,20 @@ extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, u
     const u64 T = (u64)k1 * l, orows = batch * k1, drows = batch * T;
     const u64 *G2 = (const u64 *)d_prepared;
     void *wsv = nullptr;
+    if (ext32_on(n, k, l)) {
+        fhe::Ext32Args a{};
+        if ((rc = ext32_tables(n, &a)) != FHE_OK) return rc;
+        const u32 parts32 = fhe::digit_mac_parts(batch, (u32)T, z1.dp[0].log_n, 2 * k1);
+        if ((rc = fhe_workspace_get(1, (u64)batch * parts32 * 2 * (2 * k1) * n * 4, st, &wsv)) != FHE_OK) return rc;
+        const u32 W = (u32)(4096 / n);
+        a.key32 = (uint32_t *)const_cast<void *>(d_prepared);
+        a.src = (const u64 *)d_tglwe; a.ct_stride = (u64)k1 * n; a.part32 = (uint32_t *)wsv; a.out = (u64 *)d_out; a.batch = batch;
+        a.l = l; a.T = (u32)T; a.parts = parts32;
+        a.tpp = (((u32)T + parts32 - 1) / parts32 + W - 1) / W * W;
+        hipError_t e = fhe::launch_ext32_mac(a, (int)z1.dp[0].log_n, st);
+        if (e == hipSuccess) e = fhe::launch_ext32_tail(a, (int)z1.dp[0].log_n, st);
+        return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "digit32 kernels");
+    }
     // Fused form: digit extraction, forward transform and multiply-accumulate in one kernel
     // (digit_mac.hip); the digit transforms never reach memory.  R[b][half][c] = sum_t G2[t][half][c] * NTT(digit_t(b)).
     static const bool fused_on = [] { const char *e = getenv("FHE_DIGIT_MAC_FUSED"); return !(e && e[0] == '0'); }();

@@ -1,12 +1,13 @@
-// digit32.hip — the TGGSW x TGLWE external product on TWO 30-bit primes with 32-bit arithmetic.
+// digit32.hip — the TGGSW x TGLWE external product on TWO 27-bit primes with 32-bit arithmetic.
 //
 // Why a second arithmetic: every kernel of the 61-bit engine is bound by the issue rate of 32-bit multiplies (ten per
 // Shoup butterfly; ~15 issue slots per 128-bit multiply-accumulate).  The external product's integers are
-// small — a half-sum  S = sum_t key_half[t] * digit_t  is below (k+1) l n 2^32 <= 2^58 in magnitude — so they are also
-// determined by their residues modulo two primes just below 2^30 (product 2^59.9995).  There a butterfly is 3 multiplies
-// (v_mul_hi_u32 + 2 v_mul_lo_u32, Harvey's lazy [0,4q) in one word) and a multiply-accumulate ONE v_mad_u64_u32 into a
-// 64-bit accumulator that is reduced every 16 terms.  Twice the transforms, a third of the multiplies each; the
-// accumulate phase shrinks from ~60 to ~6 cycles per term.
+// small — a half-sum  S = sum_t key_half[t] * digit_t  is below (k+1) l n 2^32 <= 2^53 in magnitude — so they are also
+// determined by their residues modulo two primes just below 2^32 / 25 (product 2^54.7).  There a butterfly is 3
+// multiplies (v_mul_hi_u32 + 2 v_mul_lo_u32) and, because 25 p fits a word, 3 additions with NO conditional subtraction
+// through all the stages of a transform; a multiply-accumulate is ONE v_mad_u64_u32 into a 64-bit accumulator that needs
+// no reduction for 255 terms.  Twice the transforms, a third of the multiplies each; the accumulate phase shrinks
+// from ~60 to ~6 cycles per term.
 //
 // What is computed is the reference's  TGGSW * TGLWE  (tfhe/src/tggsw.rs:45-62,139-149; Tn::decompose beta = 2,
 // ring_torus.rs:67-77, torus.rs:43-52) with the key words split in 32-bit halves exactly as in zring.hip's one-prime
@@ -24,7 +25,7 @@
 
 namespace fhe {
 
-// ---- Z_p arithmetic in one 32-bit word, p < 2^30 ---------------------------------------------------------------
+// ---- Z_p arithmetic in one 32-bit word, 4p < 2^32 (25p < 2^32 for the loose forms) ---------------------------------------------------------------
 
 __device__ __forceinline__ u32 csub_u32(u32 x, u32 m) { return min(x, x - m); }     // x - m if x >= m (x < 2m), else x
 // y * w mod p, lazily in [0, 2p), for ANY 32-bit y and w < p
@@ -43,8 +44,18 @@ __device__ __forceinline__ void gs32(u32 &x, u32 &y, Tw32 t, u32 p, u32 p2) {
     y = mul_shoup32(d, t, p);
 }
 __device__ __forceinline__ u32 canon4_32(u32 x, u32 p, u32 p2) { return csub_u32(csub_u32(x, p2), p); }
+// The same butterfly with NO conditional subtraction: the bound of the values grows by 2p per stage, and with p below
+// 2^32 / 25 (digit32.hpp) twelve stages from canonical inputs stay in one word: 1 + 2*12 = 25.
+__device__ __forceinline__ void ct32_loose(u32 &x, u32 &y, Tw32 t, u32 p, u32 p2) {
+    const u32 v = mul_shoup32(y, t, p);
+    const u32 u = x;
+    x = u + v;
+    y = u - v + p2;
+}
+// any 32-bit x -> [0, 2p), bq = floor(2^32 / p): the quotient estimate is short by at most one
+__device__ __forceinline__ u32 barrett2p_32(u32 x, u32 p, u32 bq) { return x - __umulhi(x, bq) * p; }
 
-template <int R, int I0 = 0>
+template <int R, int I0 = 0, bool LOOSE = false>
 __device__ __forceinline__ void round_fwd32(u32 (&v)[16], const Tw32 *__restrict__ tw, u32 T0, u32 p, u32 p2) {
 #pragma unroll
     for (int i = I0; i < R; i++) {
@@ -53,7 +64,10 @@ __device__ __forceinline__ void round_fwd32(u32 (&v)[16], const Tw32 *__restrict
         for (int g = 0; g < (1 << i); g++) {
             const Tw32 t = tw[(T0 << i) + g];
 #pragma unroll
-            for (int l = 0; l < span; l++) ct32(v[g * 2 * span + l], v[g * 2 * span + l + span], t, p, p2);
+            for (int l = 0; l < span; l++) {
+                if constexpr (LOOSE) ct32_loose(v[g * 2 * span + l], v[g * 2 * span + l + span], t, p, p2);
+                else ct32(v[g * 2 * span + l], v[g * 2 * span + l + span], t, p, p2);
+            }
         }
     }
 }
@@ -84,7 +98,7 @@ __device__ __forceinline__ void exchange32(u32 (&v)[16], u32 *lds, u32 w, u32 tf
 
 // round 0 on BITS by table look-up (see ntt_rounds.hpp round0_bits; tables per prime, built on the host)
 constexpr int kLut32Words = 136;
-template <int R0>
+template <int R0, bool LOOSE = false>
 __device__ __forceinline__ void round0_bits32(u32 (&v)[16], const u32 *lut, const Tw32 *__restrict__ gtw, u32 p, u32 p2) {
     if constexpr (R0 == 1) {
 #pragma unroll
@@ -115,7 +129,7 @@ __device__ __forceinline__ void round0_bits32(u32 (&v)[16], const u32 *lut, cons
                     v[c + 2 + 4 * j] = csub_u32(av[j] - bv[j] + p, p);
                 }
             }
-            if constexpr (R0 == 4) round_fwd32<4, 3>(v, gtw, 1u, p, p2);
+            if constexpr (R0 == 4) round_fwd32<4, 3, LOOSE>(v, gtw, 1u, p, p2);
         }
     }
 }
@@ -140,6 +154,51 @@ __device__ __forceinline__ void fwd_rounds32(u32 (&v)[16], u32 *lds, const Tw32 
     }
     static_assert(C::NR <= 3, "n <= 4096");
 }
+// The same for BOTH primes in lockstep (va modulo p[0] through tile / table 0, vb modulo p[1] through 1): one pair of
+// barriers per exchange instead of two and twice the independent work between barriers; butterflies WITHOUT conditional
+// subtractions (ct32_loose) — the values end below (1 + 2 LP) p <= 25 p < 2^32.
+template <int LP, int AF, int AT, bool FIRST>
+__device__ __forceinline__ void exchange32x2(u32 (&va)[16], u32 (&vb)[16], u32 *la, u32 *lb, u32 w, u32 tf) {
+    constexpr int M = 1 << LP;
+    if (!FIRST) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 s = pad16(w * M + field_of<AF>(tf, k));
+        la[s] = va[k];
+        lb[s] = vb[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 s = pad16(w * M + field_of<AT>(tf, k));
+        va[k] = la[s];
+        vb[k] = lb[s];
+    }
+}
+template <int LP, bool FRESH>
+__device__ __forceinline__ void fwd_rounds32x2_bits(u32 (&va)[16], u32 (&vb)[16], u32 *const (&tile)[2], const Tw32 *const (&ltw)[2],
+                                                    const Tw32 *const (&gtw)[2], const u32 *const (&lut)[2], u32 w, u32 tf,
+                                                    const u32 (&p)[2]) {
+    using C = ContigCfg<LP>;
+    const u32 pa = p[0], pa2 = 2u * pa, pb = p[1], pb2 = 2u * pb;
+    round0_bits32<C::R0, true>(va, lut[0], gtw[0], pa, pa2);
+    round0_bits32<C::R0, true>(vb, lut[1], gtw[1], pb, pb2);
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        constexpr bool L = C::in_lds(1);
+        exchange32x2<LP, C::A0, A, FRESH>(va, vb, tile[0], tile[1], w, tf);
+        round_fwd32<4, 0, true>(va, L ? ltw[0] : gtw[0], (1u << LS) + (tf >> A), pa, pa2);
+        round_fwd32<4, 0, true>(vb, L ? ltw[1] : gtw[1], (1u << LS) + (tf >> A), pb, pb2);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        constexpr bool L = C::in_lds(2);
+        exchange32x2<LP, C::a_of(1), A, false>(va, vb, tile[0], tile[1], w, tf);
+        round_fwd32<4, 0, true>(va, L ? ltw[0] : gtw[0], (1u << LS) + (tf >> A), pa, pa2);
+        round_fwd32<4, 0, true>(vb, L ? ltw[1] : gtw[1], (1u << LS) + (tf >> A), pb, pb2);
+    }
+}
+
 // the LP inverse stages: window [0,4) (canonical inputs) -> window [LP-4, LP), values below 2p, NOT yet scaled by n^-1
 template <int LP, bool FRESH>
 __device__ __forceinline__ void inv_rounds32(u32 (&v)[16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 w, u32 tf, u32 p, u32 p2) {
@@ -192,10 +251,8 @@ __global__ __launch_bounds__(256) void ntt32_fwd_key_kernel(Ext32Args a) {
     u32 v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        u64 x = src[field_of<C::A0>(tf, k)];          // a 32-bit half: < 2^32 < 4p
-        u32 r = (u32)x;
-        r = csub_u32(r, p2);
-        v[k] = csub_u32(r, p);
+        const u64 x = src[field_of<C::A0>(tf, k)];          // a 32-bit half
+        v[k] = csub_u32(barrett2p_32((u32)x, p, a.bq[prime]), p);
     }
     fwd_rounds32<LP, false, true>(v, lds, ltw, gtw, nullptr, w, tf, p, p2);
     if (live) {
@@ -221,16 +278,19 @@ __device__ __forceinline__ u32 reduce64_32(u64 x, u32 p, u64 mu) {
 // key32 layout: [prime][t][c][n], t = row*l + digit, c < NC (NC = 2(k+1): half-major, then component).
 // out: partial sums [b][part][prime][c][n] u32 canonical.
 template <int LP, int NC>
-__global__ __launch_bounds__(256) void digit_mac32_kernel(Ext32Args a) {
+__global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
     using C = ContigCfg<LP>;
     using K = Cfg32<LP>;
     constexpr int PPT = K::PPT, W = K::W;
     static_assert(2 * NC * PPT <= 32, "accumulators");
+    static_assert(1 + 2 * LP <= 25, "ct32_loose: the bound of the values after LP stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32 *tile[2] = {reinterpret_cast<u32 *>(smem_raw), reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES)};
-    Tw32 *ltw[2] = {reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES), reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES + K::TW_BYTES)};
-    u32 *llut[2] = {reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES),
-                    reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES) + kLut32Words};
+    u32 *const tile[2] = {reinterpret_cast<u32 *>(smem_raw), reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES)};
+    Tw32 *const ltw_w[2] = {reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES), reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES + K::TW_BYTES)};
+    const Tw32 *const ltw[2] = {ltw_w[0], ltw_w[1]};
+    u32 *const llut_w[2] = {reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES),
+                            reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES) + kLut32Words};
+    const u32 *const llut[2] = {llut_w[0], llut_w[1]};
     const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
     const u64 b = blockIdx.x / a.parts;
     const u32 part = blockIdx.x % a.parts;
@@ -238,8 +298,8 @@ __global__ __launch_bounds__(256) void digit_mac32_kernel(Ext32Args a) {
     const u32 n = 1u << LP;
 #pragma unroll
     for (int pr = 0; pr < 2; pr++) {
-        stage_tw32(ltw[pr], a.tw_fwd[pr], C::LTW_N, tid);
-        for (u32 i = tid; i < (u32)kLut32Words; i += 256) llut[pr][i] = a.lut[pr][i];
+        stage_tw32(ltw_w[pr], a.tw_fwd[pr], C::LTW_N, tid);
+        for (u32 i = tid; i < (u32)kLut32Words; i += 256) llut_w[pr][i] = a.lut[pr][i];
     }
     __syncthreads();
     const u64 *__restrict__ ct = a.src + b * a.ct_stride;
@@ -258,20 +318,17 @@ __global__ __launch_bounds__(256) void digit_mac32_kernel(Ext32Args a) {
         const u32 tt = t < t_end ? t : t_begin;               // idle units redo a valid digit, never multiplied
         const u32 r = tt / a.l, d = tt - r * a.l;
         const u64 *__restrict__ row = ct + (u64)r * n;
-        u32 bits[16];
+        u32 va[16], vb[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) bits[k] = (u32)((row[field_of<C::A0>(tf, k)] >> (a.l - 1u - d)) & 1ull);
+        for (int k = 0; k < 16; k++) va[k] = vb[k] = (u32)((row[field_of<C::A0>(tf, k)] >> (a.l - 1u - d)) & 1ull);
+        // the tiles were read by the previous step's multiply phase: barrier first (FRESH = false)
+        fwd_rounds32x2_bits<LP, false>(va, vb, tile, ltw, a.tw_fwd, llut, w, tf, a.p);
+        // every thread rewrites exactly the slots it gathered in the last exchange
 #pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-            const u32 p = a.p[pr], p2 = 2u * p;
-            u32 v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = bits[k];
-            // the tile of this prime was read by the previous step's multiply phase: barrier first (FRESH = false)
-            fwd_rounds32<LP, true, false>(v, tile[pr], ltw[pr], a.tw_fwd[pr], llut[pr], w, tf, p, p2);
-            // every thread rewrites exactly the slots it gathered in the last exchange
-#pragma unroll
-            for (int k = 0; k < 16; k++) tile[pr][pad16(w * C::M + field_of<0>(tf, k))] = canon4_32(v[k], p, p2);
+        for (int k = 0; k < 16; k++) {
+            const u32 sl = pad16(w * C::M + field_of<0>(tf, k));
+            tile[0][sl] = barrett2p_32(va[k], a.p[0], a.bq[0]);          // below 2p: a product is below 2 p^2 < 2^55.8
+            tile[1][sl] = barrett2p_32(vb[k], a.p[1], a.bq[1]);
         }
         __syncthreads();
         const u32 nu = min((u32)W, t_end - t0);
@@ -297,13 +354,13 @@ __global__ __launch_bounds__(256) void digit_mac32_kernel(Ext32Args a) {
                             gv[0] = g[(u64)c * n];
                         }
 #pragma unroll
-                        for (int i = 0; i < PPT; i++) acc[pr][c][i] += (u64)gv[i] * x[i];       // < 2^60 per term
+                        for (int i = 0; i < PPT; i++) acc[pr][c][i] += (u64)gv[i] * x[i];       // < 2^55.8 per term
                     }
                 }
             }
         }
         pending += nu;
-        if (pending + W > 15u) {                                  // 16 terms of 2^60 would reach 2^64: reduce first
+        if (pending + W > 255u) {                                 // 2^8.2 terms of 2 p^2 reach 2^64: reduce first (T > 255 only)
 #pragma unroll
             for (int pr = 0; pr < 2; pr++)
 #pragma unroll
@@ -443,7 +500,7 @@ static hipError_t launch_tail32_lp(const Ext32Args &a, hipStream_t st) {
 bool ext32_shape_supported(u64 n, unsigned k, unsigned l) {
     if (k != 1 || l < 1 || l > 64) return false;
     if (n != 256 && n != 512 && n != 1024) return false;
-    return (u64)(k + 1) * l * n <= (1ull << 26);
+    return (u64)(k + 1) * l * n <= (1ull << 21);          // |half-sum| < T n 2^32 <= 2^53 < P / 2
 }
 
 hipError_t launch_ext32_key(const Ext32Args &a, int log_n, hipStream_t st) {

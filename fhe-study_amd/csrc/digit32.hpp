@@ -1,4 +1,4 @@
-// digit32.hpp — internal interface of the 30-bit-prime external product (digit32.hip).  Not part of the public boundary.
+// digit32.hpp — internal interface of the 27-bit-prime external product (digit32.hip).  Not part of the public boundary.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,8 +9,10 @@ namespace fhe {
 
 struct Tw32 { uint32_t w, wp; };                     // twiddle and floor(w * 2^32 / p)
 
-// the two primes: largest below 2^30 with p = 1 mod 2^15; product 2^59.9995 > 2 * 2^58
-constexpr uint32_t kExt32PrimeA = 0x3ffe8001u, kExt32PrimeB = 0x3ffc0001u;
+// the two primes: the largest below 2^32 / 25 with p = 1 mod 2^15 (27.36 and 27.35 bits; product 2^54.7).  Below
+// 2^32 / 25 so that up to twelve lazy butterfly stages need no conditional subtraction (digit32.hip: ct32_loose).
+constexpr uint32_t kExt32PrimeA = 0x0a3c8001u, kExt32PrimeB = 0x0a320001u;
+static_assert((uint64_t)kExt32PrimeA * 25 < (1ull << 32) && kExt32PrimeA > kExt32PrimeB && kExt32PrimeA - kExt32PrimeB < kExt32PrimeB, "prime bounds");
 
 struct Ext32Args {
     // key preparation
@@ -29,6 +31,7 @@ struct Ext32Args {
     const uint32_t *lut[2];
     uint32_t p[2];
     u64 mu[2];                 // floor(2^64 / p)
+    uint32_t bq[2];            // floor(2^32 / p)
     Tw32 ninv[2];              // n^-1 mod p
     Tw32 crt;                  // pA^-1 mod pB
     u64 P, halfP;              // pA * pB, ceil(P / 2)

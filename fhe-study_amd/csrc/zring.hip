@@ -761,7 +761,7 @@ extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void
     return z_crt(z, true, R, R + words, R + 2 * words, (u64 *)d_out, words, st);
 }
 
-// ---- the 30-bit-prime form of the external product (digit32.hip): per (n, device) tables ---------------------------
+// ---- the two-small-prime (27-bit) form of the external product (digit32.hip): per (n, device) tables ---------------------------
 namespace {
 struct Ext32Tables {
     fhe::Tw32 *fwd[2] = {nullptr, nullptr}, *inv[2] = {nullptr, nullptr};
@@ -837,7 +837,7 @@ static int ext32_tables(u64 n, fhe::Ext32Args *a) {
                 if (dl) (void)hipFree(dl);
                 for (int j = 0; j < i; j++) { (void)hipFree(t.fwd[j]); (void)hipFree(t.inv[j]); (void)hipFree(t.lut[j]); }
                 t = Ext32Tables();
-                return fhe_hip_fail(e, "uploading the 30-bit tables");
+                return fhe_hip_fail(e, "uploading the 27-bit tables");
             }
             t.fwd[i] = df; t.inv[i] = di; t.lut[i] = dl;
             t.ninv[i] = tw32(plan->n_inv, p);
@@ -848,6 +848,7 @@ static int ext32_tables(u64 n, fhe::Ext32Args *a) {
         a->tw_fwd[i] = t.fwd[i]; a->tw_inv[i] = t.inv[i]; a->lut[i] = t.lut[i];
         a->p[i] = (uint32_t)primes[i];
         a->mu[i] = ~0ull / primes[i];                 // floor(2^64 / p): p does not divide 2^64
+        a->bq[i] = (uint32_t)(0xffffffffull / primes[i]);
         a->ninv[i] = t.ninv[i];
     }
     a->crt = tw32(hpow(pA % pB, pB - 2, pB), pB);     // pA^-1 mod pB
@@ -887,7 +888,7 @@ extern "C" int fhe_tggsw_prepare_dev(uint64_t n, unsigned k, unsigned l, const v
     const u32 k1 = k + 1;
     const u64 T = (u64)k1 * l, grows = T * k1;
     if (ext32_on(n, k, l)) {
-        // two 30-bit primes (digit32.hip): halves split into a scratch, transformed per prime into d_prepared as u32
+        // two 27-bit primes (digit32.hip): halves split into a scratch, transformed per prime into d_prepared as u32
         // [prime][t][half][c][n] — the same number of bytes as the 61-bit form
         fhe::Ext32Args a{};
         if ((rc = ext32_tables(n, &a)) != FHE_OK) return rc;

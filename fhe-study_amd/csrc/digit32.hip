@@ -46,11 +46,12 @@ __device__ __forceinline__ void gs32(u32 &x, u32 &y, Tw32 t, u32 p, u32 p2) {
 __device__ __forceinline__ u32 canon4_32(u32 x, u32 p, u32 p2) { return csub_u32(csub_u32(x, p2), p); }
 // The same butterfly with NO conditional subtraction: the bound of the values grows by 2p per stage, and with p below
 // 2^32 / 25 (digit32.hpp) twelve stages from canonical inputs stay in one word: 1 + 2*12 = 25.
+// Six instructions: the NEGATED lazy product nv = q p - y w (one subtraction), x - nv, and x + nv + 2p as one v_add3_u32.
 __device__ __forceinline__ void ct32_loose(u32 &x, u32 &y, Tw32 t, u32 p, u32 p2) {
-    const u32 v = mul_shoup32(y, t, p);
+    const u32 nv = __umulhi(y, t.wp) * p - y * t.w;
     const u32 u = x;
-    x = u + v;
-    y = u - v + p2;
+    x = u - nv;
+    y = u + nv + p2;
 }
 // any 32-bit x -> [0, 2p), bq = floor(2^32 / p): the quotient estimate is short by at most one
 __device__ __forceinline__ u32 barrett2p_32(u32 x, u32 p, u32 bq) { return x - __umulhi(x, bq) * p; }

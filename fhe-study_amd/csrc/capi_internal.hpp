@@ -43,7 +43,10 @@ fhe::u64 fhe_batch_tile_for(const fhe_ntt_plan *plan);
 // grow-only scratch per (slot, device, stream); slot 0 = fhe_rq_mul_dev / bfv tensor, slot 1 = zring, glue
 int fhe_workspace_get(int slot, size_t bytes, hipStream_t st, void **out);
 void fhe_workspace_free_all();
-void fhe_ext32_free_all();   // zring.hip: tables of the 30-bit-prime external product
+void fhe_ext32_free_all();   // zring.hip: tables of the two-small-prime (27-bit) products (digit32.hip)
+namespace fhe { struct Ext32Args; }
+int fhe_ext32_tables(uint64_t n, fhe::Ext32Args *a);   // fills the per-prime fields for the current device
+bool fhe_ext32_enabled();                              // FHE_EXT32=0 keeps every product on the 61-bit kernels
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
 int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);
 void fhe_stage_release(void *ptr, size_t bytes, int dev);

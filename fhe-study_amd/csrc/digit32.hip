@@ -136,22 +136,22 @@ __device__ __forceinline__ void round0_bits32(u32 (&v)[16], const u32 *lut, cons
 }
 
 // the LP forward stages: window [LP-4, LP) -> window [0,4); BITS: round 0 by look-up; values end below 4p
-template <int LP, bool BITS, bool FRESH>
+template <int LP, bool BITS, bool FRESH, bool LOOSE = false>
 __device__ __forceinline__ void fwd_rounds32(u32 (&v)[16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, const u32 *lut, u32 w, u32 tf,
                                              u32 p, u32 p2) {
     using C = ContigCfg<LP>;
     auto TW = [&](bool in_lds) -> const Tw32 * { return in_lds ? ltw : gtw; };
-    if constexpr (BITS) round0_bits32<C::R0>(v, lut, gtw, p, p2);
-    else round_fwd32<C::R0>(v, gtw, 1u, p, p2);
+    if constexpr (BITS) round0_bits32<C::R0, LOOSE>(v, lut, gtw, p, p2);
+    else round_fwd32<C::R0, 0, LOOSE>(v, gtw, 1u, p, p2);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         exchange32<LP, C::A0, A, FRESH>(v, lds, w, tf);
-        round_fwd32<4>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), p, p2);
+        round_fwd32<4, 0, LOOSE>(v, TW(C::in_lds(1)), (1u << LS) + (tf >> A), p, p2);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         exchange32<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd32<4>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), p, p2);
+        round_fwd32<4, 0, LOOSE>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), p, p2);
     }
     static_assert(C::NR <= 3, "n <= 4096");
 }
@@ -218,29 +218,34 @@ __device__ __forceinline__ void inv_rounds32(u32 (&v)[16], u32 *lds, const Tw32 
     round_inv32<C::R0>(v, TW(C::in_lds(0)), 1u, p, p2);
 }
 
+// Shapes: ContigCfg's — 256 threads, W = 4096 / n units side by side (one for n = 4096).  The fused digit kernel
+// multiplies at PPT = n / 256 positions per thread into NP * NC * PPT 64-bit accumulators, NP = the primes a workgroup
+// runs: both in lockstep while that is at most 32 accumulators (n <= 1024 with NC = 4), otherwise ONE prime per
+// workgroup (blockIdx.y) — twice the workgroups, each extracting the digits again, 64 accumulators at n = 4096.
 template <int LP>
 struct Cfg32 {
     using C = ContigCfg<LP>;
-    static constexpr int M = C::M, W = C::W, TH = 256, PPT = M / TH;
+    static constexpr int M = C::M, TPB = C::TPB, W = C::W, TH = 256, PPT = M / TH;
     static constexpr size_t TILE_BYTES = (size_t)(W * M + W * M / 16) * 4;          // one padded tile of u32
     static constexpr size_t TW_BYTES = (size_t)C::LTW_N * sizeof(Tw32);
-    // two tiles (one per prime), two twiddle tiles, two look-up tables
-    static constexpr size_t LDS_BYTES = 2 * TILE_BYTES + 2 * TW_BYTES + 2 * (size_t)kLut32Words * 4;
-    static_assert(LP >= 8 && LP <= 10, "n = 256 .. 1024");
+    static constexpr size_t LUT_BYTES = (size_t)kLut32Words * 4;
+    // per prime a workgroup runs: a tile, a twiddle tile, a look-up table
+    static constexpr size_t lds_bytes(int np) { return (size_t)np * (TILE_BYTES + TW_BYTES + LUT_BYTES); }
+    static_assert(LP >= 8 && LP <= 12, "n = 256 .. 4096");
 };
 
 __device__ __forceinline__ void stage_tw32(Tw32 *ltw, const Tw32 *__restrict__ tw, int count, u32 tid) {
     for (u32 i = tid; i < (u32)count; i += 256) ltw[i] = tw[i];   // s0 = blk = 0: the local table is the head of the global one
 }
 
-// ---- key preparation: [rows][n] u64 words < 2^32  ->  [prime][rows][n] u32, NTT domain -------------------------
+// ---- key preparation: [T][k1][n] u64 words  ->  [prime][T][half][k1][n] u32, NTT domain (rows = T * 2 * k1) -------------------------
 template <int LP>
 __global__ __launch_bounds__(256) void ntt32_fwd_key_kernel(Ext32Args a) {
     using C = ContigCfg<LP>;
     using K = Cfg32<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32 *lds = reinterpret_cast<u32 *>(smem_raw);
-    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + K::TILE_BYTES);
     const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
     const u32 prime = blockIdx.y;
     const u32 p = a.p[prime], p2 = 2u * p;
@@ -248,12 +253,15 @@ __global__ __launch_bounds__(256) void ntt32_fwd_key_kernel(Ext32Args a) {
     stage_tw32(ltw, gtw, C::LTW_N, tid);
     const u64 row = (u64)blockIdx.x * C::W + w;
     const bool live = row < a.rows;
-    const u64 *__restrict__ src = a.key64 + (live ? row : 0) * C::M;
+    // output row (t, half, c) is the 32-bit half `half` of source row (t, c) of the key as the reference holds it
+    const u64 orow = live ? row : 0, t = orow / (2 * a.key_k1), rem = orow - t * (2 * a.key_k1);
+    const u32 half = (u32)(rem / a.key_k1), c = (u32)(rem - (u64)half * a.key_k1);
+    const u64 *__restrict__ src = a.key64 + (t * a.key_k1 + c) * C::M;
     u32 v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u64 x = src[field_of<C::A0>(tf, k)];          // a 32-bit half
-        v[k] = csub_u32(barrett2p_32((u32)x, p, a.bq[prime]), p);
+        const u64 x = src[field_of<C::A0>(tf, k)];
+        v[k] = csub_u32(barrett2p_32((u32)(x >> (32u * half)), p, a.bq[prime]), p);
     }
     fwd_rounds32<LP, false, true>(v, lds, ltw, gtw, nullptr, w, tf, p, p2);
     if (live) {
@@ -276,38 +284,56 @@ __device__ __forceinline__ u32 reduce64_32(u64 x, u32 p, u64 mu) {
 }
 
 // ---- digits -> transforms modulo both primes -> multiply-accumulate ----------------------------------------------
-// key32 layout: [prime][t][c][n], t = row*l + digit, c < NC (NC = 2(k+1): half-major, then component).
+// digit d (0 = most significant) of a source word: SRC_DIGITS  Tn::decompose beta = 2 (torus.rs:43-52);
+// SRC_ZQBITS  Zq::decompose_base2 (zq.rs:176-190): every digit is 1 when the value is >= 2^l, with the reference's
+// `1 << l` taken modulo 64 as a --release build does (the same rule as digit_mac.hip digit_of).
+template <int SRC>
+__device__ __forceinline__ u32 digit32_of(u64 x, u32 l, u32 d) {
+    const u32 bit = (u32)(x >> (l - 1u - d)) & 1u;
+    if (SRC == SRC_DIGITS) return bit;
+    return x >= (1ull << (l & 63u)) ? 1u : bit;
+}
+
+// key32 layout: [prime][t][c][n], t = row*l + digit, c < NC (NC = 2 * output rows: half-major, then component).
 // out: partial sums [b][part][prime][c][n] u32 canonical.
-template <int LP, int NC>
+// NP = 2: both primes in this workgroup, their transforms in lockstep (32 live coefficients); NP = 1: prime blockIdx.y.
+template <int LP, int NC, int SRC, int NP>
 __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
     using C = ContigCfg<LP>;
     using K = Cfg32<LP>;
     constexpr int PPT = K::PPT, W = K::W;
-    static_assert(2 * NC * PPT <= 32, "accumulators");
+    static_assert(NP * NC * PPT <= 64, "accumulators");
     static_assert(1 + 2 * LP <= 25, "ct32_loose: the bound of the values after LP stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32 *const tile[2] = {reinterpret_cast<u32 *>(smem_raw), reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES)};
-    Tw32 *const ltw_w[2] = {reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES), reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES + K::TW_BYTES)};
-    const Tw32 *const ltw[2] = {ltw_w[0], ltw_w[1]};
-    u32 *const llut_w[2] = {reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES),
-                            reinterpret_cast<u32 *>(smem_raw + 2 * K::TILE_BYTES + 2 * K::TW_BYTES) + kLut32Words};
-    const u32 *const llut[2] = {llut_w[0], llut_w[1]};
+    const u32 pr0 = NP == 2 ? 0u : blockIdx.y;
+    u32 *tile[NP];
+    Tw32 *ltw_w[NP];
+    u32 *llut_w[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        tile[i] = reinterpret_cast<u32 *>(smem_raw + i * K::TILE_BYTES);
+        ltw_w[i] = reinterpret_cast<Tw32 *>(smem_raw + NP * K::TILE_BYTES + i * K::TW_BYTES);
+        llut_w[i] = reinterpret_cast<u32 *>(smem_raw + NP * (K::TILE_BYTES + K::TW_BYTES) + i * K::LUT_BYTES);
+    }
     const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
     const u64 b = blockIdx.x / a.parts;
     const u32 part = blockIdx.x % a.parts;
     const u32 t_begin = part * a.tpp, t_end = min(a.T, t_begin + a.tpp);
     const u32 n = 1u << LP;
+    u32 p[NP], bq[NP];
+    const Tw32 *gtw[NP];
 #pragma unroll
-    for (int pr = 0; pr < 2; pr++) {
-        stage_tw32(ltw_w[pr], a.tw_fwd[pr], C::LTW_N, tid);
-        for (u32 i = tid; i < (u32)kLut32Words; i += 256) llut_w[pr][i] = a.lut[pr][i];
+    for (int i = 0; i < NP; i++) {
+        p[i] = a.p[pr0 + i]; bq[i] = a.bq[pr0 + i]; gtw[i] = a.tw_fwd[pr0 + i];
+        stage_tw32(ltw_w[i], gtw[i], C::LTW_N, tid);
+        for (u32 e = tid; e < (u32)kLut32Words; e += 256) llut_w[i][e] = a.lut[pr0 + i][e];
     }
     __syncthreads();
     const u64 *__restrict__ ct = a.src + b * a.ct_stride;
 
-    u64 acc[2][NC][PPT];
+    u64 acc[NP][NC][PPT];
 #pragma unroll
-    for (int pr = 0; pr < 2; pr++)
+    for (int pr = 0; pr < NP; pr++)
 #pragma unroll
         for (int c = 0; c < NC; c++)
 #pragma unroll
@@ -319,35 +345,61 @@ __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
         const u32 tt = t < t_end ? t : t_begin;               // idle units redo a valid digit, never multiplied
         const u32 r = tt / a.l, d = tt - r * a.l;
         const u64 *__restrict__ row = ct + (u64)r * n;
-        u32 va[16], vb[16];
+        // the tiles were read by the previous step's multiply phase: barrier first (FRESH = false); every thread then
+        // rewrites exactly the slots it gathered in the last exchange, reduced below 2p (a product is below 2 p^2 < 2^55.8)
+        if constexpr (NP == 2) {
+            u32 va[16], vb[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) va[k] = vb[k] = (u32)((row[field_of<C::A0>(tf, k)] >> (a.l - 1u - d)) & 1ull);
-        // the tiles were read by the previous step's multiply phase: barrier first (FRESH = false)
-        fwd_rounds32x2_bits<LP, false>(va, vb, tile, ltw, a.tw_fwd, llut, w, tf, a.p);
-        // every thread rewrites exactly the slots it gathered in the last exchange
+            for (int k = 0; k < 16; k++) va[k] = vb[k] = digit32_of<SRC>(row[field_of<C::A0>(tf, k)], a.l, d);
+            const Tw32 *const lt[2] = {ltw_w[0], ltw_w[1]};
+            const u32 *const ll[2] = {llut_w[0], llut_w[1]};
+            u32 *const tl[2] = {tile[0], tile[1]};
+#ifndef FHE_D32_ABLATE_NTT      // timing-only builds (tools/abl_build.sh): the kernel without its transforms / its multiply phase
+            fwd_rounds32x2_bits<LP, false>(va, vb, tl, lt, a.tw_fwd, ll, w, tf, a.p);
+#else
+            __syncthreads();
+#endif
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u32 sl = pad16(w * C::M + field_of<0>(tf, k));
-            tile[0][sl] = barrett2p_32(va[k], a.p[0], a.bq[0]);          // below 2p: a product is below 2 p^2 < 2^55.8
-            tile[1][sl] = barrett2p_32(vb[k], a.p[1], a.bq[1]);
+            for (int k = 0; k < 16; k++) {
+                const u32 sl = pad16(w * C::M + field_of<0>(tf, k));
+                tile[0][sl] = barrett2p_32(va[k], p[0], bq[0]);
+                tile[NP - 1][sl] = barrett2p_32(vb[k], p[NP - 1], bq[NP - 1]);
+            }
+        } else {
+            u32 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = digit32_of<SRC>(row[field_of<C::A0>(tf, k)], a.l, d);
+#ifndef FHE_D32_ABLATE_NTT
+            fwd_rounds32<LP, true, false, true>(v, tile[0], ltw_w[0], gtw[0], llut_w[0], w, tf, p[0], 2u * p[0]);
+#else
+            __syncthreads();
+#endif
+#pragma unroll
+            for (int k = 0; k < 16; k++) tile[0][pad16(w * C::M + field_of<0>(tf, k))] = barrett2p_32(v[k], p[0], bq[0]);
         }
         __syncthreads();
         const u32 nu = min((u32)W, t_end - t0);
+#ifdef FHE_D32_ABLATE_MAC
+        if (a.T == 0xffffffffu)
+#endif
 #pragma unroll
         for (int u = 0; u < W; u++) {
             if ((u32)u < nu) {
 #pragma unroll
-                for (int pr = 0; pr < 2; pr++) {
+                for (int pr = 0; pr < NP; pr++) {
                     u32 x[PPT];
 #pragma unroll
                     for (int i = 0; i < PPT; i++) x[i] = tile[pr][pad16(u * C::M + j0 + i)];
-                    const u32 *__restrict__ g = a.key32 + (((u64)pr * a.T + (t0 + u)) * NC) * n + j0;
+                    const u32 *__restrict__ g = a.key32 + (((u64)(pr0 + pr) * a.T + (t0 + u)) * NC) * n + j0;
 #pragma unroll
                     for (int c = 0; c < NC; c++) {
                         u32 gv[PPT];
-                        if constexpr (PPT == 4) {
-                            const uint4 q4 = *reinterpret_cast<const uint4 *>(g + (u64)c * n);
-                            gv[0] = q4.x; gv[1] = q4.y; gv[2] = q4.z; gv[3] = q4.w;
+                        if constexpr (PPT >= 4) {
+#pragma unroll
+                            for (int i = 0; i < PPT; i += 4) {
+                                const uint4 q4 = *reinterpret_cast<const uint4 *>(g + (u64)c * n + i);
+                                gv[i] = q4.x; gv[i + 1] = q4.y; gv[i + 2] = q4.z; gv[i + 3] = q4.w;
+                            }
                         } else if constexpr (PPT == 2) {
                             const uint2 q2 = *reinterpret_cast<const uint2 *>(g + (u64)c * n);
                             gv[0] = q2.x; gv[1] = q2.y;
@@ -363,21 +415,21 @@ __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
         pending += nu;
         if (pending + W > 255u) {                                 // 2^8.2 terms of 2 p^2 reach 2^64: reduce first (T > 255 only)
 #pragma unroll
-            for (int pr = 0; pr < 2; pr++)
+            for (int pr = 0; pr < NP; pr++)
 #pragma unroll
                 for (int c = 0; c < NC; c++)
 #pragma unroll
-                    for (int i = 0; i < PPT; i++) acc[pr][c][i] = reduce64_32(acc[pr][c][i], a.p[pr], a.mu[pr]);
+                    for (int i = 0; i < PPT; i++) acc[pr][c][i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr0 + pr]);
             pending = 1;
         }
     }
 #pragma unroll
-    for (int pr = 0; pr < 2; pr++) {
-        u32 *__restrict__ o = a.part32 + ((((b * a.parts + part) * 2 + pr) * NC) * (u64)n) + j0;
+    for (int pr = 0; pr < NP; pr++) {
+        u32 *__restrict__ o = a.part32 + ((((b * a.parts + part) * 2 + pr0 + pr) * NC) * (u64)n) + j0;
 #pragma unroll
         for (int c = 0; c < NC; c++)
 #pragma unroll
-            for (int i = 0; i < PPT; i++) o[(u64)c * n + i] = reduce64_32(acc[pr][c][i], a.p[pr], a.mu[pr]);
+            for (int i = 0; i < PPT; i++) o[(u64)c * n + i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr0 + pr]);
     }
 }
 
@@ -459,74 +511,178 @@ __global__ __launch_bounds__(256) void digit_tail32_kernel(Ext32Args a) {
     }
 }
 
+// ---- key switching tail: sum of parts -> inverse transforms -> CRT lift -> mod q -> (0, b) - rhs ---------------------------
+// Unit w = output row (ciphertext b, component c < k+1).  Its two half-sums (key words split at bit 32) are each two
+// inverse transforms; a thread ends every one of them on the SAME 16 positions, so the lifts meet in registers:
+//   rhs = (lift(S_lo) + lift(S_hi) * 2^32) mod q,   out[b][c] = (c < k ? 0 : glwe[b][c]) - rhs   (glwe.rs:129-136)
+template <int LP>
+__global__ __launch_bounds__(256) void digit_tail32_ks_kernel(Ext32Args a) {
+    using C = ContigCfg<LP>;
+    using K = Cfg32<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *tile = reinterpret_cast<u32 *>(smem_raw);
+    Tw32 *ltw[2] = {reinterpret_cast<Tw32 *>(smem_raw + K::TILE_BYTES), reinterpret_cast<Tw32 *>(smem_raw + K::TILE_BYTES + K::TW_BYTES)};
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const u32 n = 1u << LP;
+    const u32 k1 = a.k + 1u, NC = 2u * k1;
+    const u64 rows = a.batch * k1;
+    const u64 R0 = (u64)blockIdx.x * C::W;
+    const u32 live = (u32)min((u64)C::W, rows - R0);
+    const bool active = w < live;
+    const u64 R = R0 + (active ? w : 0u);                       // idle units redo the first row and store nothing
+    const u64 b = R / k1;
+    const u32 c = (u32)(R - b * k1);
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) stage_tw32(ltw[pr], a.tw_inv[pr], C::LTW_N, tid);
+    __syncthreads();
+    const u32 pA = a.p[0], pB = a.p[1];
+    u64 S[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        u32 res[2][16];
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            const u32 p = a.p[pr], p2 = 2u * p;
+            u32 v[16];
+            const u32 *__restrict__ src = a.part32 + (((b * a.parts) * 2 + pr) * NC + h * k1 + c) * (u64)n + tf * 16u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(src + 4 * j);
+                v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+            }
+            for (u32 q = 1; q < a.parts; q++) {
+                const u32 *__restrict__ sp = src + (u64)q * 2 * NC * n;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(sp + 4 * j);
+                    v[4 * j] = csub_u32(v[4 * j] + x.x, p); v[4 * j + 1] = csub_u32(v[4 * j + 1] + x.y, p);
+                    v[4 * j + 2] = csub_u32(v[4 * j + 2] + x.z, p); v[4 * j + 3] = csub_u32(v[4 * j + 3] + x.w, p);
+                }
+            }
+            // one tile for the four transforms: all but the first find it read by the one before (FRESH = false)
+            if (h == 0 && pr == 0) inv_rounds32<LP, true>(v, tile, ltw[pr], a.tw_inv[pr], w, tf, p, p2);
+            else inv_rounds32<LP, false>(v, tile, ltw[pr], a.tw_inv[pr], w, tf, p, p2);
+            const Tw32 ni = a.ninv[pr];
+#pragma unroll
+            for (int k = 0; k < 16; k++) res[pr][k] = csub_u32(mul_shoup32(v[k], ni, p), p);      // * n^-1, canonical
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 rA = res[0][k], rB = res[1][k];
+            const u32 rAb = csub_u32(rA, pB);
+            const u32 diff = csub_u32(rB - rAb + pB, pB);
+            const u32 hh = csub_u32(mul_shoup32(diff, a.crt, pB), pB);
+            S[h][k] = (u64)rA + (u64)pA * hh;                       // in [0, pA * pB); centred below
+        }
+    }
+    if (!active) return;
+    const Mod &m = a.mod;
+    const u64 base = (b * k1 + c) * (u64)n;
+    const bool body = c >= a.k;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 pos = field_of<C::A0>(tf, k);
+        u64 r[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool neg = S[h][k] >= a.halfP;                  // the centred value is S - P
+            const u64 mag = reduce_any(neg ? a.P - S[h][k] : S[h][k], m);
+            r[h] = (neg && mag) ? m.q - mag : mag;
+        }
+        u64 y = r[0] + mul_mod_var(r[1], a.two32, m);             // < 2q
+        y = canon2(y, m);
+        const u64 x = body ? a.glwe[base + pos] : 0ull;
+        a.out[base + pos] = x >= y ? x - y : x + m.q - y;
+    }
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------------
 template <int LP>
 static hipError_t launch_key32_lp(const Ext32Args &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     using K = Cfg32<LP>;
+    constexpr size_t lds = K::TILE_BYTES + K::TW_BYTES;
     const u64 grid = (a.rows + C::W - 1) / C::W;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)ntt32_fwd_key_kernel<LP>, K::LDS_BYTES)) return e;
+    if (hipError_t e = allow_big_lds((const void *)ntt32_fwd_key_kernel<LP>, lds)) return e;
     KernelTimer kt("ntt32_fwd_key", LP, st);
-    hipLaunchKernelGGL((ntt32_fwd_key_kernel<LP>), dim3((unsigned)grid, 2), dim3(256), K::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((ntt32_fwd_key_kernel<LP>), dim3((unsigned)grid, 2), dim3(256), lds, st, a);
     return hipGetLastError();
 }
-template <int LP>
+template <int LP, int SRC>
 static hipError_t launch_mac32_lp(const Ext32Args &a, hipStream_t st) {
     using K = Cfg32<LP>;
-    if constexpr (2 * 4 * K::PPT > 32) {
-        return hipErrorNotSupported;
-    } else {
-        const u64 grid = a.batch * a.parts;
-        if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-        if (hipError_t e = allow_big_lds((const void *)digit_mac32_kernel<LP, 4>, K::LDS_BYTES)) return e;
-        KernelTimer kt("digit_mac32", LP, st);
-        hipLaunchKernelGGL((digit_mac32_kernel<LP, 4>), dim3((unsigned)grid), dim3(256), K::LDS_BYTES, st, a);
-        return hipGetLastError();
-    }
+    constexpr int NP = 2 * 4 * K::PPT <= 32 ? 2 : 1;     // 32 accumulators leave room for both primes' coefficients
+    constexpr size_t lds = K::lds_bytes(NP);
+    const u64 grid = a.batch * a.parts;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)digit_mac32_kernel<LP, 4, SRC, NP>, lds)) return e;
+    KernelTimer kt("digit_mac32", LP, st);
+    hipLaunchKernelGGL((digit_mac32_kernel<LP, 4, SRC, NP>), dim3((unsigned)grid, 2 / NP), dim3(256), lds, st, a);
+    return hipGetLastError();
 }
 template <int LP>
 static hipError_t launch_tail32_lp(const Ext32Args &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     using K = Cfg32<LP>;
-    constexpr size_t lds = (size_t)(C::W * C::M + C::W * C::M / 16) * 8 + 2 * K::TW_BYTES;
-    const u64 grid = (a.batch * 4 + C::W - 1) / C::W;
+    if constexpr (C::W % 4 != 0) {
+        return hipErrorNotSupported;
+    } else {
+        constexpr size_t lds = (size_t)(C::W * C::M + C::W * C::M / 16) * 8 + 2 * K::TW_BYTES;
+        const u64 grid = (a.batch * 4 + C::W - 1) / C::W;
+        if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+        if (hipError_t e = allow_big_lds((const void *)digit_tail32_kernel<LP, 4>, lds)) return e;
+        KernelTimer kt("digit_tail32", LP, st);
+        hipLaunchKernelGGL((digit_tail32_kernel<LP, 4>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        return hipGetLastError();
+    }
+}
+template <int LP>
+static hipError_t launch_tail32_ks_lp(const Ext32Args &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    using K = Cfg32<LP>;
+    constexpr size_t lds = K::TILE_BYTES + 2 * K::TW_BYTES;
+    const u64 grid = (a.batch * (a.k + 1) + C::W - 1) / C::W;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)digit_tail32_kernel<LP, 4>, lds)) return e;
-    KernelTimer kt("digit_tail32", LP, st);
-    hipLaunchKernelGGL((digit_tail32_kernel<LP, 4>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    if (hipError_t e = allow_big_lds((const void *)digit_tail32_ks_kernel<LP>, lds)) return e;
+    KernelTimer kt("digit_tail32_ks", LP, st);
+    hipLaunchKernelGGL((digit_tail32_ks_kernel<LP>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
+// TGGSW x TGLWE: k = 1, single-pass sizes where a workgroup of the tail holds whole ciphertexts
 bool ext32_shape_supported(u64 n, unsigned k, unsigned l) {
     if (k != 1 || l < 1 || l > 64) return false;
     if (n != 256 && n != 512 && n != 1024) return false;
     return (u64)(k + 1) * l * n <= (1ull << 21);          // |half-sum| < T n 2^32 <= 2^53 < P / 2
 }
+// GLWE::key_switch, base 2: k = 1, 2^8 <= n <= 2^12
+bool ks32_shape_supported(u64 n, unsigned k, unsigned l) {
+    if (k != 1 || l < 1 || l > 64) return false;
+    if (n < 256 || n > 4096 || (n & (n - 1))) return false;
+    return (u64)k * l * n <= (1ull << 21);
+}
+uint32_t ext32_units(int log_n) { return log_n >= 8 && log_n <= 12 ? 4096u >> log_n : 0u; }
 
-hipError_t launch_ext32_key(const Ext32Args &a, int log_n, hipStream_t st) {
-    switch (log_n) {
-        case 8: return launch_key32_lp<8>(a, st);
-        case 9: return launch_key32_lp<9>(a, st);
-        case 10: return launch_key32_lp<10>(a, st);
-    }
+#define FHE_LP_SWITCH(FN, ...)                                        \
+    switch (log_n) {                                                  \
+        case 8: return FN<8 __VA_ARGS__>(a, st);                      \
+        case 9: return FN<9 __VA_ARGS__>(a, st);                      \
+        case 10: return FN<10 __VA_ARGS__>(a, st);                    \
+        case 11: return FN<11 __VA_ARGS__>(a, st);                    \
+        case 12: return FN<12 __VA_ARGS__>(a, st);                    \
+    }                                                                 \
+    return hipErrorNotSupported;
+#define FHE_COMMA ,
+hipError_t launch_ext32_key(const Ext32Args &a, int log_n, hipStream_t st) { FHE_LP_SWITCH(launch_key32_lp) }
+hipError_t launch_ext32_mac(const Ext32Args &a, int log_n, int src_kind, hipStream_t st) {
+    if (src_kind == SRC_DIGITS) { FHE_LP_SWITCH(launch_mac32_lp, FHE_COMMA SRC_DIGITS) }
+    if (src_kind == SRC_ZQBITS) { FHE_LP_SWITCH(launch_mac32_lp, FHE_COMMA SRC_ZQBITS) }
     return hipErrorNotSupported;
 }
-hipError_t launch_ext32_mac(const Ext32Args &a, int log_n, hipStream_t st) {
-    switch (log_n) {
-        case 8: return launch_mac32_lp<8>(a, st);
-        case 9: return launch_mac32_lp<9>(a, st);
-        case 10: return launch_mac32_lp<10>(a, st);
-    }
-    return hipErrorNotSupported;
-}
-hipError_t launch_ext32_tail(const Ext32Args &a, int log_n, hipStream_t st) {
-    switch (log_n) {
-        case 8: return launch_tail32_lp<8>(a, st);
-        case 9: return launch_tail32_lp<9>(a, st);
-        case 10: return launch_tail32_lp<10>(a, st);
-    }
-    return hipErrorNotSupported;
-}
+hipError_t launch_ext32_tail(const Ext32Args &a, int log_n, hipStream_t st) { FHE_LP_SWITCH(launch_tail32_lp) }
+hipError_t launch_ext32_tail_ks(const Ext32Args &a, int log_n, hipStream_t st) { FHE_LP_SWITCH(launch_tail32_ks_lp) }
+#undef FHE_LP_SWITCH
+#undef FHE_COMMA
 
 }  // namespace fhe

@@ -16,9 +16,10 @@ static_assert((uint64_t)kExt32PrimeA * 25 < (1ull << 32) && kExt32PrimeA > kExt3
 
 struct Ext32Args {
     // key preparation
-    const u64 *key64;          // [rows][n] words below 2^32 (the split TGGSW)
-    uint32_t *key32;           // [prime][rows][n], NTT domain
-    u64 rows;
+    const u64 *key64;          // [T][key_k1][n] 64-bit words (the key as the reference holds it)
+    uint32_t *key32;           // [prime][T][half][key_k1][n], NTT domain
+    u64 rows;                  // T * 2 * key_k1
+    uint32_t key_k1;
     // product
     const u64 *src;            // ciphertexts, source row r of ciphertext b at src + b*ct_stride + r*n
     u64 ct_stride;
@@ -35,11 +36,19 @@ struct Ext32Args {
     Tw32 ninv[2];              // n^-1 mod p
     Tw32 crt;                  // pA^-1 mod pB
     u64 P, halfP;              // pA * pB, ceil(P / 2)
+    // key switching tail (digit_tail32_ks_kernel)
+    Mod mod;                   // the ring's q
+    u64 two32;                 // 2^32 mod q
+    const u64 *glwe;           // the ciphertexts again, for the body row
+    uint32_t k;
 };
 
-bool ext32_shape_supported(u64 n, unsigned k, unsigned l);
+bool ext32_shape_supported(u64 n, unsigned k, unsigned l);        // TGGSW x TGLWE
+bool ks32_shape_supported(u64 n, unsigned k, unsigned l);         // GLWE::key_switch, base 2
+uint32_t ext32_units(int log_n);                                   // digits per step of the fused kernel
 hipError_t launch_ext32_key(const Ext32Args &a, int log_n, hipStream_t st);
-hipError_t launch_ext32_mac(const Ext32Args &a, int log_n, hipStream_t st);
+hipError_t launch_ext32_mac(const Ext32Args &a, int log_n, int src_kind, hipStream_t st);
 hipError_t launch_ext32_tail(const Ext32Args &a, int log_n, hipStream_t st);
+hipError_t launch_ext32_tail_ks(const Ext32Args &a, int log_n, hipStream_t st);
 
 }  // namespace fhe

@@ -20,6 +20,7 @@
 
 #include "capi_internal.hpp"
 #include "digit_mac.hpp"
+#include "digit32.hpp"
 #include "zq_device.hpp"
 #include "mac_kernel.hpp"
 
@@ -409,6 +410,32 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     void *w = nullptr;
     // Base 2 at 2^8 <= n <= 2^12: decomposition, digit transforms and the multiply-accumulate against the
     // key are ONE kernel (digit_mac.hip): RHS[b][c] = sum_t KSK[t][c] (.) NTT(digit_t(b)), nothing else stored.
+    // Base 2, k = 1, key in coefficients: the sums are small integers (|half-sum| < k l n 2^32), so they are computed
+    // modulo two 27-bit primes with 32-bit arithmetic (digit32.hip) — the key split at bit 32 and transformed per
+    // prime, then digit extraction -> both transforms -> multiply-accumulate in one kernel, and a tail that lifts the
+    // sums back, reduces them modulo q and forms (0, b) - rhs.
+    if (beta == 2 && fhe_ext32_enabled() && !(flags & FHE_A_IS_EVALS) && dp.wide && fhe::ks32_shape_supported(n, k, l)) {
+        fhe::Ext32Args a{};
+        if ((rc = fhe_ext32_tables(n, &a)) != FHE_OK) return rc;
+        const u32 W = fhe::ext32_units((int)dp.log_n);
+        u32 parts = 1;
+        { const char *pe = getenv("FHE_KS_PARTS"); if (pe) parts = (u32)atoi(pe); else
+        while (parts < 8 && batch * parts < 1024 && (T / (parts * 2)) >= 2 * W) parts *= 2; }
+        // [key transforms: 2 primes * 2*T*k1 rows of u32] [partial sums: batch*parts*2*2*k1 rows of u32]
+        const u64 krows = 2ull * T * k1;
+        if ((rc = fhe_workspace_get(1, 2 * krows * n * 4 + (u64)batch * parts * 2 * (2 * k1) * n * 4, st, &w)) != FHE_OK) return rc;
+        uint32_t *KEY32 = (uint32_t *)w, *PART32 = KEY32 + 2 * krows * n;
+        a.key64 = (const u64 *)d_ksk; a.key32 = KEY32; a.rows = krows; a.key_k1 = k1;
+        hipError_t e = fhe::launch_ext32_key(a, (int)dp.log_n, st);
+        if (e != hipSuccess) return fhe_hip_fail(e, "ntt32_fwd_key_kernel");
+        a.src = (const u64 *)d_glwe; a.ct_stride = (u64)k1 * n; a.part32 = PART32; a.out = (u64 *)d_out; a.batch = batch;
+        a.l = l; a.T = T; a.parts = parts;
+        a.tpp = ((T + parts - 1) / parts + W - 1) / W * W;
+        a.mod = dp.mod; a.two32 = (1ull << 32) % plan->q; a.glwe = (const u64 *)d_glwe; a.k = k;
+        e = fhe::launch_ext32_mac(a, (int)dp.log_n, fhe::SRC_ZQBITS, st);
+        if (e == hipSuccess) e = fhe::launch_ext32_tail_ks(a, (int)dp.log_n, st);
+        return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "digit32 kernels");
+    }
     static const bool fused_on = [] { const char *e = getenv("FHE_DIGIT_MAC_FUSED"); return !(e && e[0] == '0'); }();
     if (beta == 2 && fused_on && dp.wide && dp.log_n >= 8 && dp.log_n <= 12 && (k1 == 2 || k1 == 3)) {
         const u32 parts = fhe::digit_mac_parts(batch, T, dp.log_n, k1);

@@ -786,7 +786,7 @@ void fhe_ext32_free_all() {
 
 // fills the per-prime fields of `a` (tables on the current device, built on first use from the same plans — psi by the
 // reference's search, roots[i] = psi^bitrev(i) — as every other transform of the library)
-static int ext32_tables(u64 n, fhe::Ext32Args *a) {
+int fhe_ext32_tables(uint64_t n, fhe::Ext32Args *a) {
     int dev = 0;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
@@ -856,10 +856,11 @@ static int ext32_tables(u64 n, fhe::Ext32Args *a) {
     a->halfP = (a->P + 1) / 2;
     return FHE_OK;
 }
-static bool ext32_on(u64 n, unsigned k, unsigned l) {
+bool fhe_ext32_enabled() {
     static const bool on = [] { const char *e = getenv("FHE_EXT32"); return !(e && e[0] == '0'); }();
-    return on && fhe::ext32_shape_supported(n, k, l);
+    return on;
 }
+static bool ext32_on(u64 n, unsigned k, unsigned l) { return fhe_ext32_enabled() && fhe::ext32_shape_supported(n, k, l); }
 
 // ---- TFHE: TGGSW x TGLWE external product -------------------------------------------------------
 static bool one_prime_form(u64 n, unsigned k, unsigned l) {
@@ -888,17 +889,11 @@ extern "C" int fhe_tggsw_prepare_dev(uint64_t n, unsigned k, unsigned l, const v
     const u32 k1 = k + 1;
     const u64 T = (u64)k1 * l, grows = T * k1;
     if (ext32_on(n, k, l)) {
-        // two 27-bit primes (digit32.hip): halves split into a scratch, transformed per prime into d_prepared as u32
+        // two 27-bit primes (digit32.hip): the halves of every word transformed per prime into d_prepared as u32
         // [prime][t][half][c][n] — the same number of bytes as the 61-bit form
         fhe::Ext32Args a{};
-        if ((rc = ext32_tables(n, &a)) != FHE_OK) return rc;
-        void *scratch = nullptr;
-        if ((rc = fhe_workspace_get(1, 2 * grows * n * 8, st, &scratch)) != FHE_OK) return rc;
-        { fhe::KernelTimer kt_("zr_split32", 0, st);
-        hipLaunchKernelGGL(fhe::zr_split32_kernel, dim3(fhe_ew_grid(grows * n)), dim3(256), 0, st, (const u64 *)d_tggsw, (u64 *)scratch, T, k1, (u32)n);
-        }
-        LAUNCH_OK("zr_split32_kernel");
-        a.key64 = (const u64 *)scratch; a.key32 = (uint32_t *)d_prepared; a.rows = 2 * grows;
+        if ((rc = fhe_ext32_tables(n, &a)) != FHE_OK) return rc;
+        a.key64 = (const u64 *)d_tggsw; a.key32 = (uint32_t *)d_prepared; a.rows = 2 * grows; a.key_k1 = k1;
         hipError_t e = fhe::launch_ext32_key(a, (int)z1.dp[0].log_n, st);
         return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "ntt32_fwd_key_kernel");
     }
@@ -927,7 +922,7 @@ extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, u
     void *wsv = nullptr;
     if (ext32_on(n, k, l)) {
         fhe::Ext32Args a{};
-        if ((rc = ext32_tables(n, &a)) != FHE_OK) return rc;
+        if ((rc = fhe_ext32_tables(n, &a)) != FHE_OK) return rc;
         const u32 parts32 = fhe::digit_mac_parts(batch, (u32)T, z1.dp[0].log_n, 2 * k1);
         if ((rc = fhe_workspace_get(1, (u64)batch * parts32 * 2 * (2 * k1) * n * 4, st, &wsv)) != FHE_OK) return rc;
         const u32 W = (u32)(4096 / n);
@@ -935,7 +930,7 @@ extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, u
         a.src = (const u64 *)d_tglwe; a.ct_stride = (u64)k1 * n; a.part32 = (uint32_t *)wsv; a.out = (u64 *)d_out; a.batch = batch;
         a.l = l; a.T = (u32)T; a.parts = parts32;
         a.tpp = (((u32)T + parts32 - 1) / parts32 + W - 1) / W * W;
-        hipError_t e = fhe::launch_ext32_mac(a, (int)z1.dp[0].log_n, st);
+        hipError_t e = fhe::launch_ext32_mac(a, (int)z1.dp[0].log_n, fhe::SRC_DIGITS, st);
         if (e == hipSuccess) e = fhe::launch_ext32_tail(a, (int)z1.dp[0].log_n, st);
         return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "digit32 kernels");
     }

@@ -345,7 +345,11 @@ def test_fused_external_product_and_prepared_key(pkg, oracle, n, k, l, batch):
                                            (Q61, 1024, 1, 61, 9),
                                            (Q61, 1024, 2, 33, 2),     # k+1 = 3 output rows
                                            (Q16, 256, 1, 16, 20),     # q = 65537 < 2^l: the saturation branch of Zq::decompose everywhere
-                                           (Q61, 2048, 2, 64, 1)])    # l = 64: `1 << l` wraps like a --release build
+                                           (Q61, 2048, 2, 64, 1),     # l = 64: `1 << l` wraps like a --release build
+                                           (Q61, 2048, 1, 64, 2),     # the same on the two-small-prime kernels (k = 1), 8 positions per thread
+                                           (Q61, 512, 1, 40, 5),
+                                           (Q16, 4096, 1, 16, 2),     # 512-thread workgroups with every digit saturated
+                                           (Q61, 256, 1, 7, 33)])     # more ciphertexts than a tail workgroup holds rows, odd digit count
 def test_fused_key_switch(pkg, oracle, q, n, k, l, batch):
     """GLWE::key_switch (gfhe/src/glwe.rs:126-137) with base-2 decomposition through digit_mac_kernel;
     key in coefficients and key resident in the NTT domain (FHE_A_IS_EVALS) give the oracle's words."""

@@ -218,10 +218,7 @@ __device__ __forceinline__ void inv_rounds32(u32 (&v)[16], u32 *lds, const Tw32 
     round_inv32<C::R0>(v, TW(C::in_lds(0)), 1u, p, p2);
 }
 
-// Shapes: ContigCfg's — 256 threads, W = 4096 / n units side by side (one for n = 4096).  The fused digit kernel
-// multiplies at PPT = n / 256 positions per thread into NP * NC * PPT 64-bit accumulators, NP = the primes a workgroup
-// runs: both in lockstep while that is at most 32 accumulators (n <= 1024 with NC = 4), otherwise ONE prime per
-// workgroup (blockIdx.y) — twice the workgroups, each extracting the digits again, 64 accumulators at n = 4096.
+// Shapes of the transform kernels (key preparation, tails): ContigCfg's — 256 threads, W = 4096 / n units side by side.
 template <int LP>
 struct Cfg32 {
     using C = ContigCfg<LP>;
@@ -229,13 +226,30 @@ struct Cfg32 {
     static constexpr size_t TILE_BYTES = (size_t)(W * M + W * M / 16) * 4;          // one padded tile of u32
     static constexpr size_t TW_BYTES = (size_t)C::LTW_N * sizeof(Tw32);
     static constexpr size_t LUT_BYTES = (size_t)kLut32Words * 4;
-    // per prime a workgroup runs: a tile, a twiddle tile, a look-up table
-    static constexpr size_t lds_bytes(int np) { return (size_t)np * (TILE_BYTES + TW_BYTES + LUT_BYTES); }
     static_assert(LP >= 8 && LP <= 12, "n = 256 .. 4096");
 };
+// Shape of the fused digit kernel: TH threads transform W = 16 TH / n digits side by side, then multiply at
+// PPT = n / TH positions per thread into 2 (primes) * NC * PPT 64-bit accumulators.  With NC = 4 that is 32 accumulators
+// up to n = 1024 — room for both primes' coefficients, so their transforms run in lockstep (LOCK) — and 64 beyond, where
+// the primes take turns on 16 coefficients; n = 4096 takes 512 threads (two digits side by side, one workgroup per CU).
+// Measured at n = 4096 (256 key switches, l = 61): 512 threads 354 us; 256 threads with ONE prime per workgroup (twice
+// the workgroups, 64 accumulators each, two per CU) 384 us; a software pipeline that multiplies step s-1 while step s
+// transforms (double-buffered tiles, key loads issued a half-round ahead) spills and is 2-3x slower at every size.
+template <int LP>
+struct Mac32Cfg {
+    using C = ContigCfg<LP>;
+    static constexpr int M = C::M, TPB = C::TPB;
+    static constexpr int TH = LP == 12 ? 512 : 256;
+    static constexpr int W = TH / TPB, PPT = M / TH;
+    static constexpr bool LOCK = PPT <= 4;
+    static constexpr size_t TILE_BYTES = (size_t)(W * M + W * M / 16) * 4;
+    static constexpr size_t TW_BYTES = Cfg32<LP>::TW_BYTES, LUT_BYTES = Cfg32<LP>::LUT_BYTES;
+    static constexpr size_t LDS_BYTES = 2 * (TILE_BYTES + TW_BYTES + LUT_BYTES);   // per prime: tile, twiddle tile, look-up table
+};
 
+template <int TH = 256>
 __device__ __forceinline__ void stage_tw32(Tw32 *ltw, const Tw32 *__restrict__ tw, int count, u32 tid) {
-    for (u32 i = tid; i < (u32)count; i += 256) ltw[i] = tw[i];   // s0 = blk = 0: the local table is the head of the global one
+    for (u32 i = tid; i < (u32)count; i += TH) ltw[i] = tw[i];   // s0 = blk = 0: the local table is the head of the global one
 }
 
 // ---- key preparation: [T][k1][n] u64 words  ->  [prime][T][half][k1][n] u32, NTT domain (rows = T * 2 * k1) -------------------------
@@ -296,16 +310,14 @@ __device__ __forceinline__ u32 digit32_of(u64 x, u32 l, u32 d) {
 
 // key32 layout: [prime][t][c][n], t = row*l + digit, c < NC (NC = 2 * output rows: half-major, then component).
 // out: partial sums [b][part][prime][c][n] u32 canonical.
-// NP = 2: both primes in this workgroup, their transforms in lockstep (32 live coefficients); NP = 1: prime blockIdx.y.
-template <int LP, int NC, int SRC, int NP>
-__global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
+template <int LP, int NC, int SRC>
+__global__ __launch_bounds__((Mac32Cfg<LP>::TH), (512 / Mac32Cfg<LP>::TH)) void digit_mac32_kernel(Ext32Args a) {
     using C = ContigCfg<LP>;
-    using K = Cfg32<LP>;
-    constexpr int PPT = K::PPT, W = K::W;
+    using K = Mac32Cfg<LP>;
+    constexpr int PPT = K::PPT, W = K::W, TH = K::TH, NP = 2;
     static_assert(NP * NC * PPT <= 64, "accumulators");
     static_assert(1 + 2 * LP <= 25, "ct32_loose: the bound of the values after LP stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const u32 pr0 = NP == 2 ? 0u : blockIdx.y;
     u32 *tile[NP];
     Tw32 *ltw_w[NP];
     u32 *llut_w[NP];
@@ -324,9 +336,9 @@ __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
     const Tw32 *gtw[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        p[i] = a.p[pr0 + i]; bq[i] = a.bq[pr0 + i]; gtw[i] = a.tw_fwd[pr0 + i];
-        stage_tw32(ltw_w[i], gtw[i], C::LTW_N, tid);
-        for (u32 e = tid; e < (u32)kLut32Words; e += 256) llut_w[i][e] = a.lut[pr0 + i][e];
+        p[i] = a.p[i]; bq[i] = a.bq[i]; gtw[i] = a.tw_fwd[i];
+        stage_tw32<TH>(ltw_w[i], gtw[i], C::LTW_N, tid);
+        for (u32 e = tid; e < (u32)kLut32Words; e += TH) llut_w[i][e] = a.lut[i][e];
     }
     __syncthreads();
     const u64 *__restrict__ ct = a.src + b * a.ct_stride;
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
         const u64 *__restrict__ row = ct + (u64)r * n;
         // the tiles were read by the previous step's multiply phase: barrier first (FRESH = false); every thread then
         // rewrites exactly the slots it gathered in the last exchange, reduced below 2p (a product is below 2 p^2 < 2^55.8)
-        if constexpr (NP == 2) {
+        if constexpr (K::LOCK) {
             u32 va[16], vb[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) va[k] = vb[k] = digit32_of<SRC>(row[field_of<C::A0>(tf, k)], a.l, d);
@@ -366,16 +378,22 @@ __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
                 tile[NP - 1][sl] = barrett2p_32(vb[k], p[NP - 1], bq[NP - 1]);
             }
         } else {
-            u32 v[16];
+            u32 bits = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = digit32_of<SRC>(row[field_of<C::A0>(tf, k)], a.l, d);
+            for (int k = 0; k < 16; k++) bits |= digit32_of<SRC>(row[field_of<C::A0>(tf, k)], a.l, d) << k;
+#pragma unroll
+            for (int pr = 0; pr < NP; pr++) {
+                u32 v[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = (bits >> k) & 1u;
 #ifndef FHE_D32_ABLATE_NTT
-            fwd_rounds32<LP, true, false, true>(v, tile[0], ltw_w[0], gtw[0], llut_w[0], w, tf, p[0], 2u * p[0]);
+                fwd_rounds32<LP, true, false, true>(v, tile[pr], ltw_w[pr], gtw[pr], llut_w[pr], w, tf, p[pr], 2u * p[pr]);
 #else
-            __syncthreads();
+                __syncthreads();
 #endif
 #pragma unroll
-            for (int k = 0; k < 16; k++) tile[0][pad16(w * C::M + field_of<0>(tf, k))] = barrett2p_32(v[k], p[0], bq[0]);
+                for (int k = 0; k < 16; k++) tile[pr][pad16(w * C::M + field_of<0>(tf, k))] = barrett2p_32(v[k], p[pr], bq[pr]);
+            }
         }
         __syncthreads();
         const u32 nu = min((u32)W, t_end - t0);
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
                     u32 x[PPT];
 #pragma unroll
                     for (int i = 0; i < PPT; i++) x[i] = tile[pr][pad16(u * C::M + j0 + i)];
-                    const u32 *__restrict__ g = a.key32 + (((u64)(pr0 + pr) * a.T + (t0 + u)) * NC) * n + j0;
+                    const u32 *__restrict__ g = a.key32 + (((u64)(pr) * a.T + (t0 + u)) * NC) * n + j0;
 #pragma unroll
                     for (int c = 0; c < NC; c++) {
                         u32 gv[PPT];
@@ -419,17 +437,17 @@ __global__ __launch_bounds__(256, 2) void digit_mac32_kernel(Ext32Args a) {
 #pragma unroll
                 for (int c = 0; c < NC; c++)
 #pragma unroll
-                    for (int i = 0; i < PPT; i++) acc[pr][c][i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr0 + pr]);
+                    for (int i = 0; i < PPT; i++) acc[pr][c][i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr]);
             pending = 1;
         }
     }
 #pragma unroll
     for (int pr = 0; pr < NP; pr++) {
-        u32 *__restrict__ o = a.part32 + ((((b * a.parts + part) * 2 + pr0 + pr) * NC) * (u64)n) + j0;
+        u32 *__restrict__ o = a.part32 + ((((b * a.parts + part) * 2 + pr) * NC) * (u64)n) + j0;
 #pragma unroll
         for (int c = 0; c < NC; c++)
 #pragma unroll
-            for (int i = 0; i < PPT; i++) o[(u64)c * n + i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr0 + pr]);
+            for (int i = 0; i < PPT; i++) o[(u64)c * n + i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr]);
     }
 }
 
@@ -611,14 +629,12 @@ static hipError_t launch_key32_lp(const Ext32Args &a, hipStream_t st) {
 }
 template <int LP, int SRC>
 static hipError_t launch_mac32_lp(const Ext32Args &a, hipStream_t st) {
-    using K = Cfg32<LP>;
-    constexpr int NP = 2 * 4 * K::PPT <= 32 ? 2 : 1;     // 32 accumulators leave room for both primes' coefficients
-    constexpr size_t lds = K::lds_bytes(NP);
+    using K = Mac32Cfg<LP>;
     const u64 grid = a.batch * a.parts;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)digit_mac32_kernel<LP, 4, SRC, NP>, lds)) return e;
+    if (hipError_t e = allow_big_lds((const void *)digit_mac32_kernel<LP, 4, SRC>, K::LDS_BYTES)) return e;
     KernelTimer kt("digit_mac32", LP, st);
-    hipLaunchKernelGGL((digit_mac32_kernel<LP, 4, SRC, NP>), dim3((unsigned)grid, 2 / NP), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((digit_mac32_kernel<LP, 4, SRC>), dim3((unsigned)grid), dim3(K::TH), K::LDS_BYTES, st, a);
     return hipGetLastError();
 }
 template <int LP>
@@ -662,7 +678,7 @@ bool ks32_shape_supported(u64 n, unsigned k, unsigned l) {
     if (n < 256 || n > 4096 || (n & (n - 1))) return false;
     return (u64)k * l * n <= (1ull << 21);
 }
-uint32_t ext32_units(int log_n) { return log_n >= 8 && log_n <= 12 ? 4096u >> log_n : 0u; }
+uint32_t ext32_units(int log_n) { return log_n >= 8 && log_n <= 12 ? (log_n == 12 ? 2u : 4096u >> log_n) : 0u; }
 
 #define FHE_LP_SWITCH(FN, ...)                                        \
     switch (log_n) {                                                  \

@@ -48,6 +48,7 @@ EXPORTS = [
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
     "fhe_ntt_plan_prepare", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace",
     "fhe_tggsw_prepared_words", "fhe_tggsw_prepare_dev", "fhe_tggsw_external_product_prepared_dev",
+    "fhe_glwe_ksk_prepared_words", "fhe_glwe_ksk_prepare_dev", "fhe_glwe_key_switch_prepared_dev",
     "fhe_bfv_rlk_prepared_words", "fhe_bfv_rlk_prepare_dev", "fhe_bfv_relinearize_prepared_dev", "fhe_bfv_mul_prepared_dev",
     # next rows: exact products over Z / mod 2^64 on top of the engine
     "fhe_r_naive_mul", "fhe_r_naive_mul_dev", "fhe_mul_div_round_dev",
@@ -194,6 +195,10 @@ def load_library():
     L.fhe_tggsw_prepared_words.restype = _sz
     L.fhe_tggsw_prepare_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp]
     L.fhe_tggsw_external_product_prepared_dev.argtypes = [_u64, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
+    L.fhe_glwe_ksk_prepared_words.argtypes = [_vp, _uint, _uint, _uint]
+    L.fhe_glwe_ksk_prepared_words.restype = _sz
+    L.fhe_glwe_ksk_prepare_dev.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp]
+    L.fhe_glwe_key_switch_prepared_dev.argtypes = [_vp, _uint, _uint, _uint, _vp, _vp, _vp, _sz, _vp]
     L.fhe_tr_dot_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
     L.fhe_tr_mul_r_dev.argtypes = [_vp, _vp, _vp, _vp, _uint, _sz, _uint, _vp]
     L.fhe_glev_mul_dev.argtypes = [_vp, _uint, _uint, _vp, _vp, _vp, _sz, _uint, _vp]

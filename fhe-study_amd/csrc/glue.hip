@@ -390,6 +390,51 @@ extern "C" int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l
                      flags & FHE_OUT_EVALS, l, k + 1, batch, (u64 *)w, (hipStream_t)stream);
 }
 
+// ---- key switching on two 27-bit primes (digit32.hip) -------------------------------------------------------------
+// Base 2, k = 1: the sums  sum_t ksk[t][c] * digit_t  are small integers (|half-sum| < k l n 2^32 with the key words
+// split at bit 32), so they are computed modulo two 27-bit primes with 32-bit arithmetic: the key halves transformed
+// per prime (per call, or once by fhe_glwe_ksk_prepare_dev), then digit extraction -> both transforms ->
+// multiply-accumulate in one kernel, and a tail that lifts the sums back, reduces them modulo q and forms (0, b) - rhs.
+static bool ks32_usable(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l) {
+    return beta == 2 && fhe_ext32_enabled() && (plan->q >> 61) == 0 && fhe::ks32_shape_supported(plan->n, k, l);
+}
+// key32: the prepared key ([prime][t][half][c][n] u32), or nullptr to prepare d_ksk into the workspace first
+static int ks32_run(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, unsigned k, unsigned l, const void *d_glwe,
+                    const uint32_t *key32, const void *d_ksk, void *d_out, size_t batch, hipStream_t st) {
+    const u64 n = plan->n;
+    const u32 k1 = k + 1, T = k * l;
+    fhe::Ext32Args a{};
+    int rc = fhe_ext32_tables(n, &a);
+    if (rc != FHE_OK) return rc;
+    const u32 W = fhe::ext32_units((int)dp.log_n);
+    // parts: split the digits of a ciphertext over workgroups only while the batch alone leaves CUs empty (one
+    // workgroup of 512 threads per CU at n = 4096, two of 256 below); measured at n = 4096, batch 256: 1 part 354 us,
+    // 2 parts 376, 4 parts 395 (every part ends in 64 reductions per thread and its own partial sums)
+    u32 parts = 1;
+    const u64 slots = dp.log_n == 12 ? 256 : 512;
+    while (parts < 8 && batch * parts < slots && (T / (parts * 2)) >= 2 * W) parts *= 2;
+    // [partial sums: batch*parts*2*2*k1 rows of u32] [key transforms: 2 primes * 2*T*k1 rows of u32, unless prepared]
+    const u64 krows = 2ull * T * k1, part_words = (u64)batch * parts * 2 * (2 * k1) * n;
+    void *w = nullptr;
+    if ((rc = fhe_workspace_get(1, (part_words + (key32 ? 0 : 2 * krows * n)) * 4, st, &w)) != FHE_OK) return rc;
+    uint32_t *PART32 = (uint32_t *)w;
+    hipError_t e = hipSuccess;
+    if (!key32) {
+        uint32_t *KEY32 = PART32 + part_words;
+        a.key64 = (const u64 *)d_ksk; a.key32 = KEY32; a.rows = krows; a.key_k1 = k1;
+        if ((e = fhe::launch_ext32_key(a, (int)dp.log_n, st)) != hipSuccess) return fhe_hip_fail(e, "ntt32_fwd_key_kernel");
+        key32 = KEY32;
+    }
+    a.key32 = const_cast<uint32_t *>(key32);
+    a.src = (const u64 *)d_glwe; a.ct_stride = (u64)k1 * n; a.part32 = PART32; a.out = (u64 *)d_out; a.batch = batch;
+    a.l = l; a.T = T; a.parts = parts;
+    a.tpp = ((T + parts - 1) / parts + W - 1) / W * W;
+    a.mod = dp.mod; a.two32 = (1ull << 32) % plan->q; a.glwe = (const u64 *)d_glwe; a.k = k;
+    e = fhe::launch_ext32_mac(a, (int)dp.log_n, fhe::SRC_ZQBITS, st);
+    if (e == hipSuccess) e = fhe::launch_ext32_tail_ks(a, (int)dp.log_n, st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "digit32 kernels");
+}
+
 // GLWE::key_switch: glwe [batch][k+1][n]; ksk [k][l][k+1][n] (shared); out [batch][k+1][n]
 extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const void *d_glwe, const void *d_ksk,
                                        void *d_out, size_t batch, unsigned flags, void *stream) {
@@ -410,35 +455,9 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     void *w = nullptr;
     // Base 2 at 2^8 <= n <= 2^12: decomposition, digit transforms and the multiply-accumulate against the
     // key are ONE kernel (digit_mac.hip): RHS[b][c] = sum_t KSK[t][c] (.) NTT(digit_t(b)), nothing else stored.
-    // Base 2, k = 1, key in coefficients: the sums are small integers (|half-sum| < k l n 2^32), so they are computed
-    // modulo two 27-bit primes with 32-bit arithmetic (digit32.hip) — the key split at bit 32 and transformed per
-    // prime, then digit extraction -> both transforms -> multiply-accumulate in one kernel, and a tail that lifts the
-    // sums back, reduces them modulo q and forms (0, b) - rhs.
-    if (beta == 2 && fhe_ext32_enabled() && !(flags & FHE_A_IS_EVALS) && dp.wide && fhe::ks32_shape_supported(n, k, l)) {
-        fhe::Ext32Args a{};
-        if ((rc = fhe_ext32_tables(n, &a)) != FHE_OK) return rc;
-        const u32 W = fhe::ext32_units((int)dp.log_n);
-        u32 parts = 1;
-        // parts: split the digits of a ciphertext over workgroups only while the batch alone leaves CUs empty (one
-        // workgroup of 512 threads per CU at n = 4096, two of 256 below); measured at n = 4096, batch 256: 1 part 354 us,
-        // 2 parts 376, 4 parts 395 (every part ends in 64 reductions per thread and its own partial sums)
-        const u64 slots = dp.log_n == 12 ? 256 : 512;
-        while (parts < 8 && batch * parts < slots && (T / (parts * 2)) >= 2 * W) parts *= 2;
-        // [key transforms: 2 primes * 2*T*k1 rows of u32] [partial sums: batch*parts*2*2*k1 rows of u32]
-        const u64 krows = 2ull * T * k1;
-        if ((rc = fhe_workspace_get(1, 2 * krows * n * 4 + (u64)batch * parts * 2 * (2 * k1) * n * 4, st, &w)) != FHE_OK) return rc;
-        uint32_t *KEY32 = (uint32_t *)w, *PART32 = KEY32 + 2 * krows * n;
-        a.key64 = (const u64 *)d_ksk; a.key32 = KEY32; a.rows = krows; a.key_k1 = k1;
-        hipError_t e = fhe::launch_ext32_key(a, (int)dp.log_n, st);
-        if (e != hipSuccess) return fhe_hip_fail(e, "ntt32_fwd_key_kernel");
-        a.src = (const u64 *)d_glwe; a.ct_stride = (u64)k1 * n; a.part32 = PART32; a.out = (u64 *)d_out; a.batch = batch;
-        a.l = l; a.T = T; a.parts = parts;
-        a.tpp = ((T + parts - 1) / parts + W - 1) / W * W;
-        a.mod = dp.mod; a.two32 = (1ull << 32) % plan->q; a.glwe = (const u64 *)d_glwe; a.k = k;
-        e = fhe::launch_ext32_mac(a, (int)dp.log_n, fhe::SRC_ZQBITS, st);
-        if (e == hipSuccess) e = fhe::launch_ext32_tail_ks(a, (int)dp.log_n, st);
-        return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "digit32 kernels");
-    }
+    // Base 2, k = 1, key in coefficients: two 27-bit primes and 32-bit arithmetic (ks32_run above)
+    if (!(flags & FHE_A_IS_EVALS) && ks32_usable(plan, k, beta, l))
+        return ks32_run(plan, dp, k, l, d_glwe, nullptr, d_ksk, d_out, batch, st);
     static const bool fused_on = [] { const char *e = getenv("FHE_DIGIT_MAC_FUSED"); return !(e && e[0] == '0'); }();
     if (beta == 2 && fused_on && dp.wide && dp.log_n >= 8 && dp.log_n <= 12 && (k1 == 2 || k1 == 3)) {
         const u32 parts = fhe::digit_mac_parts(batch, T, dp.log_n, k1);
@@ -499,6 +518,50 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     }
     LAUNCH_OK("ks_tail_kernel");
     return FHE_OK;
+}
+
+// Resident key-switching key: the form the product consumes, built once.  Base 2 with k = 1 at 2^8 <= n <= 2^12: the
+// two-small-prime transforms of the key halves; otherwise the forward transforms modulo q (what FHE_A_IS_EVALS takes).
+static int ksk_args_ok(const char *fn, const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l) {
+    if (!plan) return fhe_fail(FHE_E_NULL, "%s: plan is NULL", fn);
+    if (k == 0 || l == 0 || beta < 2) return fhe_fail(FHE_E_INVALID, "%s: need k, l >= 1, beta >= 2", fn);
+    return check_decompose_args(fn, plan->q, beta, l);
+}
+extern "C" size_t fhe_glwe_ksk_prepared_words(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l) {
+    if (!plan || k == 0 || l == 0 || beta < 2) return 0;
+    const size_t rows = (size_t)k * l * (k + 1);
+    return (ks32_usable(plan, k, beta, l) ? 2 : 1) * rows * plan->n;
+}
+extern "C" int fhe_glwe_ksk_prepare_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const void *d_ksk,
+                                        void *d_prepared, void *stream) {
+    int rc = ksk_args_ok("fhe_glwe_ksk_prepare_dev", plan, k, beta, l);
+    if (rc != FHE_OK) return rc;
+    if (!d_ksk || !d_prepared) return fhe_fail(FHE_E_NULL, "fhe_glwe_ksk_prepare_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_ksk); REQUIRE_ALIGNED(d_prepared);
+    if (d_ksk == d_prepared) return fhe_fail(FHE_E_INVALID, "fhe_glwe_ksk_prepare_dev: the prepared key cannot overwrite the key");
+    fhe::DevicePlan dp;
+    if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const u64 rows = (u64)k * l * (k + 1);
+    if (!ks32_usable(plan, k, beta, l)) return fwd(plan, dp, (const u64 *)d_ksk, (u64 *)d_prepared, rows, st);
+    fhe::Ext32Args a{};
+    if ((rc = fhe_ext32_tables(plan->n, &a)) != FHE_OK) return rc;
+    a.key64 = (const u64 *)d_ksk; a.key32 = (uint32_t *)d_prepared; a.rows = 2 * rows; a.key_k1 = k + 1;
+    hipError_t e = fhe::launch_ext32_key(a, (int)dp.log_n, st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "ntt32_fwd_key_kernel");
+}
+extern "C" int fhe_glwe_key_switch_prepared_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const void *d_glwe,
+                                                const void *d_prepared, void *d_out, size_t batch, void *stream) {
+    int rc = ksk_args_ok("fhe_glwe_key_switch_prepared_dev", plan, k, beta, l);
+    if (rc != FHE_OK) return rc;
+    if (!ks32_usable(plan, k, beta, l))
+        return fhe_glwe_key_switch_dev(plan, k, beta, l, d_glwe, d_prepared, d_out, batch, FHE_A_IS_EVALS, stream);
+    if (batch == 0) return FHE_OK;
+    if (!d_glwe || !d_prepared || !d_out) return fhe_fail(FHE_E_NULL, "fhe_glwe_key_switch_prepared_dev: NULL buffer");
+    REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_prepared); REQUIRE_ALIGNED(d_out);
+    fhe::DevicePlan dp;
+    if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    return ks32_run(plan, dp, k, l, d_glwe, (const uint32_t *)d_prepared, nullptr, d_out, batch, (hipStream_t)stream);
 }
 
 // ---- host-buffer forms of the N3 surfaces (what a shim of gfhe binds: its data are host Vecs) ----

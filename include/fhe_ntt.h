@@ -280,6 +280,20 @@ int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l, const voi
 int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l,
                             const void *d_glwe, const void *d_ksk, void *d_out, size_t batch,
                             unsigned flags, void *hip_stream);
+/* Resident key-switching key: the key in the form the product consumes, built once and used by every later call
+ * (a key-switching key serves every ciphertext under its secret).  The form is OPAQUE and depends on the shape: with
+ * beta = 2, k = 1, 2^8 <= n <= 2^12 and q < 2^61 it holds transforms of the key's 32-bit halves modulo two 27-bit
+ * primes (twice the words of the key); otherwise fhe_ntt_forward_dev of the key (what FHE_A_IS_EVALS takes).
+ *   fhe_glwe_ksk_prepared_words   u64 words d_prepared must hold (0: invalid arguments)
+ *   fhe_glwe_ksk_prepare_dev      d_ksk [k][l][k+1][n] -> d_prepared (distinct buffers)
+ *   ..._prepared_dev              the key switch against a prepared key; same words as fhe_glwe_key_switch_dev on
+ *                                 the original key.  plan, k, beta, l must be those of the preparation. */
+size_t fhe_glwe_ksk_prepared_words(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l);
+int fhe_glwe_ksk_prepare_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l, const void *d_ksk,
+                             void *d_prepared, void *hip_stream);
+int fhe_glwe_key_switch_prepared_dev(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l,
+                                     const void *d_glwe, const void *d_prepared, void *d_out, size_t batch,
+                                     void *hip_stream);
 
 /* Host-buffer forms of the four surfaces above (same layouts, no flags): what a shim of `gfhe`,
  * whose ciphertexts are host `Vec`s, binds.  They stage through device memory on the calling

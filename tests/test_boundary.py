@@ -157,6 +157,17 @@ def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
     assert L.fhe_rq_decompose_dev(Q16, 8, 4, 8, None, d, 1, None) == B.FHE_E_NULL               # 4^8 = 65536 <= q: fine
     assert L.fhe_glwe_key_switch_dev(plan.handle, 1, 2, 65, d, d, d, 1, 0, None) == B.FHE_E_INVALID
     assert L.fhe_glwe_key_switch_dev(plan.handle, 1, 4, 9, d, d, d, 1, 0, None) == B.FHE_E_INVALID
+    # resident key-switching key: sizes without a device, argument errors before any launch
+    assert L.fhe_glwe_ksk_prepared_words(None, 1, 2, 4) == 0
+    assert L.fhe_glwe_ksk_prepared_words(plan.handle, 0, 2, 4) == 0
+    big = pkg.Plan(Q61, 4096)
+    assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 2, 61) == 2 * 61 * 2 * 4096       # two-small-prime form: twice the key
+    assert L.fhe_glwe_ksk_prepared_words(big.handle, 2, 2, 61) == 2 * 61 * 3 * 4096       # k = 2: transforms modulo q
+    assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 4, 8) == 8 * 2 * 4096
+    assert L.fhe_glwe_ksk_prepare_dev(None, 1, 2, 4, d, d, None) == B.FHE_E_NULL
+    assert L.fhe_glwe_ksk_prepare_dev(plan.handle, 1, 2, 65, d, d, None) == B.FHE_E_INVALID
+    assert L.fhe_glwe_key_switch_prepared_dev(plan.handle, 0, 2, 4, d, d, d, 1, None) == B.FHE_E_INVALID
+    assert L.fhe_glwe_key_switch_prepared_dev(big.handle, 1, 2, 61, None, None, None, 0, None) == 0
     # empty batches are no-ops everywhere
     assert L.fhe_tn_mul_dev(8, None, None, None, 0, None) == 0
     assert L.fhe_bfv_mul_dev(Q16, 16, 2, Q16 * Q16 * Q16, None, None, None, 0, None) == 0

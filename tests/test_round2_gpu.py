@@ -374,6 +374,17 @@ def test_fused_key_switch(pkg, oracle, q, n, k, l, batch):
     B._check(L.fhe_glwe_key_switch_dev(plan.handle, k, 2, l, dglwe.data_ptr(), dKSK.data_ptr(), dout2.data_ptr(), batch,
                                        B.FHE_A_IS_EVALS, None))
     assert np.array_equal(_u64(dout2), want)
+    # resident key in the engine's own (opaque) form, built once; the original key may then go away
+    words = L.fhe_glwe_ksk_prepared_words(plan.handle, k, 2, l)
+    assert words in (ksk.size, 2 * ksk.size)
+    prep = torch.empty(words, dtype=torch.int64, device="cuda")
+    B._check(L.fhe_glwe_ksk_prepare_dev(plan.handle, k, 2, l, dksk.data_ptr(), prep.data_ptr(), None))
+    assert L.fhe_glwe_ksk_prepare_dev(plan.handle, k, 2, l, dksk.data_ptr(), dksk.data_ptr(), None) == B.FHE_E_INVALID
+    dksk.zero_()
+    for nb in (batch, 1):
+        dout3 = torch.zeros((nb, k + 1, n), dtype=torch.int64, device="cuda")
+        B._check(L.fhe_glwe_key_switch_prepared_dev(plan.handle, k, 2, l, dglwe.data_ptr(), prep.data_ptr(), dout3.data_ptr(), nb, None))
+        assert np.array_equal(_u64(dout3), want[:nb])
 
 
 def test_fused_and_unfused_digit_paths_agree_at_bench_sizes(pkg):

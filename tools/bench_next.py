@@ -59,7 +59,7 @@ def extprod(n=1024, k=1, l=64, batch=630, prepared=False):
           f"{batch/dt:,.0f} products/s   (oracle schoolbook, 1 core: {1/cpu:.2f}/s)  parity={ok}")
 
 
-def key_switch(n=4096, k=1, beta=2, l=61, batch=256, q=pkg.Q61, resident_key=False):
+def key_switch(n=4096, k=1, beta=2, l=61, batch=256, q=pkg.Q61, resident_key=False, prepared=False):
     """GLWE<Rq>::key_switch (gfhe/src/glwe.rs:126-137): k*l*(k+1) products per ciphertext"""
     rng = np.random.default_rng(3)
     plan = pkg.Plan(q, n)
@@ -73,6 +73,10 @@ def key_switch(n=4096, k=1, beta=2, l=61, batch=256, q=pkg.Q61, resident_key=Fal
         plan.forward_dev(ksk.data_ptr(), key.data_ptr(), k * l * (k + 1), st)
         flags = B.FHE_A_IS_EVALS
     f = lambda: B._check(L.fhe_glwe_key_switch_dev(plan.handle, k, beta, l, glwe.data_ptr(), key.data_ptr(), out.data_ptr(), batch, flags, st))
+    if prepared:
+        prep = torch.empty(L.fhe_glwe_ksk_prepared_words(plan.handle, k, beta, l), dtype=torch.int64, device=dev)
+        B._check(L.fhe_glwe_ksk_prepare_dev(plan.handle, k, beta, l, ksk.data_ptr(), prep.data_ptr(), st))
+        f = lambda: B._check(L.fhe_glwe_key_switch_prepared_dev(plan.handle, k, beta, l, glwe.data_ptr(), prep.data_ptr(), out.data_ptr(), batch, st))
     dt = timeit(f)
     want = np.empty((k + 1, n), dtype=np.uint64)
     t0 = time.perf_counter()
@@ -80,7 +84,7 @@ def key_switch(n=4096, k=1, beta=2, l=61, batch=256, q=pkg.Q61, resident_key=Fal
     cpu = time.perf_counter() - t0
     ok = np.array_equal(out[0].cpu().numpy().view(np.uint64), want)
     print(f"GLWE key switch  N={n} k={k} beta={beta} l={l} q~2^{q.bit_length()} batch={batch}"
-          f"{' (key resident in NTT domain)' if resident_key else ''}: {dt*1e3:.3f} ms  {batch/dt:,.0f} switches/s   "
+          f"{' (key resident in NTT domain)' if resident_key else ' (prepared key)' if prepared else ''}: {dt*1e3:.3f} ms  {batch/dt:,.0f} switches/s   "
           f"(oracle, NTT products on 1 core: {1/cpu:.1f}/s)  parity={ok}")
 
 
@@ -90,11 +94,16 @@ if __name__ == "__main__":
     extprod()
     extprod(prepared=True)
     key_switch()
+    key_switch(prepared=True)
     key_switch(resident_key=True)
     key_switch(batch=1)
+    key_switch(batch=1, prepared=True)
     key_switch(batch=1, resident_key=True)
     B.kernel_timing_reset(); B.kernel_timing_enable(True)
     extprod(batch=630, prepared=True)
+    print({k: (round(v[0], 3), v[1]) for k, v in B.kernel_timing_read().items()})
+    B.kernel_timing_reset()
+    key_switch(prepared=True)
     print({k: (round(v[0], 3), v[1]) for k, v in B.kernel_timing_read().items()})
     B.kernel_timing_reset()
     key_switch(resident_key=True)

@@ -21,6 +21,9 @@
 //   accumulators that live in registers across all steps and are reduced once per 32 terms
 //   (q < 2^61: 32 products of canonical operands stay below 2^127).
 //
+// Since round 2 the shapes with k = 1 (TGGSW x TGLWE up to n = 1024, key switching up to n = 4096) run the same scheme on
+// two 27-bit primes with 32-bit arithmetic (digit32.hip); this 61-bit form serves the others and FHE_EXT32=0.
+//
 // Output: out[b][p][c][n] — canonical partial sums, one per part; parts exist so that a small batch
 // still fills the chip (630 ciphertexts x 4 parts = 2520 workgroups); the caller adds the parts
 // (sum_parts_kernel below) before the inverse transforms.  HBM traffic per external product at

@@ -13,6 +13,7 @@ if [ "$2" = "collect" ]; then
   cp $OUT/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
   cp $OUT/${TAG}_pmc_traffic.json profiles/
   for c in 2 3 4; do cp $OUT/config$c.json profiles/${TAG}_config$c.json; cp $OUT/config${c}_kernel_stats.csv profiles/${TAG}_config${c}_kernel_stats.csv; done
+  cp $OUT/config4_pmc_traffic.txt profiles/${TAG}_config4_pmc_traffic.txt
   cp $OUT/pytest_gpu.txt profiles/${TAG}_pytest_gpu.txt
   cat $OUT/kbench_16.txt $OUT/kbench_12.txt > profiles/${TAG}_kbench.txt
   cp $OUT/bench_next_rows.txt profiles/${TAG}_bench_next_rows.txt
@@ -55,6 +56,16 @@ o=json.loads([l for l in open('$OUT/config$c.json') if l.startswith('{')][-1])
 print('config $c:', round(o['value'],1), o['unit'], 'ms/step', round(o['ms_per_step'],3), 'hbm frac', round(o['roofline']['frac'],4), 'valu frac', round(o['roofline']['valu']['frac'],3), 'cpu', round(o['cpu_baseline']['value'],1))"
 done
 
+echo "[5b] HBM-side traffic of config 4's kernels (PMC, separate passes)"; date
+C4="bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline --no-parity"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc4_fetch -o runc --output-format csv -- python3 $C4 > $OUT/pmc4_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc4_write -o runc --output-format csv -- python3 $C4 > $OUT/pmc4_write.log 2>&1
+{ echo "# HBM-side traffic per launch of the config-4 kernels (630 TGGSW x TGLWE, N=1024, k=1, l=64; plain entry point)"
+  echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, FETCH_SIZE doubled on gfx950) -- python3 $C4"
+  echo "# algorithmic: ciphertexts in 10.3 MB, key 2.1 MB in / 4.2 MB of transforms (x 8 XCD L2s), partial sums 630 x 4 parts x 32 KiB = 82.6 MB out and in, result 10.3 MB"
+  python3 tools/pmc_kernels.py $OUT/pmc4_fetch $OUT/pmc4_write; } > $OUT/config4_pmc_traffic.txt
+cat $OUT/config4_pmc_traffic.txt
+
 echo "[6/7] two ranks on one GPU (gloo rendezvous): the multi-rank driver"; date
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --share-gpu --backend gloo --batch-per-gpu 2048 --no-cpu-baseline --parity-all-ranks --gather-check > $OUT/bench_2ranks.json 2> $OUT/bench_2ranks.err || tail -5 $OUT/bench_2ranks.err
 tail -1 $OUT/bench_2ranks.json | cut -c1-300
@@ -65,6 +76,6 @@ timeout -k 10 300 python tools/kbench.py 12 262144 0 > $OUT/kbench_12.txt 2>&1
 timeout -k 10 300 python tools/mulbench.py > $OUT/rq_mul_throughput.txt 2>&1
 timeout -k 10 300 python tools/bench_next.py > $OUT/bench_next_rows.txt 2>&1 || true
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt
-rm -rf $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true
+rm -rf $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc4_*/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true
 find $OUT -name "*.db" -delete 2>/dev/null || true
 date

@@ -1,0 +1,35 @@
+// bfv32.hpp — internal interface of the BFV tensor / relinearisation on two 27-bit primes (bfv32.hip).
+// Not part of the public boundary.
+#pragma once
+#include "digit32.hpp"
+
+namespace fhe {
+
+struct Bfv32Args {
+    Ext32Args t;               // per-prime tables of the 2n-point transform: tw_fwd, tw_inv, p, mu, bq, ninv, crt, P
+    uint32_t pinv_neg[3];      // -p^-1 mod 2^32 (Montgomery products of two residues)
+    Tw32 ninv_mont[3];         // (2n)^-1 * 2^32 mod p: the inverse's scaling with the Montgomery factor folded in
+    uint32_t log_n2;
+    // forward: rows of n 64-bit words (zero-padded to 2n) -> fw[prime][row][2n] u32 for the first `primes` primes
+    const u64 *src;
+    uint32_t *fw;
+    u64 rows;
+    uint32_t primes;
+    // tensor: fw rows [a0 | a1 | b0 | b1] x batch -> out [c0 | c1 | c2] x batch x n  (scaled by num/den, rounded, folded)
+    // relinearisation (three primes): x[prime][batch][2n] (transform of c2), key[prime][2][2n] -> out [o0 | o1] x batch x n
+    const uint32_t *x, *key;
+    const u64 *addend;         // relinearisation: [c0 | c1] x batch x n
+    u64 *out;
+    u64 batch, q;
+    u64 qmu;                   // floor(2^64 / q)
+    double numf, denf;
+};
+
+// q, n, pq for which the small-prime form applies: the tensor's integers below pA pB, the relinearisation's (pq != 0)
+// below pA pB pC (pq = 0: tensor only)
+bool bfv32_shape_supported(uint64_t q, uint64_t n, uint64_t pq);
+hipError_t launch_bfv32_forward(const Bfv32Args &a, hipStream_t st);
+hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st);
+hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st);
+
+}  // namespace fhe

@@ -12,6 +12,8 @@ struct Tw32 { uint32_t w, wp; };                     // twiddle and floor(w * 2^
 // the two primes: the largest below 2^32 / 25 with p = 1 mod 2^15 (27.36 and 27.35 bits; product 2^54.7).  Below
 // 2^32 / 25 so that up to twelve lazy butterfly stages need no conditional subtraction (digit32.hip: ct32_loose).
 constexpr uint32_t kExt32PrimeA = 0x0a3c8001u, kExt32PrimeB = 0x0a320001u;
+// the next one down, for the products that need three (bfv32.hip: relinearisation, integers below 2^82)
+constexpr uint32_t kExt32PrimeC = 0x0a318001u;
 static_assert((uint64_t)kExt32PrimeA * 25 < (1ull << 32) && kExt32PrimeA > kExt32PrimeB && kExt32PrimeA - kExt32PrimeB < kExt32PrimeB, "prime bounds");
 
 struct Ext32Args {
@@ -28,13 +30,14 @@ struct Ext32Args {
     u64 batch;
     uint32_t l, T, parts, tpp;
     // per prime
-    const Tw32 *tw_fwd[2], *tw_inv[2];
-    const uint32_t *lut[2];
-    uint32_t p[2];
-    u64 mu[2];                 // floor(2^64 / p)
-    uint32_t bq[2];            // floor(2^32 / p)
-    Tw32 ninv[2];              // n^-1 mod p
+    const Tw32 *tw_fwd[3], *tw_inv[3];
+    const uint32_t *lut[3];
+    uint32_t p[3];             // kExt32PrimeA, B, C (digit32.hip uses the first two)
+    u64 mu[3];                 // floor(2^64 / p)
+    uint32_t bq[3];            // floor(2^32 / p)
+    Tw32 ninv[3];              // n^-1 mod p
     Tw32 crt;                  // pA^-1 mod pB
+    Tw32 crt_ac, crt_bc;       // pA^-1 mod pC, pB^-1 mod pC (Garner's third digit)
     u64 P, halfP;              // pA * pB, ceil(P / 2)
     // key switching tail (digit_tail32_ks_kernel)
     Mod mod;                   // the ring's q

@@ -52,13 +52,6 @@ __device__ __forceinline__ u64 f64_as_u64(double x) {   // Rust `f64 as u64`
     if (x >= 18446744073709551616.0) return ~0ull;
     return (u64)x;
 }
-__device__ __forceinline__ long long f64_as_i64_sat(double x) {
-    if (x != x) return 0;
-    if (x >= 9223372036854775808.0) return 0x7fffffffffffffffll;
-    if (x <= -9223372036854775808.0) return (long long)0x8000000000000000ull;
-    return (long long)x;
-}
-
 // Zq::mod_switch, zq.rs:134-139
 __global__ __launch_bounds__(256) void mod_switch_kernel(const u64 *__restrict__ a, u64 *__restrict__ c,
                                                          u64 count, u64 q, u64 p) {
@@ -76,15 +69,10 @@ __global__ __launch_bounds__(256) void rq_mul_div_round_kernel(const u64 *__rest
     const u64 stride = (u64)gridDim.x * 256;
     const double nf = (double)num, df = (double)den;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
-        const long long e = f64_as_i64_sat(round(round((nf * (double)a[i]) / df)));
+        const long long e = f64_as_i64(round(round((nf * (double)a[i]) / df)));
         const long long qi = (long long)q;
         c[i] = (e < 0 || e >= qi) ? (u64)(((e % qi) + qi) % qi) : (u64)e;
     }
-}
-
-__device__ __forceinline__ u64 zq_from_f64(u64 q, double x) {   // Zq::from_f64, zq.rs:32-39
-    const long long e = f64_as_i64_sat(round(x)), qi = (long long)q;
-    return (e < 0 || e >= qi) ? (u64)(((e % qi) + qi) % qi) : (u64)e;
 }
 
 // Rq::remodule(p) ring_nq.rs:82-88 (Zq::from_u64 per coefficient), Rq::mul_by_f64 :282-292,

@@ -143,6 +143,33 @@ __device__ __forceinline__ u64 canon4(u64 x, const Mod &m) { return canon2(csub_
 // [0,8q) -> [0,q)   (q < 2^61)
 __device__ __forceinline__ u64 canon8(u64 x, const Mod &m) { return canon4(csub_neg(x, m.neg4q), m); }
 
+// Rust `f64 as i64` (saturating, NaN -> 0)
+__device__ __forceinline__ long long f64_as_i64(double x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return 0x7fffffffffffffffll;
+    if (x <= -9223372036854775808.0) return (long long)0x8000000000000000ull;
+    return (long long)x;
+}
+// Zq::from_f64, arith/src/zq.rs:32-39
+__device__ __forceinline__ u64 zq_from_f64(u64 q, double ef) {
+    const long long e = f64_as_i64(round(ef));
+    const long long qi = (long long)q;
+    if (e < 0 || e >= qi) return (u64)(((e % qi) + qi) % qi);
+    return (u64)e;
+}
+
+// The same with the 64-bit remainder by multiplication: mu = floor(2^64 / q) (q >= 2).  e % q by the hardware-less
+// software division costs ~150 instructions per coefficient, more than the transform that produced it.
+__device__ __forceinline__ u64 zq_from_f64_mu(u64 q, u64 mu, double ef) {
+    const long long e = f64_as_i64(round(ef));
+    if (e >= 0 && e < (long long)q) return (u64)e;
+    const u64 m = e < 0 ? 0ull - (u64)e : (u64)e;              // |e| <= 2^63
+    u64 r = m - __umul64hi(m, mu) * q;                         // the quotient estimate is short by at most 2
+    r = r >= q ? r - q : r;
+    r = r >= q ? r - q : r;
+    return (e < 0 && r) ? q - r : r;                           // ((e % q) + q) % q
+}
+
 // x mod q for any 64-bit x (Shoup with w = 1), canonical
 __device__ __forceinline__ u64 reduce_any(u64 x, const Mod &m) {
     const u64 r = x - __umul64hi(x, m.onep) * m.q;  // [0, 2q)

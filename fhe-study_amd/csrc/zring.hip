@@ -23,6 +23,7 @@
 #include "capi_internal.hpp"
 #include "digit_mac.hpp"
 #include "digit32.hpp"
+#include "bfv32.hpp"
 #include "ntt_rounds.hpp"
 #include "zq_device.hpp"
 #include "mac_kernel.hpp"
@@ -177,21 +178,6 @@ __global__ __launch_bounds__(256) void zr_crt_kernel(const u64 *__restrict__ r1,
     const u64 stride = (u64)gridDim.x * 256;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
         out[i] = crt_value<K, SIGNED>(r1[i], K > 1 ? r2[i] : 0ull, K > 2 ? r3[i] : 0ull, cc);
-}
-
-// Rust `f64 as i64` (saturating, NaN -> 0)
-__device__ __forceinline__ long long f64_as_i64(double x) {
-    if (x != x) return 0;
-    if (x >= 9223372036854775808.0) return 0x7fffffffffffffffll;
-    if (x <= -9223372036854775808.0) return (long long)0x8000000000000000ull;
-    return (long long)x;
-}
-// Zq::from_f64, arith/src/zq.rs:32-39
-__device__ __forceinline__ u64 zq_from_f64(u64 q, double ef) {
-    const long long e = f64_as_i64(round(ef));
-    const long long qi = (long long)q;
-    if (e < 0 || e >= qi) return (u64)(((e % qi) + qi) % qi);
-    return (u64)e;
 }
 
 // mul_div_round (ring_n.rs:130-138) + Rq::from_vec_f64 (ring_nq.rs:160-163) + the X^n+1 fold
@@ -545,6 +531,61 @@ extern "C" int fhe_mul_div_round_dev(uint64_t q, uint64_t n, const void *d_v, ui
     return FHE_OK;
 }
 
+// ---- BFV on two / three 27-bit primes (bfv32.hip): small q, 1024 <= n <= 8192 -----------------------------------------
+static bool bfv32_on(uint64_t q, uint64_t n, uint64_t pq) { return fhe_ext32_enabled() && fhe::bfv32_shape_supported(q, n, pq); }
+static int bfv32_args(uint64_t n, fhe::Bfv32Args *a) {
+    int rc = fhe_ext32_tables(2 * n, &a->t);
+    if (rc != FHE_OK) return rc;
+    a->log_n2 = ceil_log2(2 * n);
+    for (int i = 0; i < 3; i++) {
+        const uint32_t p = a->t.p[i];
+        uint32_t inv = p;                                       // Newton: p^-1 mod 2^32 (p odd: 3 correct bits, doubled per step)
+        for (int it = 0; it < 5; it++) inv *= 2u - p * inv;
+        a->pinv_neg[i] = 0u - inv;
+        const u64 w = ((u64)a->t.ninv[i].w << 32) % p;          // (2n)^-1 * 2^32 mod p
+        a->ninv_mont[i] = fhe::Tw32{(uint32_t)w, (uint32_t)((w << 32) / p)};
+    }
+    return FHE_OK;
+}
+static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, void *d_c, size_t batch, hipStream_t st) {
+    fhe::Bfv32Args a{};
+    int rc = bfv32_args(n, &a);
+    if (rc != FHE_OK) return rc;
+    void *wsv = nullptr;
+    // transforms of [a0 | a1 | b0 | b1] x batch modulo two primes: 2 * 4 * batch rows of 2n u32
+    if ((rc = fhe_workspace_get(1, (u64)2 * 4 * batch * 2 * n * 4, st, &wsv)) != FHE_OK) return rc;
+    a.src = (const u64 *)d_ab; a.fw = (uint32_t *)wsv; a.rows = 4 * (u64)batch; a.primes = 2;
+    hipError_t e = fhe::launch_bfv32_forward(a, st);
+    if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
+    a.batch = batch; a.out = (u64 *)d_c; a.q = q; a.qmu = ~0ull / q; a.numf = (double)t; a.denf = (double)q;
+    e = fhe::launch_bfv32_tensor_inverse(a, st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "bfv32_tensor_inverse_kernel");
+}
+// key: [rlk0 | rlk1] x n words -> prep[prime (3)][2][2n] u32 = 6n 64-bit words
+static int bfv32_rlk_prepare(uint64_t n, const u64 *d_rlk, void *prep, hipStream_t st) {
+    fhe::Bfv32Args a{};
+    int rc = bfv32_args(n, &a);
+    if (rc != FHE_OK) return rc;
+    a.src = d_rlk; a.fw = (uint32_t *)prep; a.rows = 2; a.primes = 3;
+    hipError_t e = fhe::launch_bfv32_forward(a, st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "bfv32_forward_kernel");
+}
+static int bfv32_relinearize(uint64_t q, uint64_t n, uint64_t pq, const void *d_prep, const void *d_c, void *d_out, size_t batch,
+                             hipStream_t st) {
+    fhe::Bfv32Args a{};
+    int rc = bfv32_args(n, &a);
+    if (rc != FHE_OK) return rc;
+    void *wsv = nullptr;
+    if ((rc = fhe_workspace_get(1, (u64)3 * batch * 2 * n * 4, st, &wsv)) != FHE_OK) return rc;
+    a.src = (const u64 *)d_c + 2 * (u64)batch * n; a.fw = (uint32_t *)wsv; a.rows = batch; a.primes = 3;
+    hipError_t e = fhe::launch_bfv32_forward(a, st);
+    if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
+    a.x = (const uint32_t *)wsv; a.key = (const uint32_t *)d_prep;
+    a.addend = (const u64 *)d_c; a.out = (u64 *)d_out; a.batch = batch; a.q = q; a.qmu = ~0ull / q; a.numf = 1.0; a.denf = (double)(pq / q);
+    e = fhe::launch_bfv32_relin_inverse(a, st);
+    return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "bfv32_relin_inverse_kernel");
+}
+
 // ---- BFV: RLWE::tensor / relinearize_204 / RLWE::mul ------------------------------------------
 // d_ab: [a0 | a1 | b0 | b1], each batch x n (mod q).  d_c: [c0 | c1 | c2], each batch x n.
 extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, void *d_c, size_t batch,
@@ -555,6 +596,7 @@ extern "C" int fhe_bfv_tensor_dev(uint64_t q, uint64_t n, uint64_t t, const void
     if (batch == 0) return FHE_OK;
     if (!d_ab || !d_c) return fhe_fail(FHE_E_NULL, "fhe_bfv_tensor_dev: NULL buffer");
     REQUIRE_ALIGNED(d_ab); REQUIRE_ALIGNED(d_c);
+    if (bfv32_on(q, n, 0)) return bfv32_tensor(q, n, t, d_ab, d_c, batch, (hipStream_t)hip_stream);
     const u64 n2 = 2 * n;
     ZCtx z;
     // c1 = a0*b1 + a1*b0 < 2 * n * q^2
@@ -605,6 +647,7 @@ static int bfv_relin_ctx(ZCtx *z, unsigned *h, uint64_t q, uint64_t n, uint64_t 
 
 extern "C" size_t fhe_bfv_rlk_prepared_words(uint64_t q, uint64_t n, uint64_t pq) {
     if (n < 2 || (n & (n - 1)) || n > (1ull << 19) || q < 2 || (q >> 63) || pq < q || (pq >> 63)) return 0;
+    if (bfv32_on(q, n, pq)) return (size_t)6 * n;                            // 3 primes x 2 rows of 2n u32
     if (relin_split_bits(q, n, pq)) return (size_t)4 * 2 * n;
     const int K = primes_for_bits(bits_of(q - 1) + bits_of(pq - 1) + ceil_log2(n), false);
     return K >= 1 && K <= 3 ? (size_t)K * 2 * 2 * n : 0;
@@ -633,6 +676,7 @@ extern "C" int fhe_bfv_rlk_prepare_dev(uint64_t q, uint64_t n, uint64_t pq, cons
     if (!d_rlk || !d_prepared) return fhe_fail(FHE_E_NULL, "fhe_bfv_rlk_prepare_dev: NULL buffer");
     REQUIRE_ALIGNED(d_rlk); REQUIRE_ALIGNED(d_prepared);
     hipStream_t st = (hipStream_t)hip_stream;
+    if (bfv32_on(q, n, pq)) return bfv32_rlk_prepare(n, (const u64 *)d_rlk, d_prepared, st);
     void *scratch = nullptr;
     if (h && (rc = fhe_workspace_get(1, 4 * n * 8, st, &scratch)) != FHE_OK) return rc;
     return bfv_rlk_prepare(z, h, n, (const u64 *)d_rlk, (u64 *)d_prepared, (u64 *)scratch, st);
@@ -684,6 +728,7 @@ extern "C" int fhe_bfv_relinearize_prepared_dev(uint64_t q, uint64_t n, uint64_t
     if (batch == 0) return FHE_OK;
     if (!d_prepared || !d_c || !d_out) return fhe_fail(FHE_E_NULL, "fhe_bfv_relinearize_prepared_dev: NULL buffer");
     REQUIRE_ALIGNED(d_prepared); REQUIRE_ALIGNED(d_c); REQUIRE_ALIGNED(d_out);
+    if (bfv32_on(q, n, pq)) return bfv32_relinearize(q, n, pq, d_prepared, d_c, d_out, batch, (hipStream_t)hip_stream);
     return bfv_relinearize_with(z, h, q, n, pq, (const u64 *)d_prepared, d_c, d_out, batch, (hipStream_t)hip_stream);
 }
 
@@ -705,6 +750,10 @@ extern "C" int fhe_bfv_relinearize_dev(uint64_t q, uint64_t n, uint64_t pq, cons
     void *w0 = nullptr;
     if ((rc = fhe_workspace_get(0, (tensor_words + 16 * n) * 8, st, &w0)) != FHE_OK) return rc;
     u64 *prep = (u64 *)w0 + tensor_words;
+    if (bfv32_on(q, n, pq)) {                                  // 6n words of prepared key
+        if ((rc = bfv32_rlk_prepare(n, (const u64 *)d_rlk, prep, st)) != FHE_OK) return rc;
+        return bfv32_relinearize(q, n, pq, prep, d_c, d_out, batch, st);
+    }
     if ((rc = bfv_rlk_prepare(z, h, n, (const u64 *)d_rlk, prep, prep + 12 * n, st)) != FHE_OK) return rc;
     return bfv_relinearize_with(z, h, q, n, pq, prep, d_c, d_out, batch, st);
 }
@@ -764,9 +813,9 @@ extern "C" int fhe_tn_mul_dev(uint64_t n, const void *d_a, const void *d_b, void
 // ---- the two-small-prime (27-bit) form of the external product (digit32.hip): per (n, device) tables ---------------------------
 namespace {
 struct Ext32Tables {
-    fhe::Tw32 *fwd[2] = {nullptr, nullptr}, *inv[2] = {nullptr, nullptr};
-    uint32_t *lut[2] = {nullptr, nullptr};
-    fhe::Tw32 ninv[2]{};
+    fhe::Tw32 *fwd[3] = {nullptr, nullptr, nullptr}, *inv[3] = {nullptr, nullptr, nullptr};
+    uint32_t *lut[3] = {nullptr, nullptr, nullptr};
+    fhe::Tw32 ninv[3]{};
 };
 std::mutex g_e32_lock;
 std::map<std::pair<u64, int>, Ext32Tables> g_e32;
@@ -776,7 +825,7 @@ inline fhe::Tw32 tw32(u64 w, u64 p) { return fhe::Tw32{(uint32_t)w, (uint32_t)((
 void fhe_ext32_free_all() {
     std::lock_guard<std::mutex> lk(g_e32_lock);
     for (auto &kv : g_e32)
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < 3; i++) {
             if (kv.second.fwd[i]) (void)hipFree(kv.second.fwd[i]);
             if (kv.second.inv[i]) (void)hipFree(kv.second.inv[i]);
             if (kv.second.lut[i]) (void)hipFree(kv.second.lut[i]);
@@ -790,11 +839,11 @@ int fhe_ext32_tables(uint64_t n, fhe::Ext32Args *a) {
     int dev = 0;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
-    const u64 primes[2] = {fhe::kExt32PrimeA, fhe::kExt32PrimeB};
+    const u64 primes[3] = {fhe::kExt32PrimeA, fhe::kExt32PrimeB, fhe::kExt32PrimeC};
     std::lock_guard<std::mutex> lk(g_e32_lock);
     Ext32Tables &t = g_e32[std::make_pair(n, dev)];
     if (!t.fwd[0]) {
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < 3; i++) {
             const u64 p = primes[i];
             const fhe_ntt_plan *plan = nullptr;
             if ((rc = fhe_ntt_plan_get(p, n, &plan)) != FHE_OK) return rc;
@@ -844,7 +893,7 @@ int fhe_ext32_tables(uint64_t n, fhe::Ext32Args *a) {
         }
     }
     const u64 pA = primes[0], pB = primes[1];
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         a->tw_fwd[i] = t.fwd[i]; a->tw_inv[i] = t.inv[i]; a->lut[i] = t.lut[i];
         a->p[i] = (uint32_t)primes[i];
         a->mu[i] = ~0ull / primes[i];                 // floor(2^64 / p): p does not divide 2^64
@@ -852,6 +901,9 @@ int fhe_ext32_tables(uint64_t n, fhe::Ext32Args *a) {
         a->ninv[i] = t.ninv[i];
     }
     a->crt = tw32(hpow(pA % pB, pB - 2, pB), pB);     // pA^-1 mod pB
+    const u64 pC = primes[2];
+    a->crt_ac = tw32(hpow(pA % pC, pC - 2, pC), pC);
+    a->crt_bc = tw32(hpow(pB % pC, pC - 2, pC), pC);
     a->P = pA * pB;
     a->halfP = (a->P + 1) / 2;
     return FHE_OK;

@@ -494,7 +494,7 @@ def test_bfv_multiply_with_a_resident_relinearisation_key(pkg, oracle, q, n, p, 
     dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
     dab, drlk = dev(ab), dev(rlk)
     words = L.fhe_bfv_rlk_prepared_words(q, n, pq)
-    assert words in (4 * n, 8 * n, 12 * n)
+    assert words in (4 * n, 6 * n, 8 * n, 12 * n)       # opaque: 61-bit CRT primes (one, split key, or several) or three 27-bit primes
     prep = torch.empty(words, dtype=torch.int64, device="cuda")
     B._check(L.fhe_bfv_rlk_prepare_dev(q, n, pq, drlk.data_ptr(), prep.data_ptr(), None))
     plain = torch.empty((2, batch, n), dtype=torch.int64, device="cuda")

@@ -20,6 +20,8 @@
 #include "bfv32.hpp"
 #include "ntt32_rounds.hpp"
 
+#include <type_traits>
+
 namespace fhe {
 
 // rounds of a 2^LP-point transform held by ONE workgroup (the index algebra of ContigCfg with W = 1): 2^LP / 16 logical
@@ -285,8 +287,8 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_relin_inverse_kernel(Bf
     // v2 = ((rC - v0) pA^-1 - v1) pB^-1 mod pC; only x mod 2^64 is kept
     u32 v0[C::VT][16], v1[C::VT][16];
     u64 R[C::VT][16];
-#pragma unroll
-    for (int pr = 0; pr < 3; pr++) {
+    auto prime = [&](auto prc) __attribute__((always_inline)) {     // a lambda per prime: the loop form is not unrolled by the compiler
+        constexpr int pr = decltype(prc)::value;
         const u32 p = a.t.p[pr], p2 = 2u * p, pn = a.pinv_neg[pr];
         u32 v[C::VT][16];
 #pragma unroll
@@ -305,9 +307,9 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_relin_inverse_kernel(Bf
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const u32 r = csub_u32(mul_shoup32(v[s][k], ni, p), p);
-                if (pr == 0) {
+                if constexpr (pr == 0) {
                     v0[s][k] = r;
-                } else if (pr == 1) {
+                } else if constexpr (pr == 1) {
                     const u32 d = csub_u32(r - csub_u32(v0[s][k], p) + p, p);              // pA - pB < pB: one subtraction reduces v0
                     v1[s][k] = csub_u32(mul_shoup32(d, a.t.crt, p), p);
                 } else {
@@ -319,7 +321,10 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_relin_inverse_kernel(Bf
                     R[s][k] = (u64)v0[s][k] + (u64)a.t.p[0] * v1[s][k] + a.t.P * v2;        // mod 2^64; P = pA pB < 2^55
                 }
             }
-    }
+    };
+    prime(std::integral_constant<int, 0>{});
+    prime(std::integral_constant<int, 1>{});
+    prime(std::integral_constant<int, 2>{});
     const u64 off = ((u64)o * a.batch + b) * n + tf;
 #pragma unroll
     for (int s = 0; s < C::VT; s++)

@@ -162,8 +162,7 @@ __device__ __forceinline__ u64 zq_from_f64(u64 q, double ef) {
 // software division costs ~150 instructions per coefficient, more than the transform that produced it.
 __device__ __forceinline__ u64 zq_from_f64_mu(u64 q, u64 mu, double ef) {
     const long long e = f64_as_i64(round(ef));
-    if (e >= 0 && e < (long long)q) return (u64)e;
-    const u64 m = e < 0 ? 0ull - (u64)e : (u64)e;              // |e| <= 2^63
+    const u64 m = e < 0 ? 0ull - (u64)e : (u64)e;              // |e| <= 2^63; no early exit for 0 <= e < q: straight-line code
     u64 r = m - __umul64hi(m, mu) * q;                         // the quotient estimate is short by at most 2
     r = r >= q ? r - q : r;
     r = r >= q ? r - q : r;

@@ -212,8 +212,13 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_tensor_inverse_kernel(B
     Tw32 *ltw[3];
     const u32 tf = threadIdx.x;
     stage_all<LP>(ltw, smem_raw + C::TILE_BYTES, a.t.tw_inv, tf);
-    const u64 b = blockIdx.x / 3;
-    const u32 which = blockIdx.x % 3;
+    // the three workgroups of a pair read the same four transforms: workgroup ids are dealt round-robin over the 8 XCDs,
+    // so ids 24 g + 8 which + (b % 8) put them on ONE XCD (one L2), a few dispatches apart
+    const u64 g8 = blockIdx.x / 24;
+    const u32 r24 = blockIdx.x % 24;
+    const u64 b = g8 * 8 + (r24 & 7u);
+    const u32 which = r24 >> 3;
+    if (b >= a.batch) return;                                   // padding of the last group (before any barrier)
     const u32 n = C::M / 2;
     __syncthreads();
     u32 resA[C::VT][16];
@@ -242,7 +247,9 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_tensor_inverse_kernel(B
                 for (int k = 0; k < 16; k++) v[s][k] = mont32(v[s][k], y[k], p, pn);
             }
         }
+#ifndef FHE_B32_ABLATE_INV      // timing-only builds (tools/abl_build.sh): the kernels without their transforms / their f64 epilogues
         inv_big<LP>(v, lds, ltw[pr], a.t.tw_inv[pr], tf, p, p2);
+#endif
         const Tw32 ni = a.ninv_mont[pr];
         if (pr == 0) {
 #pragma unroll
@@ -260,8 +267,12 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_tensor_inverse_kernel(B
                     const u32 rl = csub_u32(mul_shoup32(v[s][k], ni, p), p), rh = csub_u32(mul_shoup32(v[s][k + 8], ni, p), p);
                     const long long lo = (long long)crt2(resA[s][k], rl, a.t.p[0], a.t.p[1], a.t.crt);
                     const long long hi = (long long)crt2(resA[s][k + 8], rh, a.t.p[0], a.t.p[1], a.t.crt);
+#ifndef FHE_B32_ABLATE_EPI
                     const u64 zl = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)lo) / a.denf));
                     const u64 zh = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)hi) / a.denf));    // slot 2n-1 of a (2n-1)-term convolution is 0
+#else
+                    const u64 zl = (u64)lo, zh = (u64)hi;
+#endif
                     po[(u32)k * (C::VT * C::TH) + s * C::TH] = zl >= zh ? zl - zh : (a.q + zl) - zh;   // Zq::sub, zq.rs:259-276
                 }
         }
@@ -279,8 +290,12 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_relin_inverse_kernel(Bf
     Tw32 *ltw[3];
     const u32 tf = threadIdx.x;
     stage_all<LP>(ltw, smem_raw + C::TILE_BYTES, a.t.tw_inv, tf);
-    const u64 b = blockIdx.x >> 1;
-    const u32 o = blockIdx.x & 1u;
+    // both output polynomials of a ciphertext read the same transform of c2: ids 16 g + 8 o + (b % 8) share an XCD
+    const u64 g8 = blockIdx.x / 16;
+    const u32 r16 = blockIdx.x % 16;
+    const u64 b = g8 * 8 + (r16 & 7u);
+    const u32 o = r16 >> 3;
+    if (b >= a.batch) return;
     const u32 n = C::M / 2;
     __syncthreads();
     // Garner's digits: x = v0 + pA v1 + pA pB v2 with v0 = rA, v1 = (rB - v0) pA^-1 mod pB,
@@ -300,7 +315,9 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_relin_inverse_kernel(Bf
 #pragma unroll
             for (int k = 0; k < 16; k++) v[s][k] = mont32(v[s][k], y[k], p, pn);
         }
+#ifndef FHE_B32_ABLATE_INV      // timing-only builds (tools/abl_build.sh): the kernels without their transforms / their f64 epilogues
         inv_big<LP>(v, lds, ltw[pr], a.t.tw_inv[pr], tf, p, p2);
+#endif
         const Tw32 ni = a.ninv_mont[pr];
 #pragma unroll
         for (int s = 0; s < C::VT; s++)
@@ -331,8 +348,12 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_relin_inverse_kernel(Bf
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const long long lo = (long long)R[s][k], hi = (long long)R[s][k + 8];
+#ifndef FHE_B32_ABLATE_EPI
             const u64 zl = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)lo) / a.denf));
             const u64 zh = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)hi) / a.denf));
+#else
+            const u64 zl = (u64)lo, zh = (u64)hi;
+#endif
             u64 v = zl >= zh ? zl - zh : (a.q + zl) - zh;      // Zq::sub, zq.rs:259-276
             const u64 at = off + (u32)k * (C::VT * C::TH) + s * C::TH;
             v += a.addend[at];
@@ -377,8 +398,8 @@ hipError_t launch_bfv32_forward(const Bfv32Args &a, hipStream_t st) {
     if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", a.rows) }
     return hipErrorNotSupported;
 }
-hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_tensor_inverse_kernel, "bfv32_tensor_inverse", 3 * a.batch) }
-hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_relin_inverse_kernel, "bfv32_relin_inverse", 2 * a.batch) }
+hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_tensor_inverse_kernel, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8)) }
+hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_relin_inverse_kernel, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8)) }
 #undef FHE_BIG_SWITCH
 
 }  // namespace fhe

@@ -42,6 +42,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Chip-wide ceiling of the 64-bit Shoup/Harvey butterfly in registers, no memory at all:
 # tools/ubench_bfly.hip v8 (the production form) at 8 waves per SIMD, profiles/r01_ubench_bfly.txt.
 VALU_PEAK_GBFLY = 2018.7
+# the 32-bit butterfly of the small-prime kernels (digit32.hip / bfv32.hip): tools/ubench_bfly.hip v13, registers only
+VALU_PEAK_GBFLY32 = 5730.0
 # HBM traffic per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
 # WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Counters cannot be read from inside this process.
@@ -224,14 +226,15 @@ def workload_bfv(args, pkg, torch, dev, st, rank, world):
                 "value_1core": one}
 
     log2n = (2 * n).bit_length() - 1
-    # tensor: 1 prime x (4 forward + 3 inverse) size-2N transforms; relinearise: 2 primes x (1 forward + 2 inverse)
-    # (the key's two forward transforms per prime are per call, not per ciphertext)
-    transforms = 7 + 2 * 3
+    # bfv32.hip (small q): tensor 2 primes x (4 forward + 3 inverse) size-2N transforms, relinearisation 3 primes x
+    # (1 forward + 2 inverse), all 32-bit butterflies (the key's forward transforms are per call, not per ciphertext)
+    transforms = 2 * 7 + 3 * 3
     return {
         "metric": "BFV ct x ct multiply + relinearise per second (N=8192, q=65537, t=2, p=q^2) per node",
         "unit": "ct-mul/s", "units_per_step": batch, "step": step, "parity": parity, "cpu": cpu,
         "alg_bytes_per_unit": (4 + 2) * 8 * n,      # two ciphertexts in, one out; the key is shared by the batch
         "bfly_per_unit": transforms * n * log2n,    # (2N/2) * log2(2N) per size-2N transform
+        "bfly_bits": 32,
         "pass_bytes_per_launch_per_unit": None,
         "config": {"workload": f"RLWE::mul (tensor + relinearize_204), N={n}, q={q}, t={t}, p=q^2, {batch} ciphertext pairs "
                                "per GPU (BASELINE.json configs[2]), device-resident",
@@ -277,12 +280,14 @@ def workload_extprod(args, pkg, torch, dev, st, rank, world):
                 "value_1core": one}
 
     log2n = n.bit_length() - 1
-    transforms = (k + 1) * l + 2 * (k + 1)     # digit transforms + the inverses of the two 32-bit key halves
+    # digit32.hip: every transform modulo two 27-bit primes (32-bit butterflies)
+    transforms = 2 * ((k + 1) * l + 2 * (k + 1))     # digit transforms + the inverses of the two 32-bit key halves
     return {
         "metric": "TGGSW x TGLWE external products per second (N=1024, k=1, l=64) per node",
         "unit": "products/s", "units_per_step": batch, "step": step, "parity": parity, "cpu": cpu,
         "alg_bytes_per_unit": 2 * (k + 1) * 8 * n,    # ciphertext in + out; the TGGSW key is shared by the batch
         "bfly_per_unit": transforms * (n // 2) * log2n,
+        "bfly_bits": 32,
         "pass_bytes_per_launch_per_unit": None,
         "config": {"workload": f"TGGSW x TGLWE external product, N={n}, k={k}, l={l}, {total} products block-sharded over "
                                f"{world} GPU(s) by fhe_shard_range (BASELINE.json configs[3]), device-resident",
@@ -376,6 +381,8 @@ def main():
                    for k, (ms, cnt) in timing.items() if cnt}
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
         step_achieved = per_gpu * W["alg_bytes_per_unit"] / 1e9      # the whole step, algorithmic GB/s per GPU
+        small = W.get("bfly_bits", 64) == 32
+        valu_peak = VALU_PEAK_GBFLY32 if small else VALU_PEAK_GBFLY
         roofline = {
             "bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": step_achieved / HBM_PEAK_GBS, "traffic": None,
@@ -386,10 +393,12 @@ def main():
             "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS,
             "dominant_kernel": dom, "kernels": kernels,
             "valu": {"bound": "integer butterflies (no MFMA on this path)", "achieved": per_gpu * W["bfly_per_unit"] / 1e9,
-                     "peak": VALU_PEAK_GBFLY, "unit": "Gbutterfly/s",
-                     "frac": per_gpu * W["bfly_per_unit"] / 1e9 / VALU_PEAK_GBFLY,
+                     "peak": valu_peak, "unit": "Gbutterfly/s",
+                     "frac": per_gpu * W["bfly_per_unit"] / 1e9 / valu_peak,
                      "butterflies_per_unit": W["bfly_per_unit"],
-                     "peak_source": "tools/ubench_bfly.hip v8 (production butterfly, registers only), profiles/r01_ubench_bfly.txt"},
+                     "butterfly": "32-bit words modulo 27-bit primes (6 instructions)" if small else "64-bit words modulo q < 2^61 (Shoup, 10 multiplies)",
+                     "peak_source": ("tools/ubench_bfly.hip v13 (registers only), profiles/r02_ubench_bfly.txt" if small else
+                                     "tools/ubench_bfly.hip v8 (production butterfly, registers only), profiles/r01_ubench_bfly.txt")},
         }
         if dom and W["pass_bytes_per_launch_per_unit"]:
             # The transform configurations: `achieved` / `frac` / `traffic` describe the DOMINANT KERNEL, one launch of it

@@ -308,6 +308,32 @@ __global__ void k12(u64* p, Q c, T12 t, int iters) {
   for (int j = 0; j < 4; j++) { p[threadIdx.x + 64 * j] = x[j]; p[threadIdx.x + 64 * j + 256] = y[j]; }
 }
 
+// v13: the 32-bit butterfly of digit32.hip / bfv32.hip modulo a 27-bit prime p < 2^32 / 25: negated lazy Shoup product,
+// x - nv, x + nv + 2p (v_add3_u32) — six instructions, no conditional subtraction; the values grow by 2p per butterfly,
+// so every 8 butterflies both are brought below 2p (x - mulhi(x, floor(2^32 / p)) * p: three instructions each), as the
+// kernels do between rounds.  Counted per butterfly including that share (6 + 6/8 instructions).
+__global__ void k13(u32* p, u32 pr, u32 bq, u32 w, u32 wp, int iters) {
+  u32 x[8], y[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { x[j] = p[threadIdx.x + 64 * j] % pr; y[j] = p[threadIdx.x + 64 * j + 512] % pr; }
+  const u32 p2 = 2u * pr;
+  for (int i = 0; i < iters; i += 8) {
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const u32 nv = __umulhi(y[j], wp) * pr - y[j] * w;
+        const u32 u = x[j];
+        x[j] = u - nv;
+        y[j] = u + nv + p2;
+      }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x[j] -= __umulhi(x[j], bq) * pr; y[j] -= __umulhi(y[j], bq) * pr; }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) { p[threadIdx.x + 64 * j] = x[j]; p[threadIdx.x + 64 * j + 512] = y[j]; }
+}
+
 static u64 href(u64 x, u64 y, u64 w, u64 q, int iters, u64* yo) {  // canonical reference
   for (int i = 0; i < iters; i++) {
     u64 t = (u64)(((u128)y * w) % q);
@@ -395,6 +421,36 @@ int main() {
       double bf = (double)blocks * threads * 4 * iters;
       printf("   wpS=%d %8.3f ms  %8.1f Gbfly/s  %6.1f cyc/bfly-wave/SIMD(nominal clk)\n", wpS, best, bf / best * 1e-6,
              best * 1e-3 * clk / ((double)iters * 4 * wpS));
+    }
+  }
+  {  // v13
+    const u32 pr = 0x0a3c8001u, w32 = 123456789u % pr, wp32 = (u32)(((u64)w32 << 32) / pr), bq = 0xffffffffu / pr;
+    u32* p32 = (u32*)p;
+    std::vector<u32> h32(1024), o32(1024);
+    for (int i = 0; i < 1024; i++) h32[i] = (u32)((0x9E3779B97F4A7C15ull * (i + 1)) >> 20);
+    hipMemcpy(p32, h32.data(), 1024 * 4, hipMemcpyHostToDevice);
+    int it = 16;
+    k13<<<1, 64>>>(p32, pr, bq, w32, wp32, it);
+    hipMemcpy(o32.data(), p32, 1024 * 4, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int tt = 0; tt < 64; tt++) for (int j = 0; j < 8; j++) {
+      u64 yo, xo = href(h32[tt + 64 * j] % pr, h32[tt + 64 * j + 512] % pr, w32, pr, it, &yo);
+      if (o32[tt + 64 * j] % pr != xo || o32[tt + 64 * j + 512] % pr != yo) bad++;
+    }
+    printf("%-20s correctness: %s\n", "v13 32-bit, 27-bit p", bad ? "FAIL" : "ok");
+    for (int wpS : {2, 4, 8}) {
+      int blocks = cus * wpS, threads = 256, iters = 4000;
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      float best = 1e30f;
+      for (int r = 0; r < 4; r++) {
+        hipEventRecord(e0);
+        k13<<<blocks, threads>>>(p32, pr, bq, w32, wp32, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
+      }
+      double bf = (double)blocks * threads * 8 * iters;
+      printf("   wpS=%d %8.3f ms  %8.1f Gbfly/s  %6.1f cyc/bfly-wave/SIMD(nominal clk)\n", wpS, best, bf / best * 1e-6,
+             best * 1e-3 * clk / ((double)iters * 8 * wpS));
     }
   }
   return 0;

@@ -197,8 +197,9 @@ int fhe_bfv_mul(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const uint64_t 
 int fhe_bfv_mul_dev(uint64_t q, uint64_t n, uint64_t t, uint64_t pq, const void *d_rlk, const void *d_ab,
                     void *d_out, size_t batch, void *hip_stream);
 /* Resident relinearisation key (RLWE::mul is called with the same `rlk` for every product of a computation,
- * bfv/src/lib.rs:87-90; relinearize_204 :251-271): rlk in the form the products consume — split in two halves and
- * transformed modulo one prime where the half-products fit, reduced and transformed per CRT prime otherwise — built
+ * bfv/src/lib.rs:87-90; relinearize_204 :251-271): rlk in the form the products consume — its transforms modulo three
+ * 27-bit primes where the products stay below 2^82 (q = 65537, p = q^2, n <= 8192), else split in two halves and
+ * transformed modulo one 61-bit prime where the half-products fit, reduced and transformed per CRT prime otherwise — built
  * once per key (fhe_bfv_rlk_prepared_words words; 0 = invalid parameters; the layout is opaque) and reused by every
  * later call; same words as the plain entry points produce. */
 size_t fhe_bfv_rlk_prepared_words(uint64_t q, uint64_t n, uint64_t pq);

@@ -409,12 +409,58 @@ def test_fused_and_unfused_digit_paths_agree_at_bench_sizes(pkg):
         "B._check(L.fhe_glwe_key_switch_dev(plan.handle, k, 2, l, glwe.data_ptr(), ksk.data_ptr(), o.data_ptr(), batch, 0, None))\n"
         "print('ks', hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())\n" % ROOT)
     outs = []
+    # FHE_EXT32=0: both forms of the 61-bit kernels (with it on, these shapes take the small-prime kernels: next test)
     for fused in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FHE_DIGIT_MAC_FUSED=fused),
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FHE_DIGIT_MAC_FUSED=fused, FHE_EXT32="0"),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("ext", "ks"))])
     assert len(outs[0]) == 2 and outs[0] == outs[1]
+
+
+def test_small_prime_and_61_bit_kernels_agree_at_bench_sizes(pkg):
+    """FHE_EXT32=0 keeps the 61-bit kernels for the external product, key switching and BFV; the default takes the
+    27-bit-prime kernels (digit32.hip, bfv32.hip) where the shape allows.  Both must produce identical words: 630 external
+    products (N=1024), 256 key switches (N=4096) with the plain and the prepared key, 64 BFV products at N=8192 and 4096."""
+    code = (
+        "import sys, hashlib, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import fhe_study_amd as pkg\n"
+        "L, B = pkg.load_library(), pkg.binding\n"
+        "rng = np.random.default_rng(11)\n"
+        "H = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()\n"
+        "n, k, l, batch = 1024, 1, 64, 630\n"
+        "g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).cuda()\n"
+        "c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (batch, k + 1, n), dtype=np.int64)).cuda()\n"
+        "o = torch.empty_like(c)\n"
+        "B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), o.data_ptr(), batch, None))\n"
+        "print('ext', H(o))\n"
+        "q, n, k, l, batch = pkg.Q61, 4096, 1, 61, 256\n"
+        "plan = pkg.Plan(q, n)\n"
+        "glwe = torch.from_numpy(rng.integers(0, q, (batch, k + 1, n), dtype=np.int64)).cuda()\n"
+        "ksk = torch.from_numpy(rng.integers(0, q, (k, l, k + 1, n), dtype=np.int64)).cuda()\n"
+        "o = torch.empty_like(glwe)\n"
+        "B._check(L.fhe_glwe_key_switch_dev(plan.handle, k, 2, l, glwe.data_ptr(), ksk.data_ptr(), o.data_ptr(), batch, 0, None))\n"
+        "print('ks', H(o))\n"
+        "prep = torch.empty(L.fhe_glwe_ksk_prepared_words(plan.handle, k, 2, l), dtype=torch.int64, device='cuda')\n"
+        "B._check(L.fhe_glwe_ksk_prepare_dev(plan.handle, k, 2, l, ksk.data_ptr(), prep.data_ptr(), None))\n"
+        "o.zero_()\n"
+        "B._check(L.fhe_glwe_key_switch_prepared_dev(plan.handle, k, 2, l, glwe.data_ptr(), prep.data_ptr(), o.data_ptr(), batch, None))\n"
+        "print('ksp', H(o))\n"
+        "for n in (8192, 4096):\n"
+        "    q, t, batch = 65537, 2, 64\n"
+        "    pq = q * q * q\n"
+        "    ab = torch.from_numpy(rng.integers(0, q, (4, batch, n), dtype=np.int64)).cuda()\n"
+        "    rlk = torch.from_numpy(rng.integers(0, pq, (2, n), dtype=np.int64)).cuda()\n"
+        "    o = torch.empty((2, batch, n), dtype=torch.int64, device='cuda')\n"
+        "    B._check(L.fhe_bfv_mul_dev(q, n, t, pq, rlk.data_ptr(), ab.data_ptr(), o.data_ptr(), batch, None))\n"
+        "    print('bfv', n, H(o))\n" % ROOT)
+    outs = []
+    for on in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FHE_EXT32=on), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("ext", "ks", "bfv"))])
+    assert len(outs[0]) == 5 and outs[0] == outs[1]
+    assert outs[0][1].split()[1] == outs[0][2].split()[1]            # plain and prepared key: the same words
 
 
 def test_two_devices_from_two_host_threads(pkg, oracle):

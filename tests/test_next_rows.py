@@ -254,6 +254,9 @@ def test_gpu_mul_div_round(pkg, oracle):
     (Q16, 8192, Q16 * Q16, 2, 2),         # BASELINE.json configs[2]: N = 8192
     (Q61, 64, 2, 16, 3),                  # 61-bit q: three CRT primes, i64 wrap everywhere
     (12289, 1024, 12289, 3, 2),
+    (Q16, 2048, Q16 * Q16, 2, 3),         # 2n = 4096: 256-thread workgroups of the small-prime kernels (bfv32.hip)
+    (786433, 4096, 786433 ** 2, 5, 2),    # 20-bit q: the tensor fits two 27-bit primes, the relinearisation (20 + 59 + 12 bits) does
+                                          # not fit three — small-prime tensor feeding the 61-bit relinearisation
 ])
 def test_gpu_bfv_tensor_and_mul(pkg, oracle, q, n, p, t, batch):
     rng = np.random.default_rng(q % 1000 + n)

@@ -13,12 +13,13 @@
 // ring_torus.rs:67-77, torus.rs:43-52) with the key words split in 32-bit halves exactly as in zring.hip's one-prime
 // form:  out[c] = lift(S_lo[c]) + (lift(S_hi[c]) << 32)  mod 2^64,  lift = the centred CRT lift from the two residues.
 //
-// Kernels (all single-pass sizes 2^8 <= n <= 2^10 with k = 1, the shape of BASELINE.json configs[3]; anything else keeps
+// Kernels (single-pass sizes 2^8 <= n <= 2^12 with k = 1 — BASELINE.json configs[3] is n = 2^10; anything else keeps
 // the 61-bit path of zring.hip / digit_mac.hip):
 //   ntt32_fwd_key_kernel   key preparation: halves reduced mod p, forward transform, stored as u32
 //   digit_mac32_kernel     digit extraction -> forward transform modulo BOTH primes (round 0 by table look-up, as in
 //                          ntt_rounds.hpp round0_bits) -> multiply-accumulate against the key rows, per (ciphertext, part)
-//   digit_tail32_kernel    sum of the parts -> inverse transforms modulo both primes -> CRT lift -> lo + (hi << 32)
+//   digit_tail32_kernel    sum of the parts -> inverse transforms modulo both primes -> CRT lift -> lo + (hi << 32), or
+//                          modulo q and (0, b) - rhs (key switching)
 // Index algebra, register windows and LDS exchanges are those of ntt_rounds.hpp (ContigCfg, field_of, pad16).
 #include "digit32.hpp"
 #include "ntt32_rounds.hpp"
@@ -331,90 +332,15 @@ __global__ __launch_bounds__((Mac32Cfg<LP>::TH), (512 / Mac32Cfg<LP>::TH)) void 
     }
 }
 
-// ---- sum of parts -> inverse transforms (both primes) -> CRT lift -> lo + (hi << 32) ----------------------------------
-// One workgroup = W rows = W / NC ciphertexts; unit w = row (ciphertext, c); every thread runs BOTH primes for its 16
-// coefficients, lifts them and leaves the centred 64-bit integer in the (u64) tile, where the two halves of an output meet.
-template <int LP, int NC>
-__global__ __launch_bounds__(256) void digit_tail32_kernel(Ext32Args a) {
-    using C = ContigCfg<LP>;
-    using K = Cfg32<LP>;
-    static_assert(C::W % NC == 0, "whole ciphertexts per workgroup");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // LDS: a u64 tile for the lifted integers, overlaid at first by the two u32 exchange tiles, then the twiddle tiles
-    u64 *tile64 = reinterpret_cast<u64 *>(smem_raw);
-    constexpr size_t T64_BYTES = (size_t)(C::W * C::M + C::W * C::M / 16) * 8;
-    u32 *tile[2] = {reinterpret_cast<u32 *>(smem_raw), reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES)};
-    Tw32 *ltw[2] = {reinterpret_cast<Tw32 *>(smem_raw + T64_BYTES), reinterpret_cast<Tw32 *>(smem_raw + T64_BYTES + K::TW_BYTES)};
-    static_assert(2 * Cfg32<LP>::TILE_BYTES <= T64_BYTES, "the two u32 tiles fit under the u64 tile");
-    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
-    const u32 n = 1u << LP;
-    const u64 rows = a.batch * NC;
-    const u64 R0 = (u64)blockIdx.x * C::W;
-    const u32 live = (u32)min((u64)C::W, rows - R0);
-    const u64 R = R0 + (w < live ? w : 0u);
-    const u64 b = R / NC;
-    const u32 c = (u32)(R - b * NC);
-#pragma unroll
-    for (int pr = 0; pr < 2; pr++) stage_tw32(ltw[pr], a.tw_inv[pr], C::LTW_N, tid);
-    __syncthreads();
-    u32 res[2][16];
-#pragma unroll
-    for (int pr = 0; pr < 2; pr++) {
-        const u32 p = a.p[pr], p2 = 2u * p;
-        u32 v[16];
-        {
-            const u32 *__restrict__ src = a.part32 + (((b * a.parts) * 2 + pr) * NC + c) * (u64)n + tf * 16u;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(src + 4 * j);
-                v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
-            }
-            for (u32 q = 1; q < a.parts; q++) {
-                const u32 *__restrict__ sp = src + (u64)q * 2 * NC * n;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint4 x = *reinterpret_cast<const uint4 *>(sp + 4 * j);
-                    v[4 * j] = csub_u32(v[4 * j] + x.x, p); v[4 * j + 1] = csub_u32(v[4 * j + 1] + x.y, p);
-                    v[4 * j + 2] = csub_u32(v[4 * j + 2] + x.z, p); v[4 * j + 3] = csub_u32(v[4 * j + 3] + x.w, p);
-                }
-            }
-        }
-        if (pr == 0) inv_rounds32<LP, true>(v, tile[pr], ltw[pr], a.tw_inv[pr], w, tf, p, p2);
-        else inv_rounds32<LP, true>(v, tile[pr], ltw[pr], a.tw_inv[pr], w, tf, p, p2);
-        const Tw32 ni = a.ninv[pr];
-#pragma unroll
-        for (int k = 0; k < 16; k++) res[pr][k] = csub_u32(mul_shoup32(v[k], ni, p), p);      // * n^-1, canonical
-    }
-    // CRT: S = rA + pA * ((rB - rA) * pA^-1 mod pB), centred into (-P/2, P/2]; then the halves meet in the u64 tile
-    const u32 pA = a.p[0], pB = a.p[1];
-    __syncthreads();                                               // the u32 tiles were gathered from by every thread
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 rA = res[0][k], rB = res[1][k];
-        const u32 rAb = csub_u32(rA, pB);                           // rA mod pB (pA - pB < pB)
-        const u32 diff = csub_u32(rB - rAb + pB, pB);
-        const u32 h = csub_u32(mul_shoup32(diff, a.crt, pB), pB);
-        u64 S = (u64)rA + (u64)pA * h;                              // in [0, pA * pB)
-        if (S >= a.halfP) S -= a.P;                                 // two's complement of the centred value
-        tile64[pad16(w * C::M + field_of<C::A0>(tf, k))] = S;
-    }
-    __syncthreads();
-    constexpr int K1 = NC / 2;
-    const u32 cts = live / NC;
-    const u64 b0 = R0 / NC;
-    for (u32 e = tid; e < cts * K1 * n; e += 256) {
-        const u32 j = e & (n - 1), cc = (e >> LP) % K1, bb = (e >> LP) / K1;
-        const u64 lo = tile64[pad16((bb * NC + cc) * C::M + j)], hi = tile64[pad16((bb * NC + K1 + cc) * C::M + j)];
-        a.out[((b0 + bb) * K1 + cc) * (u64)n + j] = lo + (hi << 32);
-    }
-}
-
-// ---- key switching tail: sum of parts -> inverse transforms -> CRT lift -> mod q -> (0, b) - rhs ---------------------------
+// ---- the tail: sum of parts -> inverse transforms -> CRT lift -> recombination of the halves ----------------------------
 // Unit w = output row (ciphertext b, component c < k+1).  Its two half-sums (key words split at bit 32) are each two
 // inverse transforms; a thread ends every one of them on the SAME 16 positions, so the lifts meet in registers:
-//   rhs = (lift(S_lo) + lift(S_hi) * 2^32) mod q,   out[b][c] = (c < k ? 0 : glwe[b][c]) - rhs   (glwe.rs:129-136)
-template <int LP>
-__global__ __launch_bounds__(256) void digit_tail32_ks_kernel(Ext32Args a) {
+//   EPI32_TORUS  out[b][c] = lift(S_lo) + (lift(S_hi) << 32)  mod 2^64          (TGGSW x TGLWE)
+//   EPI32_KS     rhs = (lift(S_lo) + lift(S_hi) * 2^32) mod q,   out[b][c] = (c < k ? 0 : glwe[b][c]) - rhs   (glwe.rs:129-136)
+// lift = the centred representative modulo pA pB.
+enum : int { EPI32_TORUS = 0, EPI32_KS = 1 };
+template <int LP, int EPI>
+__global__ __launch_bounds__(256) void digit_tail32_kernel(Ext32Args a) {
     using C = ContigCfg<LP>;
     using K = Cfg32<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -474,23 +400,33 @@ __global__ __launch_bounds__(256) void digit_tail32_ks_kernel(Ext32Args a) {
         }
     }
     if (!active) return;
-    const Mod &m = a.mod;
     const u64 base = (b * k1 + c) * (u64)n;
-    const bool body = c >= a.k;
+    if constexpr (EPI == EPI32_TORUS) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 pos = field_of<C::A0>(tf, k);
-        u64 r[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const bool neg = S[h][k] >= a.halfP;                  // the centred value is S - P
-            const u64 mag = reduce_any(neg ? a.P - S[h][k] : S[h][k], m);
-            r[h] = (neg && mag) ? m.q - mag : mag;
+        for (int k = 0; k < 16; k++) {
+            u64 lo = S[0][k], hi = S[1][k];
+            if (lo >= a.halfP) lo -= a.P;                       // two's complement of the centred value
+            if (hi >= a.halfP) hi -= a.P;
+            a.out[base + field_of<C::A0>(tf, k)] = lo + (hi << 32);
         }
-        u64 y = r[0] + mul_mod_var(r[1], a.two32, m);             // < 2q
-        y = canon2(y, m);
-        const u64 x = body ? a.glwe[base + pos] : 0ull;
-        a.out[base + pos] = x >= y ? x - y : x + m.q - y;
+    } else {
+        const Mod &m = a.mod;
+        const bool body = c >= a.k;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 pos = field_of<C::A0>(tf, k);
+            u64 r[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const bool neg = S[h][k] >= a.halfP;              // the centred value is S - P
+                const u64 mag = reduce_any(neg ? a.P - S[h][k] : S[h][k], m);
+                r[h] = (neg && mag) ? m.q - mag : mag;
+            }
+            u64 y = r[0] + mul_mod_var(r[1], a.two32, m);         // < 2q
+            y = canon2(y, m);
+            const u64 x = body ? a.glwe[base + pos] : 0ull;
+            a.out[base + pos] = x >= y ? x - y : x + m.q - y;
+        }
     }
 }
 
@@ -517,39 +453,23 @@ static hipError_t launch_mac32_lp(const Ext32Args &a, hipStream_t st) {
     hipLaunchKernelGGL((digit_mac32_kernel<LP, 4, SRC>), dim3((unsigned)grid), dim3(K::TH), K::LDS_BYTES, st, a);
     return hipGetLastError();
 }
-template <int LP>
+template <int LP, int EPI>
 static hipError_t launch_tail32_lp(const Ext32Args &a, hipStream_t st) {
-    using C = ContigCfg<LP>;
-    using K = Cfg32<LP>;
-    if constexpr (C::W % 4 != 0) {
-        return hipErrorNotSupported;
-    } else {
-        constexpr size_t lds = (size_t)(C::W * C::M + C::W * C::M / 16) * 8 + 2 * K::TW_BYTES;
-        const u64 grid = (a.batch * 4 + C::W - 1) / C::W;
-        if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-        if (hipError_t e = allow_big_lds((const void *)digit_tail32_kernel<LP, 4>, lds)) return e;
-        KernelTimer kt("digit_tail32", LP, st);
-        hipLaunchKernelGGL((digit_tail32_kernel<LP, 4>), dim3((unsigned)grid), dim3(256), lds, st, a);
-        return hipGetLastError();
-    }
-}
-template <int LP>
-static hipError_t launch_tail32_ks_lp(const Ext32Args &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     using K = Cfg32<LP>;
     constexpr size_t lds = K::TILE_BYTES + 2 * K::TW_BYTES;
     const u64 grid = (a.batch * (a.k + 1) + C::W - 1) / C::W;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)digit_tail32_ks_kernel<LP>, lds)) return e;
-    KernelTimer kt("digit_tail32_ks", LP, st);
-    hipLaunchKernelGGL((digit_tail32_ks_kernel<LP>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    if (hipError_t e = allow_big_lds((const void *)digit_tail32_kernel<LP, EPI>, lds)) return e;
+    KernelTimer kt(EPI == EPI32_KS ? "digit_tail32_ks" : "digit_tail32", LP, st);
+    hipLaunchKernelGGL((digit_tail32_kernel<LP, EPI>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
-// TGGSW x TGLWE: k = 1, single-pass sizes where a workgroup of the tail holds whole ciphertexts
+// TGGSW x TGLWE: k = 1, 2^8 <= n <= 2^12
 bool ext32_shape_supported(u64 n, unsigned k, unsigned l) {
     if (k != 1 || l < 1 || l > 64) return false;
-    if (n != 256 && n != 512 && n != 1024) return false;
+    if (n < 256 || n > 4096 || (n & (n - 1))) return false;
     return (u64)(k + 1) * l * n <= (1ull << 21);          // |half-sum| < T n 2^32 <= 2^53 < P / 2
 }
 // GLWE::key_switch, base 2: k = 1, 2^8 <= n <= 2^12
@@ -576,8 +496,8 @@ hipError_t launch_ext32_mac(const Ext32Args &a, int log_n, int src_kind, hipStre
     if (src_kind == SRC_ZQBITS) { FHE_LP_SWITCH(launch_mac32_lp, FHE_COMMA SRC_ZQBITS) }
     return hipErrorNotSupported;
 }
-hipError_t launch_ext32_tail(const Ext32Args &a, int log_n, hipStream_t st) { FHE_LP_SWITCH(launch_tail32_lp) }
-hipError_t launch_ext32_tail_ks(const Ext32Args &a, int log_n, hipStream_t st) { FHE_LP_SWITCH(launch_tail32_ks_lp) }
+hipError_t launch_ext32_tail(const Ext32Args &a, int log_n, hipStream_t st) { FHE_LP_SWITCH(launch_tail32_lp, FHE_COMMA EPI32_TORUS) }
+hipError_t launch_ext32_tail_ks(const Ext32Args &a, int log_n, hipStream_t st) { FHE_LP_SWITCH(launch_tail32_lp, FHE_COMMA EPI32_KS) }
 #undef FHE_LP_SWITCH
 #undef FHE_COMMA
 

@@ -975,9 +975,14 @@ extern "C" int fhe_tggsw_external_product_prepared_dev(uint64_t n, unsigned k, u
     if (ext32_on(n, k, l)) {
         fhe::Ext32Args a{};
         if ((rc = fhe_ext32_tables(n, &a)) != FHE_OK) return rc;
-        const u32 parts32 = fhe::digit_mac_parts(batch, (u32)T, z1.dp[0].log_n, 2 * k1);
+        // parts: enough workgroups to fill the chip several times over (n <= 1024: four workgroups' worth of LDS per CU),
+        // only as many as leave no CU empty above (one or two workgroups per CU: see fhe_glwe_key_switch_dev)
+        const u32 W = fhe::ext32_units((int)z1.dp[0].log_n);
+        u32 parts32 = 1;
+        const u64 slots = n <= 1024 ? 2048 : n == 2048 ? 512 : 256;
+        while (parts32 < 8 && batch * parts32 < slots && (T / (parts32 * 2)) >= 2 * W) parts32 *= 2;
         if ((rc = fhe_workspace_get(1, (u64)batch * parts32 * 2 * (2 * k1) * n * 4, st, &wsv)) != FHE_OK) return rc;
-        const u32 W = (u32)(4096 / n);
+        a.k = k;
         a.key32 = (uint32_t *)const_cast<void *>(d_prepared);
         a.src = (const u64 *)d_tglwe; a.ct_stride = (u64)k1 * n; a.part32 = (uint32_t *)wsv; a.out = (u64 *)d_out; a.batch = batch;
         a.l = l; a.T = (u32)T; a.parts = parts32;

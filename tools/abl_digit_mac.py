@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fhe_study_amd as pkg
 B, L = pkg.binding, pkg.load_library()
-n, k, l, batch = 1024, 1, 64, 630
+n, k, l, batch = int(os.environ.get("EXT_N", "1024")), 1, 64, int(os.environ.get("EXT_BATCH", "630"))
 rng = np.random.default_rng(2)
 g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).cuda()
 c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (batch, k + 1, n), dtype=np.int64)).cuda()

@@ -145,7 +145,7 @@ __device__ __forceinline__ void stage_all(Tw32 *(&ltw)[3], unsigned char *base, 
     }
 }
 
-// ---- forward: row r of n words (one limb of it), zero-padded to 2n, modulo both primes --------------------------------
+// ---- forward: row r of n words, zero-padded to 2n, modulo the first NPR primes ----------------------------------------
 template <int LP, int NPR>
 __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_forward_kernel(Bfv32Args a) {
     using C = Big32<LP>;

@@ -311,7 +311,7 @@ def test_two_pass_product_device_entry_point_outputs_workspaces_and_tiles(pkg, o
                                          (256, 1, 64, 3),       # 16 units per workgroup
                                          (512, 1, 7, 9),        # l not a multiple of the units: steps straddle source rows
                                          (2048, 1, 33, 2),
-                                         (4096, 1, 64, 1)])     # 2(k+1) * n/256 = 64 accumulators: takes the unfused form
+                                         (4096, 1, 64, 1)])     # 512-thread workgroups of digit32.hip (61-bit family: 64 accumulators, the unfused form)
 def test_fused_external_product_and_prepared_key(pkg, oracle, n, k, l, batch):
     """TGGSW x TGLWE through digit_mac_kernel (tfhe/src/tggsw.rs:45-62): same words as the oracle's
     schoolbook; the key prepared once (fhe_tggsw_prepare_dev) gives the same words again, for several

@@ -27,8 +27,10 @@
  *     `hipStream_t` passed as `void*` (NULL = the default stream); they only
  *     enqueue work and never synchronise — except the first use of a plan on a
  *     device, which uploads its tables (call fhe_ntt_plan_prepare() beforehand
- *     to keep that out of, e.g., a stream capture), growth of a library
- *     workspace, and the opt-in FHE_NTT_CHECK_CANONICAL mode.  Device buffers must be 16-byte
+ *     to keep that out of, e.g., a stream capture; the products of rows N1 - N3
+ *     — BFV, TGGSW x TGLWE, key switching — upload the tables of their internal
+ *     primes on the first call per (n, device): run one call before capturing),
+ *     growth of a library workspace, and the opt-in FHE_NTT_CHECK_CANONICAL mode.  Device buffers must be 16-byte
  *     aligned (FHE_E_INVALID otherwise; anything hipMalloc returns is).  Host-pointer variants copy
  *     host→device→host around the same kernels and return when `out` is valid.
  *   - There is no CPU fallback: without a HIP device every compute entry point

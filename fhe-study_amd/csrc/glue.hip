@@ -82,11 +82,12 @@ template <EwF OP>
 __global__ __launch_bounds__(256) void ewf_kernel(const u64 *__restrict__ a, u64 *__restrict__ c, u64 count,
                                                   u64 q, u64 su, double sf) {
     const u64 stride = (u64)gridDim.x * 256;
+    const u64 qmu = OP == EwF::Remodule || q == 0 ? 0ull : ~0ull / q;          // Zq::from_f64's remainder by multiplication
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
         const u64 v = a[i];
         if (OP == EwF::Remodule) c[i] = v >= q ? v % q : v;                       // q = the new modulus p
-        else if (OP == EwF::MulF64) c[i] = zq_from_f64(q, (double)v * sf);
-        else c[i] = zq_from_f64(q, round((double)v / (double)su));
+        else if (OP == EwF::MulF64) c[i] = zq_from_f64_mu(q, qmu, (double)v * sf);
+        else c[i] = zq_from_f64_mu(q, qmu, round((double)v / (double)su));
     }
 }
 

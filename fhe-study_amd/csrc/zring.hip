@@ -188,12 +188,13 @@ __global__ __launch_bounds__(256) void zr_mul_div_round_kernel(const u64 *__rest
                                                                u64 q, u64 num, u64 den) {
     const u64 total = rows * n, stride = (u64)gridDim.x * 256;
     const double numf = (double)num, denf = (double)den;
+    const u64 qmu = ~0ull / q;                                  // Zq::from_f64's remainder by multiplication (zq_device.hpp)
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const u64 r = i / n;
         const u32 j = (u32)(i - r * n);
         const long long lo = (long long)v[r * 2 * n + j], hi = (long long)v[r * 2 * n + n + j];
-        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
-        const u64 zh = (j == n - 1) ? 0ull : zq_from_f64(q, round((numf * (double)hi) / denf));
+        const u64 zl = zq_from_f64_mu(q, qmu, round((numf * (double)lo) / denf));
+        const u64 zh = (j == n - 1) ? 0ull : zq_from_f64_mu(q, qmu, round((numf * (double)hi) / denf));
         out[i] = zl >= zh ? zl - zh : (q + zl) - zh;   // Zq::sub, zq.rs:259-276
     }
 }
@@ -208,16 +209,17 @@ __global__ __launch_bounds__(256) void zr_crt_mdr_kernel(const u64 *__restrict__
                                                          u64 den, CrtConsts cc) {
     const u64 total = rows * n, stride = (u64)gridDim.x * 256;
     const double numf = (double)num, denf = (double)den;
+    const u64 qmu = ~0ull / q;                                  // Zq::from_f64's remainder by multiplication (zq_device.hpp)
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const u64 r = i / n;
         const u32 j = (u32)(i - r * n);
         const u64 il = r * 2 * n + j, ih = il + n;
         const long long lo = (long long)crt_value<K, false>(r1[il], K > 1 ? r2[il] : 0ull, K > 2 ? r3[il] : 0ull, cc);
-        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
+        const u64 zl = zq_from_f64_mu(q, qmu, round((numf * (double)lo) / denf));
         u64 zh = 0;
         if (j != n - 1) {
             const long long hi = (long long)crt_value<K, false>(r1[ih], K > 1 ? r2[ih] : 0ull, K > 2 ? r3[ih] : 0ull, cc);
-            zh = zq_from_f64(q, round((numf * (double)hi) / denf));
+            zh = zq_from_f64_mu(q, qmu, round((numf * (double)hi) / denf));
         }
         u64 v = zl >= zh ? zl - zh : (q + zl) - zh;   // Zq::sub, zq.rs:259-276
         if (addend) {
@@ -247,16 +249,17 @@ __global__ __launch_bounds__(256) void zr_split_mdr_kernel(const u64 *__restrict
                                                            u64 *__restrict__ out, u64 batch, u32 n, u32 h, u64 q, u64 num, u64 den) {
     const u64 per = batch * n, total = 2 * per, stride = (u64)gridDim.x * 256;
     const double numf = (double)num, denf = (double)den;
+    const u64 qmu = ~0ull / q;                                  // Zq::from_f64's remainder by multiplication (zq_device.hpp)
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const u64 o = i / per, bj = i - o * per, b = bj / n;
         const u32 j = (u32)(bj - b * n);
         const u64 il = ((2 * o) * batch + b) * 2 * n + j, ih = ((2 * o + 1) * batch + b) * 2 * n + j;
         const long long lo = (long long)(R[il] + (R[ih] << h));
-        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
+        const u64 zl = zq_from_f64_mu(q, qmu, round((numf * (double)lo) / denf));
         u64 zh = 0;
         if (j != n - 1) {
             const long long hi = (long long)(R[il + n] + (R[ih + n] << h));
-            zh = zq_from_f64(q, round((numf * (double)hi) / denf));
+            zh = zq_from_f64_mu(q, qmu, round((numf * (double)hi) / denf));
         }
         u64 v = zl >= zh ? zl - zh : (q + zl) - zh;   // Zq::sub, zq.rs:259-276
         v += addend[i];
@@ -305,6 +308,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void zr_inv_strided_mdr_k
     const u32 cg = blockIdx.x & ((1u << lcg) - 1u);
     const u64 poly = (u64)(blockIdx.x >> lcg);
     const Mod &m = a.mod;
+    const u64 qmu = ~0ull / q;
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
     __syncthreads();
@@ -317,8 +321,8 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void zr_inv_strided_mdr_k
     for (int k = 0; k < 8; k++) {
         const u32 f = ((u32)k << C::A0) | tf;
         const long long lo = (long long)canon2(v[k], m), hi = (long long)canon2(v[k + 8], m);
-        const u64 zl = zq_from_f64(q, round((numf * (double)lo) / denf));
-        const u64 zh = zq_from_f64(q, round((numf * (double)hi) / denf));   // slot 2n-1 of a (2n-1)-term convolution is 0
+        const u64 zl = zq_from_f64_mu(q, qmu, round((numf * (double)lo) / denf));
+        const u64 zh = zq_from_f64_mu(q, qmu, round((numf * (double)hi) / denf));   // slot 2n-1 of a (2n-1)-term convolution is 0
         po[(u64)f << lb] = zl >= zh ? zl - zh : (q + zl) - zh;    // Zq::sub, zq.rs:259-276
     }
 }

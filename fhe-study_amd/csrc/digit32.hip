@@ -126,6 +126,9 @@ struct Cfg32 {
 // Measured at n = 4096 (256 key switches, l = 61): 512 threads 354 us; 256 threads with ONE prime per workgroup (twice
 // the workgroups, 64 accumulators each, two per CU) 384 us; a software pipeline that multiplies step s-1 while step s
 // transforms (double-buffered tiles, key loads issued a half-round ahead) spills and is 2-3x slower at every size.
+// At n = 1024 (630 external products, lockstep 320 us): the primes taking turns in 168 registers, three workgroups per
+// CU, 340 us; the multiply phase made unconditional so that a step's key loads issue together, 322 us (351 -> 371 at
+// n = 4096).
 template <int LP>
 struct Mac32Cfg {
     using C = ContigCfg<LP>;

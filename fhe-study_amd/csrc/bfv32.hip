@@ -147,7 +147,8 @@ __device__ __forceinline__ void stage_all(Tw32 *(&ltw)[3], unsigned char *base, 
 }
 
 // ---- forward: row r of n words, zero-padded to 2n, modulo the first NPR primes ----------------------------------------
-template <int LP, int NPR>
+// WORD32: the source words are below 2^32 (ciphertext words modulo a q that small): reduced in one word
+template <int LP, int NPR, bool WORD32>
 __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_forward_kernel(Bfv32Args a) {
     using C = Big32<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -165,18 +166,22 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_forward_kernel(Bfv32Arg
 #pragma unroll
         for (int k = 0; k < 8; k++) x[s][k] = src[(u32)k * (C::VT * C::TH) + tf + s * C::TH];
     __syncthreads();                                            // the twiddle tiles
+    // NPR == 1: prime blockIdx.y of this row (the relinearisation key: two rows, so three workgroups each instead of three
+    // transforms in turn)
 #pragma unroll
-    for (int pr = 0; pr < NPR; pr++) {
+    for (int i = 0; i < NPR; i++) {
+        const u32 pr = NPR == 1 ? blockIdx.y : (u32)i;
         const u32 p = a.t.p[pr], p2 = 2u * p;
+        const Tw32 *lt = reinterpret_cast<const Tw32 *>(smem_raw + C::TILE_BYTES + pr * C::TW_BYTES);
         u32 v[C::VT][16];
 #pragma unroll
         for (int s = 0; s < C::VT; s++)
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                v[s][k] = reduce64_32(x[s][k], p, a.t.mu[pr]);
+                v[s][k] = WORD32 ? csub_u32(barrett2p_32((u32)x[s][k], p, a.t.bq[pr]), p) : reduce64_32(x[s][k], p, a.t.mu[pr]);
                 v[s][k + 8] = v[s][k];                          // stage 0 against zeros: x + w * 0 and x - w * 0
             }
-        fwd_big<LP, 1>(v, lds, ltw[pr], a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr]);
+        fwd_big<LP, 1>(v, lds, lt, a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr]);
 #pragma unroll
         for (int s = 0; s < C::VT; s++) {
             // stored order (internal to this file): quad j of logical thread t at j * (M / 4) + 4 t — a wave's 16-byte
@@ -375,32 +380,35 @@ bool bfv32_shape_supported(uint64_t q, uint64_t n, uint64_t pq) {
 }
 
 template <typename K>
-static hipError_t launch_big(K kernel, const char *name, int lp, size_t lds, unsigned th, u64 grid, const Bfv32Args &a, hipStream_t st) {
+static hipError_t launch_big(K kernel, const char *name, int lp, size_t lds, unsigned th, u64 grid, const Bfv32Args &a, hipStream_t st,
+                             unsigned gridy = 1) {
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     if (hipError_t e = allow_big_lds((const void *)kernel, lds)) return e;
     KernelTimer kt(name, lp, st);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(th), lds, st, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid, gridy), dim3(th), lds, st, a);
     return hipGetLastError();
 }
-#define FHE_BIG_SWITCH(KERNEL, NAME, GRID)                                                                                   \
+#define FHE_BIG_SWITCH(KERNEL, NAME, GRID, GRIDY)                                                                                 \
     switch (a.log_n2) {                                                                                                      \
-        case 11: return launch_big(KERNEL<11>, NAME, 11, Big32<11>::TILE_BYTES + 3 * Big32<11>::TW_BYTES, Big32<11>::TH, GRID, a, st); \
-        case 12: return launch_big(KERNEL<12>, NAME, 12, Big32<12>::TILE_BYTES + 3 * Big32<12>::TW_BYTES, Big32<12>::TH, GRID, a, st); \
-        case 13: return launch_big(KERNEL<13>, NAME, 13, Big32<13>::TILE_BYTES + 3 * Big32<13>::TW_BYTES, Big32<13>::TH, GRID, a, st); \
-        case 14: return launch_big(KERNEL<14>, NAME, 14, Big32<14>::TILE_BYTES + 3 * Big32<14>::TW_BYTES, Big32<14>::TH, GRID, a, st); \
+        case 11: return launch_big(KERNEL<11>, NAME, 11, Big32<11>::TILE_BYTES + 3 * Big32<11>::TW_BYTES, Big32<11>::TH, GRID, a, st, GRIDY); \
+        case 12: return launch_big(KERNEL<12>, NAME, 12, Big32<12>::TILE_BYTES + 3 * Big32<12>::TW_BYTES, Big32<12>::TH, GRID, a, st, GRIDY); \
+        case 13: return launch_big(KERNEL<13>, NAME, 13, Big32<13>::TILE_BYTES + 3 * Big32<13>::TW_BYTES, Big32<13>::TH, GRID, a, st, GRIDY); \
+        case 14: return launch_big(KERNEL<14>, NAME, 14, Big32<14>::TILE_BYTES + 3 * Big32<14>::TW_BYTES, Big32<14>::TH, GRID, a, st, GRIDY); \
     }                                                                                                                        \
     return hipErrorNotSupported;
 
-template <int LP> static constexpr auto bfv32_forward2 = bfv32_forward_kernel<LP, 2>;
-template <int LP> static constexpr auto bfv32_forward3 = bfv32_forward_kernel<LP, 3>;
+template <int LP> static constexpr auto bfv32_forward2 = bfv32_forward_kernel<LP, 2, true>;
+template <int LP> static constexpr auto bfv32_forward3 = bfv32_forward_kernel<LP, 3, true>;
+template <int LP> static constexpr auto bfv32_forward1w = bfv32_forward_kernel<LP, 1, false>;
 hipError_t launch_bfv32_forward(const Bfv32Args &a, hipStream_t st) {
-    if (a.primes == 2) { FHE_BIG_SWITCH(bfv32_forward2, "bfv32_forward", a.rows) }
-    if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", a.rows) }
+    if (a.primes == 2 && a.word32) { FHE_BIG_SWITCH(bfv32_forward2, "bfv32_forward", a.rows, 1) }
+    if (a.primes == 3 && a.word32) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", a.rows, 1) }
+    if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward1w, "bfv32_forward_key", a.rows, 3) }      // grid (rows, primes)
     return hipErrorNotSupported;
 }
-hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_tensor_inverse_kernel, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8)) }
-hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_relin_inverse_kernel, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8)) }
+hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_tensor_inverse_kernel, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1) }
+hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_relin_inverse_kernel, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1) }
 #undef FHE_BIG_SWITCH
 
 }  // namespace fhe

@@ -15,6 +15,7 @@ struct Bfv32Args {
     uint32_t *fw;
     u64 rows;
     uint32_t primes;
+    uint32_t word32;           // the source words are below 2^32 (words modulo q; not the relinearisation key)
     // tensor: fw rows [a0 | a1 | b0 | b1] x batch -> out [c0 | c1 | c2] x batch x n  (scaled by num/den, rounded, folded)
     // relinearisation (three primes): x[prime][batch][2n] (transform of c2), key[prime][2][2n] -> out [o0 | o1] x batch x n
     const uint32_t *x, *key;

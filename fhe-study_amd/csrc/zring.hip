@@ -558,7 +558,7 @@ static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, vo
     void *wsv = nullptr;
     // transforms of [a0 | a1 | b0 | b1] x batch modulo two primes: 2 * 4 * batch rows of 2n u32
     if ((rc = fhe_workspace_get(1, (u64)2 * 4 * batch * 2 * n * 4, st, &wsv)) != FHE_OK) return rc;
-    a.src = (const u64 *)d_ab; a.fw = (uint32_t *)wsv; a.rows = 4 * (u64)batch; a.primes = 2;
+    a.src = (const u64 *)d_ab; a.fw = (uint32_t *)wsv; a.rows = 4 * (u64)batch; a.primes = 2; a.word32 = 1;   // q < 2^21
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.batch = batch; a.out = (u64 *)d_c; a.q = q; a.qmu = ~0ull / q; a.numf = (double)t; a.denf = (double)q;
@@ -581,7 +581,7 @@ static int bfv32_relinearize(uint64_t q, uint64_t n, uint64_t pq, const void *d_
     if (rc != FHE_OK) return rc;
     void *wsv = nullptr;
     if ((rc = fhe_workspace_get(1, (u64)3 * batch * 2 * n * 4, st, &wsv)) != FHE_OK) return rc;
-    a.src = (const u64 *)d_c + 2 * (u64)batch * n; a.fw = (uint32_t *)wsv; a.rows = batch; a.primes = 3;
+    a.src = (const u64 *)d_c + 2 * (u64)batch * n; a.fw = (uint32_t *)wsv; a.rows = batch; a.primes = 3; a.word32 = 1;
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.x = (const uint32_t *)wsv; a.key = (const uint32_t *)d_prep;

@@ -387,6 +387,49 @@ def test_fused_key_switch(pkg, oracle, q, n, k, l, batch):
         assert np.array_equal(_u64(dout3), want[:nb])
 
 
+def test_small_prime_products_on_random_shapes(pkg, oracle):
+    """A seeded sweep over the shapes digit32.hip serves (k = 1; n = 2^8 .. 2^12; any 1 <= l <= 64; batches that do and do
+    not fill whole steps / parts / tail workgroups): external product and key switch, plain and prepared keys, word for
+    word against the oracle."""
+    import torch
+
+    L, B = pkg.load_library(), pkg.binding
+    rng = np.random.default_rng(0xD16175)
+    k = 1
+    for case in range(10):
+        n = 1 << int(rng.integers(8, 13))
+        l = int(rng.integers(1, 65))
+        batch = int(rng.integers(1, 12)) if n >= 2048 else int(rng.integers(1, 40))
+        # external product (full-range torus words)
+        if n <= 1024 or case % 2 == 0:                      # the schoolbook oracle is O(n^2 l) per ciphertext
+            nb = min(batch, 2 if n > 1024 else 6)
+            g = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (k + 1, l, k + 1, n), dtype=np.int64)).cuda()
+            c = torch.from_numpy(rng.integers(-(1 << 63), 1 << 63, (nb, k + 1, n), dtype=np.int64)).cuda()
+            out = torch.empty_like(c)
+            B._check(L.fhe_tggsw_external_product_dev(n, k, l, g.data_ptr(), c.data_ptr(), out.data_ptr(), nb, None))
+            assert np.array_equal(_u64(out), oracle.external_product(n, k, l, _u64(g), _u64(c))), ("ext", n, l, nb)
+        # key switch (q61, or q = 65537 where every digit above bit 16 saturates)
+        q = Q16 if case % 3 == 0 else Q61
+        plan = pkg.Plan(q, n)
+        glwe = rng.integers(0, q, (batch, k + 1, n), dtype=np.uint64)
+        ksk = rng.integers(0, q, (k, l, k + 1, n), dtype=np.uint64)
+        dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
+        dglwe, dksk = dev(glwe), dev(ksk)
+        dout = torch.empty_like(dglwe)
+        if L.fhe_glwe_key_switch_dev(plan.handle, k, 2, l, dglwe.data_ptr(), dksk.data_ptr(), dout.data_ptr(), batch, 0, None) != 0:
+            assert q == Q16 and l > 16                       # Zq::decompose is undefined there (q / 2^l = 0): rejected, as documented
+            continue
+        want = np.empty((batch, k + 1, n), dtype=np.uint64)
+        for i in range(batch):
+            oracle.glue("key_switch", q, n, k, 2, l, glwe[i], ksk, want[i])
+        assert np.array_equal(_u64(dout), want), ("ks", q, n, l, batch)
+        prep = torch.empty(L.fhe_glwe_ksk_prepared_words(plan.handle, k, 2, l), dtype=torch.int64, device="cuda")
+        B._check(L.fhe_glwe_ksk_prepare_dev(plan.handle, k, 2, l, dksk.data_ptr(), prep.data_ptr(), None))
+        dout.zero_()
+        B._check(L.fhe_glwe_key_switch_prepared_dev(plan.handle, k, 2, l, dglwe.data_ptr(), prep.data_ptr(), dout.data_ptr(), batch, None))
+        assert np.array_equal(_u64(dout), want), ("ks prepared", q, n, l, batch)
+
+
 def test_fused_and_unfused_digit_paths_agree_at_bench_sizes(pkg):
     """FHE_DIGIT_MAC_FUSED=0 keeps round 1's materialised digit transforms + mac_rows_kernel; both forms
     must produce identical words for 630 external products (N=1024) and 256 key switches (N=4096)."""

@@ -165,6 +165,11 @@ def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
     assert L.fhe_glwe_ksk_prepared_words(big.handle, 2, 2, 61) == 2 * 61 * 3 * 4096       # k = 2: transforms modulo q
     assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 4, 8) == 8 * 2 * 4096
     assert L.fhe_glwe_ksk_prepare_dev(None, 1, 2, 4, d, d, None) == B.FHE_E_NULL
+    # resident relinearisation key: three 27-bit primes where c2 * rlk over n terms stays below 2^82, 61-bit forms otherwise
+    assert L.fhe_bfv_rlk_prepared_words(Q16, 8192, Q16 ** 3) == 6 * 8192                 # 17 + 51 + 13 bits
+    assert L.fhe_bfv_rlk_prepared_words(Q16, 16384, Q16 ** 3) == 8 * 16384               # n > 8192: one 61-bit prime, key in halves
+    assert L.fhe_bfv_rlk_prepared_words(786433, 4096, 786433 ** 3) == 8 * 4096           # 20 + 59 + 12 > 82 bits
+    assert L.fhe_bfv_rlk_prepared_words(Q16, 512, Q16 ** 3) == 8 * 512                   # n < 1024: 61-bit path
     assert L.fhe_glwe_ksk_prepare_dev(plan.handle, 1, 2, 65, d, d, None) == B.FHE_E_INVALID
     assert L.fhe_glwe_key_switch_prepared_dev(plan.handle, 0, 2, 4, d, d, d, 1, None) == B.FHE_E_INVALID
     assert L.fhe_glwe_key_switch_prepared_dev(big.handle, 1, 2, 61, None, None, None, 0, None) == 0

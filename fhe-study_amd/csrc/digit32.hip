@@ -41,8 +41,18 @@ __device__ __forceinline__ void fwd_rounds32(u32 (&v)[16], u32 *lds, const Tw32 
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        exchange32<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd32<4, 0, LOOSE>(v, TW(C::in_lds(2)), (1u << LS) + (tf >> A), p, p2);
+        if constexpr (!C::in_lds(2)) {
+            // twiddles from the global table (unique per thread): requested BEFORE the exchange, so that their latency
+            // runs under its barriers (ntt32_rounds.hpp: load_tw32) — with one workgroup per CU at n = 4096 nothing else
+            // hides it: 256 key switches 351 -> 316 us
+            Tw32 t[15];
+            load_tw32<4>(t, gtw, (1u << LS) + (tf >> A));
+            exchange32<LP, C::a_of(1), A, false>(v, lds, w, tf);
+            round_fwd32_tw<4, 0, LOOSE>(v, t, p, p2);
+        } else {
+            exchange32<LP, C::a_of(1), A, false>(v, lds, w, tf);
+            round_fwd32<4, 0, LOOSE>(v, ltw, (1u << LS) + (tf >> A), p, p2);
+        }
     }
     static_assert(C::NR <= 3, "n <= 4096");
 }
@@ -85,6 +95,8 @@ __device__ __forceinline__ void fwd_rounds32x2_bits(u32 (&va)[16], u32 (&vb)[16]
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         constexpr bool L = C::in_lds(2);
+        // (requesting the global twiddles of both primes ahead of this exchange, as fwd_rounds32 does, costs 35 registers
+        // here and was measured slower: 329 vs 320 us per 630 products — two workgroups per CU hide that latency already)
         exchange32x2<LP, C::a_of(1), A, false>(va, vb, tile[0], tile[1], w, tf);
         round_fwd32<4, 0, true>(va, L ? ltw[0] : gtw[0], (1u << LS) + (tf >> A), pa, pa2);
         round_fwd32<4, 0, true>(vb, L ? ltw[1] : gtw[1], (1u << LS) + (tf >> A), pb, pb2);

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "capi_internal.hpp"
+#include "smallq.hpp"
 
 using fhe::u64;
 typedef unsigned __int128 u128;
@@ -236,14 +237,38 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
             if (dl) (void)hipFree(dl);
             return hip_fail(e, "uploading the twiddle tables");
         }
+        // small moduli: the same two tables as 32-bit Shoup pairs (smallq.hip)
+        fhe::Tw32 *sf = nullptr, *si = nullptr;
+        if (fhe::smallq_supported(q, plan->log_n)) {
+            std::vector<fhe::Tw32> f32(n), i32(n);
+            for (u64 k = 0; k < n; k++) {
+                f32[k] = fhe::Tw32{(uint32_t)plan->roots[k], (uint32_t)((plan->roots[k] << 32) / q)};
+                i32[k] = fhe::Tw32{(uint32_t)plan->roots_inv[k], (uint32_t)((plan->roots_inv[k] << 32) / q)};
+            }
+            e = hipMalloc((void **)&sf, n * sizeof(fhe::Tw32));
+            if (e == hipSuccess) e = hipMalloc((void **)&si, n * sizeof(fhe::Tw32));
+            if (e == hipSuccess) e = hipMemcpy(sf, f32.data(), n * sizeof(fhe::Tw32), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(si, i32.data(), n * sizeof(fhe::Tw32), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (sf) (void)hipFree(sf);
+                if (si) (void)hipFree(si);
+                (void)hipFree(df); (void)hipFree(di);
+                if (dl) (void)hipFree(dl);
+                return hip_fail(e, "uploading the 32-bit twiddle tables");
+            }
+        }
         t.tw_fwd = df;
         t.tw_inv = di;
         t.digit_lut = dl;
+        t.tw32_fwd = sf;
+        t.tw32_inv = si;
         t.ready = true;
     }
     dp->tw_fwd = t.tw_fwd;
     dp->tw_inv = t.tw_inv;
     dp->digit_lut = t.digit_lut;
+    dp->tw32_fwd = t.tw32_fwd;
+    dp->tw32_inv = t.tw32_inv;
     dp->mod = plan->mod;
     dp->ninv = plan->ninv;
     dp->s_ninv = plan->s_ninv;
@@ -569,6 +594,21 @@ extern "C" int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_
     return i;
 }
 
+// small moduli (q < 2^32 / 25, 2^8 <= n <= 2^12): one 32-bit word per coefficient (smallq.hip); FHE_EXT32=0 keeps the 61-bit kernels
+static bool smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a) {
+    if (!dp.tw32_fwd || !fhe_ext32_enabled()) return false;
+    const u64 q = plan->q;
+    a->tw_fwd = dp.tw32_fwd; a->tw_inv = dp.tw32_inv;
+    a->q = (uint32_t)q; a->bq = (uint32_t)(0xffffffffull / q);
+    uint32_t inv = (uint32_t)q;                                 // Newton: q^-1 mod 2^32 (q odd)
+    for (int it = 0; it < 5; it++) inv *= 2u - (uint32_t)q * inv;
+    a->qinv_neg = 0u - inv;
+    a->ninv = fhe::Tw32{(uint32_t)plan->n_inv, (uint32_t)((plan->n_inv << 32) / q)};
+    const u64 nm = (plan->n_inv << 32) % q;
+    a->ninv_mont = fhe::Tw32{(uint32_t)nm, (uint32_t)((nm << 32) / q)};
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // device-resident entry points
 // ---------------------------------------------------------------------------
@@ -583,6 +623,12 @@ extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, v
     int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
     if ((rc = check_canonical_dev(plan, d_in, batch * plan->n, (hipStream_t)hip_stream, "fhe_ntt_forward_dev")) != FHE_OK) return rc;
+    fhe::SmallQArgs sq{};
+    if (smallq_args(plan, dp, &sq)) {
+        sq.a = (const u64 *)d_in; sq.out = (u64 *)d_out; sq.rows = batch;
+        hipError_t se = fhe::launch_sq_forward(sq, (int)dp.log_n, (hipStream_t)hip_stream);
+        return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_forward_kernel");
+    }
     hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_in, (u64 *)d_out, batch,
                                            fhe_batch_tile_for(plan), (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward");
@@ -600,6 +646,12 @@ extern "C" int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, v
     int rc = fhe_device_plan(plan, &dp);
     if (rc != FHE_OK) return rc;
     if ((rc = check_canonical_dev(plan, d_in, batch * plan->n, (hipStream_t)hip_stream, "fhe_ntt_inverse_dev")) != FHE_OK) return rc;
+    fhe::SmallQArgs sq{};
+    if (smallq_args(plan, dp, &sq)) {
+        sq.a = (const u64 *)d_in; sq.out = (u64 *)d_out; sq.rows = batch;
+        hipError_t se = fhe::launch_sq_inverse(sq, (int)dp.log_n, (hipStream_t)hip_stream);
+        return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_inverse_kernel");
+    }
     hipError_t e = fhe::launch_ntt_inverse(dp, (const u64 *)d_in, nullptr, nullptr, (u64 *)d_out,
                                            batch, fhe_batch_tile_for(plan), (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_inverse");
@@ -634,6 +686,13 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
     if ((rc = check_canonical_dev(plan, d_a, elems, st, "fhe_rq_mul_dev (a)")) != FHE_OK) return rc;
     if ((rc = check_canonical_dev(plan, d_b, elems, st, "fhe_rq_mul_dev (b)")) != FHE_OK) return rc;
 
+    // small modulus, plain product (no cached evals in or out): the whole product in 32-bit words (smallq.hip)
+    fhe::SmallQArgs sq{};
+    if (!a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out && smallq_args(plan, dp, &sq)) {
+        sq.a = (const u64 *)d_a; sq.b = (const u64 *)d_b; sq.out = (u64 *)d_c; sq.rows = batch;
+        hipError_t se = fhe::launch_sq_rq_mul(sq, (int)dp.log_n, st);
+        return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_rq_mul_kernel");
+    }
     // single-pass sizes: the whole product in one kernel (both forward transforms, the pointwise
     // product and the inverse transform stay on chip); FHE_RQ_MUL_FUSED=0 selects the three-kernel path
     static const bool fused_on = [] {
@@ -900,6 +959,8 @@ extern "C" int fhe_ntt_shutdown(void) {
             if (t.tw_fwd) (void)hipFree(t.tw_fwd);
             if (t.tw_inv) (void)hipFree(t.tw_inv);
             if (t.digit_lut) (void)hipFree(t.digit_lut);
+            if (t.tw32_fwd) (void)hipFree(t.tw32_fwd);
+            if (t.tw32_inv) (void)hipFree(t.tw32_inv);
             t = DeviceTables();
         }
     }

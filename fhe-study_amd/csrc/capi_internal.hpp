@@ -16,6 +16,7 @@ struct DeviceTables {
     fhe::Tw *tw_fwd = nullptr;
     fhe::Tw *tw_inv = nullptr;
     fhe::u64 *digit_lut = nullptr;   // 136 words, n >= 8 (ntt_rounds.hpp: round0_bits)
+    fhe::Tw32 *tw32_fwd = nullptr, *tw32_inv = nullptr;   // small moduli (smallq.hip)
     bool ready = false;
 };
 

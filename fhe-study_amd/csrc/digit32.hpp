@@ -7,7 +7,6 @@
 
 namespace fhe {
 
-struct Tw32 { uint32_t w, wp; };                     // twiddle and floor(w * 2^32 / p)
 
 // the two primes: the largest below 2^32 / 25 with p = 1 mod 2^15 (27.36 and 27.35 bits; product 2^54.7).  Below
 // 2^32 / 25 so that up to twelve lazy butterfly stages need no conditional subtraction (digit32.hip: ct32_loose).

@@ -1,0 +1,266 @@
+// smallq.hip — NTT::ntt / NTT::intt / Rq x Rq (arith/src/ntt.rs:44-104, ring_nq.rs:586-607) for SMALL moduli in 32-bit words.
+//
+// The reference's own tests and its BFV / GLWE demos run at q = 65537 (and 12289, 1021, ...): 64-bit Shoup butterflies —
+// ten 32-bit multiplies and ~22 instructions each — for 17-bit numbers.  For an NTT-friendly q below 2^32 / 25 the same
+// transform (same psi, same tables, same bit-reversed layout: the plan's) runs in one word per coefficient with the
+// butterflies of ntt32_rounds.hpp: 3 multiplies + 3 additions, no conditional subtraction on the forward side.  The
+// interface stays 64-bit words; a transform is then bound by its 16 n bytes of traffic instead of by multiplier issue.
+// Single-pass sizes 2^8 <= n <= 2^12; everything else (and FHE_EXT32=0) keeps the 61-bit kernels.  Same values, word for
+// word: every result is canonical modulo the same q.
+//   sq_forward_kernel   n words in (natural order) -> forward transform -> n words out (the reference's bit-reversed order)
+//   sq_inverse_kernel   the inverse, n^-1 folded in
+//   sq_rq_mul_kernel    both forward transforms in lockstep (one twiddle load for both), pointwise Montgomery product,
+//                       inverse transform — the whole product on chip, as rq_mul_fused_kernel does for 61-bit q
+#include "smallq.hpp"
+#include "ntt32_rounds.hpp"
+
+namespace fhe {
+
+template <int LP>
+struct SqCfg {
+    using C = ContigCfg<LP>;
+    static constexpr int M = C::M, W = C::W, TPB = C::TPB;
+    static constexpr size_t TILE_BYTES = (size_t)(W * M + W * M / 16) * 4, TW_BYTES = (size_t)C::LTW_N * sizeof(Tw32);
+    static_assert(LP >= 8 && LP <= 12, "n = 256 .. 4096");
+};
+
+// two polynomials through two tiles with one pair of barriers
+template <int LP, int AF, int AT, bool FIRST>
+__device__ __forceinline__ void sq_exchange2(u32 (&va)[16], u32 (&vb)[16], u32 *la, u32 *lb, u32 w, u32 tf) {
+    constexpr int M = 1 << LP;
+    if (!FIRST) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 s = pad16(w * M + field_of<AF>(tf, k));
+        la[s] = va[k];
+        lb[s] = vb[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 s = pad16(w * M + field_of<AT>(tf, k));
+        va[k] = la[s];
+        vb[k] = lb[s];
+    }
+}
+
+// forward stages of two polynomials in lockstep, ct32_loose (canonical inputs: values end below (1 + 2 LP) q <= 25 q)
+template <int LP>
+__device__ __forceinline__ void sq_fwd2(u32 (&va)[16], u32 (&vb)[16], u32 *la, u32 *lb, const Tw32 *ltw, const Tw32 *gtw, u32 w, u32 tf,
+                                        u32 q, u32 q2) {
+    using C = ContigCfg<LP>;
+    Tw32 t[15];
+    load_tw32<C::R0>(t, gtw, 1u);
+    round_fwd32_tw<C::R0, 0, true>(va, t, q, q2);
+    round_fwd32_tw<C::R0, 0, true>(vb, t, q, q2);
+    {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        load_tw32<4>(t, C::in_lds(1) ? ltw : gtw, (1u << LS) + (tf >> A));
+        sq_exchange2<LP, C::A0, A, true>(va, vb, la, lb, w, tf);
+        round_fwd32_tw<4, 0, true>(va, t, q, q2);
+        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        load_tw32<4>(t, C::in_lds(2) ? ltw : gtw, (1u << LS) + (tf >> A));
+        sq_exchange2<LP, C::a_of(1), A, false>(va, vb, la, lb, w, tf);
+        round_fwd32_tw<4, 0, true>(va, t, q, q2);
+        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+    }
+    static_assert(C::NR >= 2 && C::NR <= 3, "256 .. 4096 points");
+}
+
+// forward stages of one polynomial (window [LP-4, LP) -> [0,4)); FRESH: nobody has touched the tile
+template <int LP>
+__device__ __forceinline__ void sq_fwd1(u32 (&v)[16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 w, u32 tf, u32 q, u32 q2) {
+    using C = ContigCfg<LP>;
+    Tw32 t[15];
+    load_tw32<C::R0>(t, gtw, 1u);
+    round_fwd32_tw<C::R0, 0, true>(v, t, q, q2);
+    {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        load_tw32<4>(t, C::in_lds(1) ? ltw : gtw, (1u << LS) + (tf >> A));
+        exchange32<LP, C::A0, A, true>(v, lds, w, tf);
+        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        load_tw32<4>(t, C::in_lds(2) ? ltw : gtw, (1u << LS) + (tf >> A));
+        exchange32<LP, C::a_of(1), A, false>(v, lds, w, tf);
+        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+    }
+}
+// inverse stages (gs32, values below 2q throughout): window [0,4) -> [LP-4, LP); FRESH: the tile is untouched
+template <int LP, bool FRESH>
+__device__ __forceinline__ void sq_inv1(u32 (&v)[16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 w, u32 tf, u32 q, u32 q2) {
+    using C = ContigCfg<LP>;
+    Tw32 t[15];
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        load_tw32<4>(t, C::in_lds(2) ? ltw : gtw, (1u << LS) + (tf >> A));
+        round_inv32_tw<4>(v, t, q, q2);
+        constexpr int A1 = C::a_of(1), LS1 = C::ls0_of(1);
+        load_tw32<4>(t, C::in_lds(1) ? ltw : gtw, (1u << LS1) + (tf >> A1));      // ahead of the exchange
+        exchange32<LP, A, A1, FRESH>(v, lds, w, tf);
+    } else {
+        constexpr int A1 = C::a_of(1), LS1 = C::ls0_of(1);
+        load_tw32<4>(t, C::in_lds(1) ? ltw : gtw, (1u << LS1) + (tf >> A1));
+    }
+    {
+        constexpr int A = C::a_of(1);
+        round_inv32_tw<4>(v, t, q, q2);
+        load_tw32<C::R0>(t, gtw, 1u);
+        exchange32<LP, A, C::A0, FRESH && (C::NR <= 2)>(v, lds, w, tf);
+    }
+    round_inv32_tw<C::R0>(v, t, q, q2);
+}
+
+// a row of n 64-bit words at the positions of window [LP-4, LP): register k = word k * TPB + tf (512 bytes per wave)
+template <int LP>
+__device__ __forceinline__ void sq_load_natural(u32 (&v)[16], const u64 *__restrict__ src, u32 tf, u32 q, u32 bq) {
+    using C = ContigCfg<LP>;
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TPB + tf], q, bq), q);   // words are below q; any 32-bit word is reduced
+}
+
+// x * y * 2^-32 mod q, in [0, 2q), for x * y < q * 2^32 (Montgomery; q is odd: 2n divides q - 1)
+__device__ __forceinline__ u32 sq_mont(u32 x, u32 y, u32 q, u32 qinv_neg) {
+    const u64 t = (u64)x * y;
+    const u32 m = (u32)t * qinv_neg;
+    return (u32)((t + (u64)m * q) >> 32);
+}
+
+struct SqLds {
+    u32 *tile_a, *tile_b;
+    Tw32 *ltw;
+};
+template <int LP, bool TWO>
+__device__ __forceinline__ SqLds sq_lds(unsigned char *smem, const Tw32 *gtw, u32 tid) {
+    using K = SqCfg<LP>;
+    SqLds l;
+    l.tile_a = reinterpret_cast<u32 *>(smem);
+    l.tile_b = reinterpret_cast<u32 *>(smem + K::TILE_BYTES);
+    l.ltw = reinterpret_cast<Tw32 *>(smem + (TWO ? 2 : 1) * K::TILE_BYTES);
+    stage_tw32(l.ltw, gtw, ContigCfg<LP>::LTW_N, tid);
+    __syncthreads();
+    return l;
+}
+
+// ---- forward: natural order in, the reference's bit-reversed order out --------------------------------------------------
+template <int LP>
+__global__ __launch_bounds__(256) void sq_forward_kernel(SmallQArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const SqLds l = sq_lds<LP, false>(smem_raw, a.tw_fwd, tid);
+    const u64 R0 = (u64)blockIdx.x * C::W;
+    const u64 row = min(R0 + w, a.rows - 1);                    // idle units redo the last row and store nothing
+    u32 v[16];
+    sq_load_natural<LP>(v, a.a + row * C::M, tf, a.q, a.bq);
+    sq_fwd1<LP>(v, l.tile_a, l.ltw, a.tw_fwd, w, tf, a.q, 2u * a.q);
+    // window [0,4): register k = output word 16 tf + k.  Through the tile so that a wave stores 512 contiguous bytes
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) l.tile_a[pad16(w * C::M + tf * 16u + k)] = csub_u32(barrett2p_32(v[k], a.q, a.bq), a.q);
+    __syncthreads();
+    if (R0 + w < a.rows) {
+        u64 *__restrict__ dst = a.out + row * C::M;
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = l.tile_a[pad16(w * C::M + (u32)k * C::TPB + tf)];
+    }
+}
+
+// ---- inverse: bit-reversed order in, natural order out, n^-1 folded in --------------------------------------------------
+template <int LP>
+__global__ __launch_bounds__(256) void sq_inverse_kernel(SmallQArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    const SqLds l = sq_lds<LP, false>(smem_raw, a.tw_inv, tid);
+    const u64 R0 = (u64)blockIdx.x * C::W;
+    const u64 row = min(R0 + w, a.rows - 1);
+    {   // coalesced loads, through the tile into window [0,4)
+        const u64 *__restrict__ src = a.a + row * C::M;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            l.tile_a[pad16(w * C::M + (u32)k * C::TPB + tf)] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TPB + tf], a.q, a.bq), a.q);
+    }
+    __syncthreads();
+    u32 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = l.tile_a[pad16(w * C::M + tf * 16u + k)];
+    sq_inv1<LP, false>(v, l.tile_a, l.ltw, a.tw_inv, w, tf, a.q, 2u * a.q);
+    if (R0 + w < a.rows) {
+        u64 *__restrict__ dst = a.out + row * C::M;
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = csub_u32(mul_shoup32(v[k], a.ninv, a.q), a.q);
+    }
+}
+
+// ---- Rq x Rq: forward(a), forward(b), pointwise product, inverse — one kernel -------------------------------------------
+template <int LP>
+__global__ __launch_bounds__(256) void sq_rq_mul_kernel(SmallQArgs a) {
+    using C = ContigCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
+    SqLds l;
+    {
+        using K = SqCfg<LP>;
+        l.tile_a = reinterpret_cast<u32 *>(smem_raw);
+        l.tile_b = reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES);
+        l.ltw = reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES);
+        Tw32 *ltw_inv = l.ltw + C::LTW_N;
+        stage_tw32(l.ltw, a.tw_fwd, C::LTW_N, tid);
+        stage_tw32(ltw_inv, a.tw_inv, C::LTW_N, tid);
+        __syncthreads();
+    }
+    const Tw32 *ltw_inv = l.ltw + C::LTW_N;
+    const u64 R0 = (u64)blockIdx.x * C::W;
+    const u64 row = min(R0 + w, a.rows - 1);
+    const u32 q = a.q, q2 = 2u * q;
+    u32 va[16], vb[16];
+    sq_load_natural<LP>(va, a.a + row * C::M, tf, q, a.bq);
+    sq_load_natural<LP>(vb, a.b + row * C::M, tf, q, a.bq);
+    sq_fwd2<LP>(va, vb, l.tile_a, l.tile_b, l.ltw, a.tw_fwd, w, tf, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; k++)                                // both below 2q: the product is below q * 2^32
+        va[k] = sq_mont(barrett2p_32(va[k], q, a.bq), barrett2p_32(vb[k], q, a.bq), q, a.qinv_neg);
+    sq_inv1<LP, false>(va, l.tile_a, ltw_inv, a.tw_inv, w, tf, q, q2);
+    if (R0 + w < a.rows) {
+        u64 *__restrict__ dst = a.out + row * C::M;
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = csub_u32(mul_shoup32(va[k], a.ninv_mont, q), q);   // * n^-1 * 2^32
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+bool smallq_supported(uint64_t q, unsigned log_n) {
+    return q >= 3 && (q & 1) && q * 25 < (1ull << 32) && log_n >= 8 && log_n <= 12;
+}
+
+template <typename K>
+static hipError_t sq_launch(K kernel, const char *name, int lp, size_t lds, unsigned units, const SmallQArgs &a, hipStream_t st) {
+    if (a.rows == 0) return hipSuccess;
+    const u64 grid = (a.rows + units - 1) / units;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)kernel, lds)) return e;
+    KernelTimer kt(name, lp, st);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+#define FHE_SQ_SWITCH(KERNEL, NAME, TILES, TWS)                                                                                         \
+    switch (log_n) {                                                                                                                    \
+        case 8: return sq_launch(KERNEL<8>, NAME, 8, TILES * SqCfg<8>::TILE_BYTES + TWS * SqCfg<8>::TW_BYTES, ContigCfg<8>::W, a, st);      \
+        case 9: return sq_launch(KERNEL<9>, NAME, 9, TILES * SqCfg<9>::TILE_BYTES + TWS * SqCfg<9>::TW_BYTES, ContigCfg<9>::W, a, st);      \
+        case 10: return sq_launch(KERNEL<10>, NAME, 10, TILES * SqCfg<10>::TILE_BYTES + TWS * SqCfg<10>::TW_BYTES, ContigCfg<10>::W, a, st); \
+        case 11: return sq_launch(KERNEL<11>, NAME, 11, TILES * SqCfg<11>::TILE_BYTES + TWS * SqCfg<11>::TW_BYTES, ContigCfg<11>::W, a, st); \
+        case 12: return sq_launch(KERNEL<12>, NAME, 12, TILES * SqCfg<12>::TILE_BYTES + TWS * SqCfg<12>::TW_BYTES, ContigCfg<12>::W, a, st); \
+    }                                                                                                                                   \
+    return hipErrorNotSupported;
+
+hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st) { FHE_SQ_SWITCH(sq_forward_kernel, "sq_forward", 1, 1) }
+hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) { FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1) }
+hipError_t launch_sq_rq_mul(const SmallQArgs &a, int log_n, hipStream_t st) { FHE_SQ_SWITCH(sq_rq_mul_kernel, "sq_rq_mul", 2, 2) }
+#undef FHE_SQ_SWITCH
+
+}  // namespace fhe

@@ -1,0 +1,25 @@
+// smallq.hpp — internal interface of the small-modulus transforms and product (smallq.hip).  Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ntt_kernels.hpp"
+
+namespace fhe {
+
+struct SmallQArgs {
+    const Tw32 *tw_fwd, *tw_inv;   // the plan's roots / roots_inv as 32-bit Shoup pairs (DevicePlan::tw32_*)
+    uint32_t q, bq;                // modulus, floor(2^32 / q)
+    uint32_t qinv_neg;             // -q^-1 mod 2^32
+    Tw32 ninv, ninv_mont;          // n^-1 mod q; n^-1 * 2^32 mod q (after a Montgomery product)
+    const u64 *a, *b;              // rows of n 64-bit words (b: the product's second operand)
+    u64 *out;
+    u64 rows;
+};
+
+bool smallq_supported(uint64_t q, unsigned log_n);
+hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st);
+hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st);
+hipError_t launch_sq_rq_mul(const SmallQArgs &a, int log_n, hipStream_t st);
+
+}  // namespace fhe

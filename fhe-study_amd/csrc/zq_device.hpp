@@ -34,6 +34,8 @@ struct Tw {  // one twiddle: w and its Shoup companion floor(w*2^64/q)
 };
 
 // Modulus constants handed to kernels by value (live in SGPRs).
+struct Tw32 { uint32_t w, wp; };   // the small-modulus kernels (digit32 / bfv32 / smallq): twiddle and floor(w * 2^32 / p)
+
 struct Mod {
     u64 q;      // modulus, 3 <= q < 2^62
     u64 q2;     // 2q

@@ -387,6 +387,41 @@ def test_fused_key_switch(pkg, oracle, q, n, k, l, batch):
         assert np.array_equal(_u64(dout3), want[:nb])
 
 
+@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 37), (Q16, 1024, 9), (Q16, 4096, 5), (12289, 2048, 3), (Q16, 512, 1)])
+def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
+    """q < 2^32 / 25, 2^8 <= n <= 2^12: NTT::ntt / NTT::intt / Rq x Rq (arith/src/ntt.rs:44-104, ring_nq.rs:586-607) run
+    in one 32-bit word per coefficient (smallq.hip) — the same canonical words, in the same order, as the oracle's; the
+    kernel timer names prove the path; cached-evals products (61-bit kernels) consume its transforms unchanged."""
+    import torch
+
+    B = pkg.binding
+    plan = pkg.Plan(q, n)
+    rng = np.random.default_rng(q + n)
+    a = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    b = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    a[0, :3] = [0, q - 1, 1]
+    dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
+    da, db = dev(a), dev(b)
+    A, r, c = torch.empty_like(da), torch.empty_like(da), torch.empty_like(da)
+    B.kernel_timing_reset(); B.kernel_timing_enable(True)
+    plan.forward_dev(da.data_ptr(), A.data_ptr(), batch)
+    plan.inverse_dev(A.data_ptr(), r.data_ptr(), batch)
+    plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch)
+    torch.cuda.synchronize()
+    names = set(B.kernel_timing_read())
+    B.kernel_timing_enable(False)
+    lg = n.bit_length() - 1
+    assert {f"sq_forward_{lg}", f"sq_inverse_{lg}", f"sq_rq_mul_{lg}"} <= names, names
+    assert np.array_equal(_u64(A), oracle.ntt(q, n, a).reshape(batch, n))
+    assert np.array_equal(_u64(r), a)
+    assert np.array_equal(_u64(c), oracle.rq_mul(q, n, a, b)[0].reshape(batch, n))
+    # the transforms feed the 61-bit product kernels as cached evals (ring_nq.rs:590-599)
+    Bv, c2 = torch.empty_like(db), torch.empty_like(da)
+    plan.forward_dev(db.data_ptr(), Bv.data_ptr(), batch)
+    plan.rq_mul_dev(A.data_ptr(), Bv.data_ptr(), c2.data_ptr(), batch, a_is_evals=True, b_is_evals=True)
+    assert torch.equal(c2, c)
+
+
 def test_small_prime_products_on_random_shapes(pkg, oracle):
     """A seeded sweep over the shapes digit32.hip serves (k = 1; n = 2^8 .. 2^12; any 1 <= l <= 64; batches that do and do
     not fill whole steps / parts / tail workgroups): external product and key switch, plain and prepared keys, word for

@@ -18,109 +18,11 @@
 // Arithmetic, rounding and wrap-around semantics are those of zring.hip's epilogues (same device functions); results are
 // bit-exact with them and with the oracle.
 #include "bfv32.hpp"
-#include "ntt32_rounds.hpp"
+#include "ntt32_big.hpp"
 
 #include <type_traits>
 
 namespace fhe {
-
-// rounds of a 2^LP-point transform held by ONE workgroup (the index algebra of ContigCfg with W = 1): 2^LP / 16 logical
-// threads of 16 coefficients each, VT of them per thread.  VT = 1: a 16384-point transform is a workgroup of 1024
-// threads, one per CU (68 KiB of LDS, 128 VGPRs).  VT = 2 (512 threads, two workgroups per CU, so that one computes while
-// the other waits at a barrier) needs 32 coefficients + 30 twiddle registers per thread inside the same 128: it spills
-// (57-373 registers); 512 threads with 256 registers (one workgroup per CU, more work per thread) ran 2048 BFV
-// products in 3.52 ms against 2.86.  VT stays a parameter.
-template <int LP>
-struct Big32 {
-    static constexpr int VT = 1;                               // logical threads (register windows of 16 coefficients) per thread
-    static constexpr int M = 1 << LP, TH = M / (16 * VT);
-    static constexpr int NR = (LP + 3) / 4, R0 = LP - 4 * (NR - 1), A0 = LP - 4;
-    static constexpr int LTW_LOG = 8, LTW_N = 1 << LTW_LOG;
-    static constexpr size_t TILE_BYTES = (size_t)(M + M / 16) * 4, TW_BYTES = (size_t)LTW_N * sizeof(Tw32);
-    static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
-    static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
-    static constexpr bool in_lds(int j) { return ls0_of(j) + (j == 0 ? R0 : 4) <= LTW_LOG; }
-    static_assert(LP >= 11 && LP <= 14 && NR >= 3 && NR <= 4, "2048 .. 16384 points");
-};
-
-// the register windows of a thread through the tile: barrier (the tile may have been gathered from by the transform or
-// exchange before this one), scatter, barrier, gather
-template <int LP, int AF, int AT>
-__device__ __forceinline__ void exchange_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, u32 tf) {
-    using C = Big32<LP>;
-    constexpr u32 TH = C::TH;
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < C::VT; s++)
-#pragma unroll
-        for (int k = 0; k < 16; k++) lds[pad16(field_of<AF>(tf + s * TH, k))] = v[s][k];
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < C::VT; s++)
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[s][k] = lds[pad16(field_of<AT>(tf + s * TH, k))];
-}
-
-// Forward stages with ct32_loose: the bound of the values grows by 2p per stage from B·p and must stay below 25p, so
-// the values are brought below 2p (barrett2p_32) before a round that would pass it.  Round 0 starts at stage I0.
-// Ends with the values in window [0,4) (16 consecutive points per logical thread), below 25p.
-template <int LP, int J, int B>
-__device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq) {
-    using C = Big32<LP>;
-    if constexpr (J < C::NR) {
-        constexpr int A = C::a_of(J), LS = C::ls0_of(J);
-        Tw32 t[C::VT][15];                                      // requested before the exchange: see load_tw32
-#pragma unroll
-        for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J) ? ltw : gtw, (1u << LS) + ((tf + s * C::TH) >> A));
-        exchange_big<LP, C::a_of(J - 1), A>(v, lds, tf);
-        constexpr bool RED = B + 8 > 25;
-#pragma unroll
-        for (int s = 0; s < C::VT; s++) {
-            if constexpr (RED) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) v[s][k] = barrett2p_32(v[s][k], p, bq);
-            }
-            round_fwd32_tw<4, 0, true>(v[s], t[s], p, p2);
-        }
-        fwd_round_big<LP, J + 1, (RED ? 2 : B) + 8>(v, lds, ltw, gtw, tf, p, p2, bq);
-    }
-}
-template <int LP, int I0>
-__device__ __forceinline__ void fwd_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq) {
-    using C = Big32<LP>;
-#pragma unroll
-    for (int s = 0; s < C::VT; s++) round_fwd32<C::R0, I0, true>(v[s], ltw, 1u, p, p2);
-    fwd_round_big<LP, 1, 1 + 2 * C::R0>(v, lds, ltw, gtw, tf, p, p2, bq);
-}
-// Inverse stages (gs32: values below 2p throughout): window [0,4) -> window [LP-4, LP), not yet scaled.  `t` holds the
-// twiddles of round J on entry (requested by the caller / the round before, ahead of the exchange).
-template <int LP, int J>
-__device__ __forceinline__ void inv_round_big(u32 (&v)[Big32<LP>::VT][16], Tw32 (&t)[Big32<LP>::VT][15], u32 *lds, const Tw32 *ltw, const Tw32 *gtw,
-                                              u32 tf, u32 p, u32 p2) {
-    using C = Big32<LP>;
-    constexpr int A = C::a_of(J);
-#pragma unroll
-    for (int s = 0; s < C::VT; s++) round_inv32_tw<4>(v[s], t[s], p, p2);
-    if constexpr (J > 1) {
-        constexpr int AN = C::a_of(J - 1), LSN = C::ls0_of(J - 1);
-#pragma unroll
-        for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J - 1) ? ltw : gtw, (1u << LSN) + ((tf + s * C::TH) >> AN));
-    }
-    exchange_big<LP, A, C::a_of(J - 1)>(v, lds, tf);
-}
-template <int LP>
-__device__ __forceinline__ void inv_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2) {
-    using C = Big32<LP>;
-    Tw32 t[C::VT][15];
-    constexpr int JT = C::NR - 1;
-#pragma unroll
-    for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(JT) ? ltw : gtw, (1u << C::ls0_of(JT)) + ((tf + s * C::TH) >> C::a_of(JT)));
-    if constexpr (C::NR > 3) inv_round_big<LP, 3>(v, t, lds, ltw, gtw, tf, p, p2);
-    inv_round_big<LP, 2>(v, t, lds, ltw, gtw, tf, p, p2);
-    inv_round_big<LP, 1>(v, t, lds, ltw, gtw, tf, p, p2);
-#pragma unroll
-    for (int s = 0; s < C::VT; s++) round_inv32<C::R0>(v[s], ltw, 1u, p, p2);
-}
 
 // x * y * 2^-32 mod p, in [0, 2p), for x * y < p * 2^32 (Montgomery; the factor is folded into the inverse's scaling)
 __device__ __forceinline__ u32 mont32(u32 x, u32 y, u32 p, u32 pinv_neg) {

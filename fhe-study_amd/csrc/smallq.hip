@@ -5,14 +5,16 @@
 // transform (same psi, same tables, same bit-reversed layout: the plan's) runs in one word per coefficient with the
 // butterflies of ntt32_rounds.hpp: 3 multiplies + 3 additions, no conditional subtraction on the forward side.  The
 // interface stays 64-bit words; a transform is then bound by its 16 n bytes of traffic instead of by multiplier issue.
-// Single-pass sizes 2^8 <= n <= 2^12; everything else (and FHE_EXT32=0) keeps the 61-bit kernels.  Same values, word for
+// Single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
+// one workgroup of n / 16 threads around a whole-transform LDS tile, ntt32_big.hpp); everything else (and FHE_EXT32=0)
+// keeps the 61-bit kernels.  Same values, word for
 // word: every result is canonical modulo the same q.
 //   sq_forward_kernel   n words in (natural order) -> forward transform -> n words out (the reference's bit-reversed order)
 //   sq_inverse_kernel   the inverse, n^-1 folded in
 //   sq_rq_mul_kernel    both forward transforms in lockstep (one twiddle load for both), pointwise Montgomery product,
 //                       inverse transform — the whole product on chip, as rq_mul_fused_kernel does for 61-bit q
 #include "smallq.hpp"
-#include "ntt32_rounds.hpp"
+#include "ntt32_big.hpp"
 
 namespace fhe {
 
@@ -233,9 +235,87 @@ __global__ __launch_bounds__(256) void sq_rq_mul_kernel(SmallQArgs a) {
     }
 }
 
+// ---- n = 8192 / 16384: one workgroup of n / 16 threads per polynomial (ntt32_big.hpp) ------------------------------------
+template <int LP>
+__device__ __forceinline__ const Tw32 *sq_big_stage(unsigned char *smem, const Tw32 *gtw, u32 tid, int slot) {
+    using C = Big32<LP>;
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem + C::TILE_BYTES + slot * C::TW_BYTES);
+    stage_tw32<C::TH>(ltw, gtw, C::LTW_N, tid);
+    return ltw;
+}
+template <int LP>
+__device__ __forceinline__ void sq_big_load(u32 (&v)[1][16], const u64 *__restrict__ src, u32 tf, u32 q, u32 bq) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[0][k] = csub_u32(barrett2p_32((u32)src[(u32)k * Big32<LP>::TH + tf], q, bq), q);
+}
+template <int LP>
+__global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_forward_kernel(SmallQArgs a) {
+    using C = Big32<LP>;
+    static_assert(C::VT == 1, "one register window per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *lds = reinterpret_cast<u32 *>(smem_raw);
+    const u32 tf = threadIdx.x;
+    const Tw32 *ltw = sq_big_stage<LP>(smem_raw, a.tw_fwd, tf, 0);
+    __syncthreads();
+    const u64 row = blockIdx.x;
+    u32 v[1][16];
+    sq_big_load<LP>(v, a.a + row * C::M, tf, a.q, a.bq);
+    fwd_big<LP, 0>(v, lds, ltw, a.tw_fwd, tf, a.q, 2u * a.q, a.bq);
+    __syncthreads();                                            // window [0,4) out through the tile: 512 contiguous bytes per wave
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16(tf * 16u + k)] = csub_u32(barrett2p_32(v[0][k], a.q, a.bq), a.q);
+    __syncthreads();
+    u64 *__restrict__ dst = a.out + row * C::M;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = lds[pad16((u32)k * C::TH + tf)];
+}
+template <int LP>
+__global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_inverse_kernel(SmallQArgs a) {
+    using C = Big32<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *lds = reinterpret_cast<u32 *>(smem_raw);
+    const u32 tf = threadIdx.x;
+    const Tw32 *ltw = sq_big_stage<LP>(smem_raw, a.tw_inv, tf, 0);
+    const u64 row = blockIdx.x;
+    const u64 *__restrict__ src = a.a + row * C::M;
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16((u32)k * C::TH + tf)] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TH + tf], a.q, a.bq), a.q);
+    __syncthreads();
+    u32 v[1][16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[0][k] = lds[pad16(tf * 16u + k)];
+    inv_big<LP>(v, lds, ltw, a.tw_inv, tf, a.q, 2u * a.q);      // its exchanges start with a barrier
+    u64 *__restrict__ dst = a.out + row * C::M;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(mul_shoup32(v[0][k], a.ninv, a.q), a.q);
+}
+template <int LP>
+__global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQArgs a) {
+    using C = Big32<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *lds = reinterpret_cast<u32 *>(smem_raw);
+    const u32 tf = threadIdx.x;
+    const Tw32 *ltw = sq_big_stage<LP>(smem_raw, a.tw_fwd, tf, 0);
+    const Tw32 *ltw_inv = sq_big_stage<LP>(smem_raw, a.tw_inv, tf, 1);
+    __syncthreads();
+    const u64 row = blockIdx.x;
+    const u32 q = a.q, q2 = 2u * q;
+    u32 va[1][16], vb[1][16];
+    sq_big_load<LP>(va, a.a + row * C::M, tf, q, a.bq);
+    fwd_big<LP, 0>(va, lds, ltw, a.tw_fwd, tf, q, q2, a.bq);
+    sq_big_load<LP>(vb, a.b + row * C::M, tf, q, a.bq);
+    fwd_big<LP, 0>(vb, lds, ltw, a.tw_fwd, tf, q, q2, a.bq);
+#pragma unroll
+    for (int k = 0; k < 16; k++) va[0][k] = sq_mont(barrett2p_32(va[0][k], q, a.bq), barrett2p_32(vb[0][k], q, a.bq), q, a.qinv_neg);
+    inv_big<LP>(va, lds, ltw_inv, a.tw_inv, tf, q, q2);
+    u64 *__restrict__ dst = a.out + row * C::M;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(mul_shoup32(va[0][k], a.ninv_mont, q), q);
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 bool smallq_supported(uint64_t q, unsigned log_n) {
-    return q >= 3 && (q & 1) && q * 25 < (1ull << 32) && log_n >= 8 && log_n <= 12;
+    return q >= 3 && (q & 1) && q * 25 < (1ull << 32) && log_n >= 8 && log_n <= 14;
 }
 
 template <typename K>
@@ -258,9 +338,32 @@ static hipError_t sq_launch(K kernel, const char *name, int lp, size_t lds, unsi
     }                                                                                                                                   \
     return hipErrorNotSupported;
 
-hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st) { FHE_SQ_SWITCH(sq_forward_kernel, "sq_forward", 1, 1) }
-hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) { FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1) }
-hipError_t launch_sq_rq_mul(const SmallQArgs &a, int log_n, hipStream_t st) { FHE_SQ_SWITCH(sq_rq_mul_kernel, "sq_rq_mul", 2, 2) }
+template <typename K>
+static hipError_t sq_big_launch(K kernel, const char *name, int lp, size_t lds, unsigned th, const SmallQArgs &a, hipStream_t st) {
+    if (a.rows == 0) return hipSuccess;
+    if (a.rows > 0x7fffffffull) return hipErrorInvalidValue;
+    if (hipError_t e = allow_big_lds((const void *)kernel, lds)) return e;
+    KernelTimer kt(name, lp, st);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)a.rows), dim3(th), lds, st, a);
+    return hipGetLastError();
+}
+#define FHE_SQ_BIG(KERNEL, NAME, TWS)                                                                                             \
+    if (log_n == 13) return sq_big_launch(KERNEL<13>, NAME, 13, Big32<13>::TILE_BYTES + TWS * Big32<13>::TW_BYTES, Big32<13>::TH, a, st); \
+    if (log_n == 14) return sq_big_launch(KERNEL<14>, NAME, 14, Big32<14>::TILE_BYTES + TWS * Big32<14>::TW_BYTES, Big32<14>::TH, a, st);
+
+hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st) {
+    FHE_SQ_BIG(sq_big_forward_kernel, "sq_forward", 1)
+    FHE_SQ_SWITCH(sq_forward_kernel, "sq_forward", 1, 1)
+}
+hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) {
+    FHE_SQ_BIG(sq_big_inverse_kernel, "sq_inverse", 1)
+    FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1)
+}
+hipError_t launch_sq_rq_mul(const SmallQArgs &a, int log_n, hipStream_t st) {
+    FHE_SQ_BIG(sq_big_rq_mul_kernel, "sq_rq_mul", 2)
+    FHE_SQ_SWITCH(sq_rq_mul_kernel, "sq_rq_mul", 2, 2)
+}
 #undef FHE_SQ_SWITCH
+#undef FHE_SQ_BIG
 
 }  // namespace fhe

@@ -387,9 +387,10 @@ def test_fused_key_switch(pkg, oracle, q, n, k, l, batch):
         assert np.array_equal(_u64(dout3), want[:nb])
 
 
-@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 37), (Q16, 1024, 9), (Q16, 4096, 5), (12289, 2048, 3), (Q16, 512, 1)])
+@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 37), (Q16, 1024, 9), (Q16, 4096, 5), (12289, 2048, 3), (Q16, 512, 1),
+                                        (Q16, 8192, 3), (Q16, 16384, 2), (786433, 8192, 2)])       # one workgroup of n / 16 threads
 def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
-    """q < 2^32 / 25, 2^8 <= n <= 2^12: NTT::ntt / NTT::intt / Rq x Rq (arith/src/ntt.rs:44-104, ring_nq.rs:586-607) run
+    """q < 2^32 / 25, 2^8 <= n <= 2^14: NTT::ntt / NTT::intt / Rq x Rq (arith/src/ntt.rs:44-104, ring_nq.rs:586-607) run
     in one 32-bit word per coefficient (smallq.hip) — the same canonical words, in the same order, as the oracle's; the
     kernel timer names prove the path; cached-evals products (61-bit kernels) consume its transforms unchanged."""
     import torch

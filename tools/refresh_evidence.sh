@@ -20,6 +20,7 @@ if [ "$2" = "collect" ]; then
   cp $OUT/rq_mul_throughput.txt profiles/${TAG}_rq_mul_throughput.txt
   cp $OUT/ubench_bfly.txt profiles/${TAG}_ubench_bfly.txt
   cp $OUT/bfv_kernels.txt profiles/${TAG}_bfv_kernels.txt
+  grep FHE_EXT32 $OUT/smallq.txt > profiles/${TAG}_small_modulus.txt
   cp $OUT/bench_2ranks.json profiles/${TAG}_bench_2ranks_one_gpu.json 2>/dev/null || true
   sed -i '/amdgpu.ids/d' profiles/${TAG}_*.txt
   exit 0
@@ -79,6 +80,8 @@ timeout -k 10 300 python tools/mulbench.py > $OUT/rq_mul_throughput.txt 2>&1
 timeout -k 10 300 python tools/bench_next.py > $OUT/bench_next_rows.txt 2>&1 || true
 [ -x tools/ubench_bfly ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/ubench_bfly tools/ubench_bfly.hip
 timeout -k 10 200 ./tools/ubench_bfly > $OUT/ubench_bfly.txt 2>&1 || true
+timeout -k 10 200 python tools/smallq_bench.py > $OUT/smallq.txt 2>&1 || true
+FHE_EXT32=0 timeout -k 10 200 python tools/smallq_bench.py >> $OUT/smallq.txt 2>&1 || true
 timeout -k 10 100 python tools/abl_bfv.py > $OUT/bfv_kernels.txt 2>&1 || true
 FHE_EXT32=0 timeout -k 10 100 python tools/abl_bfv.py >> $OUT/bfv_kernels.txt 2>&1 || true
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt

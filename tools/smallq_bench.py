@@ -7,7 +7,7 @@ import numpy as np, torch
 import fhe_study_amd as pkg
 q = 65537
 rng = np.random.default_rng(1)
-for n, batch in ((1024, 262144), (4096, 65536)):
+for n, batch in ((1024, 262144), (4096, 65536), (8192, 32768), (16384, 16384)):
     plan = pkg.Plan(q, n)
     a = torch.from_numpy(rng.integers(0, q, (batch, n), dtype=np.int64)).cuda()
     b = torch.from_numpy(rng.integers(0, q, (batch, n), dtype=np.int64)).cuda()

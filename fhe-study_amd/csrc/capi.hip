@@ -595,7 +595,7 @@ extern "C" int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_
 }
 
 // small moduli (q < 2^32 / 25, 2^8 <= n <= 2^12): one 32-bit word per coefficient (smallq.hip); FHE_EXT32=0 keeps the 61-bit kernels
-static bool smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a) {
+bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a) {
     if (!dp.tw32_fwd || !fhe_ext32_enabled()) return false;
     const u64 q = plan->q;
     a->tw_fwd = dp.tw32_fwd; a->tw_inv = dp.tw32_inv;
@@ -624,7 +624,7 @@ extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, v
     if (rc != FHE_OK) return rc;
     if ((rc = check_canonical_dev(plan, d_in, batch * plan->n, (hipStream_t)hip_stream, "fhe_ntt_forward_dev")) != FHE_OK) return rc;
     fhe::SmallQArgs sq{};
-    if (smallq_args(plan, dp, &sq)) {
+    if (fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_in; sq.out = (u64 *)d_out; sq.rows = batch;
         hipError_t se = fhe::launch_sq_forward(sq, (int)dp.log_n, (hipStream_t)hip_stream);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_forward_kernel");
@@ -647,7 +647,7 @@ extern "C" int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, v
     if (rc != FHE_OK) return rc;
     if ((rc = check_canonical_dev(plan, d_in, batch * plan->n, (hipStream_t)hip_stream, "fhe_ntt_inverse_dev")) != FHE_OK) return rc;
     fhe::SmallQArgs sq{};
-    if (smallq_args(plan, dp, &sq)) {
+    if (fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_in; sq.out = (u64 *)d_out; sq.rows = batch;
         hipError_t se = fhe::launch_sq_inverse(sq, (int)dp.log_n, (hipStream_t)hip_stream);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_inverse_kernel");
@@ -688,7 +688,7 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
 
     // small modulus, plain product (no cached evals in or out): the whole product in 32-bit words (smallq.hip)
     fhe::SmallQArgs sq{};
-    if (!a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out && smallq_args(plan, dp, &sq)) {
+    if (!a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out && fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_a; sq.b = (const u64 *)d_b; sq.out = (u64 *)d_c; sq.rows = batch;
         hipError_t se = fhe::launch_sq_rq_mul(sq, (int)dp.log_n, st);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_rq_mul_kernel");

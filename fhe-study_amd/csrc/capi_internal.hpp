@@ -47,6 +47,9 @@ void fhe_workspace_free_all();
 void fhe_ext32_free_all();   // zring.hip: tables of the two-small-prime (27-bit) products (digit32.hip)
 namespace fhe { struct Ext32Args; }
 int fhe_ext32_tables(uint64_t n, fhe::Ext32Args *a);   // fills the per-prime fields for the current device
+namespace fhe { struct SmallQArgs; }
+// fills the modulus-dependent fields when the plan has a 32-bit form on this device (smallq.hip) and FHE_EXT32 is on
+bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a);
 bool fhe_ext32_enabled();                              // FHE_EXT32=0 keeps every product on the 61-bit kernels
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
 int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);

@@ -21,6 +21,7 @@
 #include "capi_internal.hpp"
 #include "digit_mac.hpp"
 #include "digit32.hpp"
+#include "smallq.hpp"
 #include "zq_device.hpp"
 #include "mac_kernel.hpp"
 
@@ -147,11 +148,24 @@ __global__ __launch_bounds__(256) void ks_tail_kernel(const u64 *__restrict__ gl
 }  // namespace fhe
 
 
+// the transforms of the batch surfaces: the 32-bit kernels where the plan has them (small q: smallq.hip; in == out allowed)
 static int fwd(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
+    fhe::SmallQArgs sq{};
+    if (fhe_smallq_args(plan, dp, &sq)) {
+        sq.a = in; sq.out = out; sq.rows = rows;
+        hipError_t se = fhe::launch_sq_forward(sq, (int)dp.log_n, st);
+        return se == hipSuccess ? FHE_OK : fhe_hip_fail(se, "glue forward NTT (32-bit)");
+    }
     hipError_t e = fhe::launch_ntt_forward(dp, in, out, rows, fhe_batch_tile_for(plan), st);
     return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "glue forward NTT");
 }
 static int inv(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *in, u64 *out, u64 rows, hipStream_t st) {
+    fhe::SmallQArgs sq{};
+    if (fhe_smallq_args(plan, dp, &sq)) {
+        sq.a = in; sq.out = out; sq.rows = rows;
+        hipError_t se = fhe::launch_sq_inverse(sq, (int)dp.log_n, st);
+        return se == hipSuccess ? FHE_OK : fhe_hip_fail(se, "glue inverse NTT (32-bit)");
+    }
     hipError_t e = fhe::launch_ntt_inverse(dp, in, nullptr, nullptr, out, rows, fhe_batch_tile_for(plan), st);
     return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "glue inverse NTT");
 }

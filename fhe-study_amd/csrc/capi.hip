@@ -608,6 +608,16 @@ bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::S
     a->ninv_mont = fhe::Tw32{(uint32_t)nm, (uint32_t)((nm << 32) / q)};
     return true;
 }
+// the u32 buffer between the passes of the two-pass sizes: its own workspace slot (the callers' slots 0 / 1 stay theirs)
+int fhe_smallq_scratch(unsigned log_n, uint64_t rows, hipStream_t st, fhe::SmallQArgs *a) {
+    a->mid = nullptr;
+    const size_t bytes = fhe::smallq_scratch_bytes(log_n, rows);
+    if (!bytes) return FHE_OK;
+    void *w = nullptr;
+    int rc = fhe_workspace_get(3, bytes, st, &w);
+    if (rc == FHE_OK) a->mid = (uint32_t *)w;
+    return rc;
+}
 
 // ---------------------------------------------------------------------------
 // device-resident entry points
@@ -626,6 +636,7 @@ extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, v
     fhe::SmallQArgs sq{};
     if (fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_in; sq.out = (u64 *)d_out; sq.rows = batch;
+        if ((rc = fhe_smallq_scratch(dp.log_n, batch, (hipStream_t)hip_stream, &sq)) != FHE_OK) return rc;
         hipError_t se = fhe::launch_sq_forward(sq, (int)dp.log_n, (hipStream_t)hip_stream);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_forward_kernel");
     }
@@ -649,6 +660,7 @@ extern "C" int fhe_ntt_inverse_dev(const fhe_ntt_plan *plan, const void *d_in, v
     fhe::SmallQArgs sq{};
     if (fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_in; sq.out = (u64 *)d_out; sq.rows = batch;
+        if ((rc = fhe_smallq_scratch(dp.log_n, batch, (hipStream_t)hip_stream, &sq)) != FHE_OK) return rc;
         hipError_t se = fhe::launch_sq_inverse(sq, (int)dp.log_n, (hipStream_t)hip_stream);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_inverse_kernel");
     }
@@ -688,7 +700,7 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
 
     // small modulus, plain product (no cached evals in or out): the whole product in 32-bit words (smallq.hip)
     fhe::SmallQArgs sq{};
-    if (!a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out && fhe_smallq_args(plan, dp, &sq)) {
+    if (!a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out && dp.log_n <= 14 && fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_a; sq.b = (const u64 *)d_b; sq.out = (u64 *)d_c; sq.rows = batch;
         hipError_t se = fhe::launch_sq_rq_mul(sq, (int)dp.log_n, st);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_rq_mul_kernel");

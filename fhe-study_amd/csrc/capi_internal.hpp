@@ -50,6 +50,7 @@ int fhe_ext32_tables(uint64_t n, fhe::Ext32Args *a);   // fills the per-prime fi
 namespace fhe { struct SmallQArgs; }
 // fills the modulus-dependent fields when the plan has a 32-bit form on this device (smallq.hip) and FHE_EXT32 is on
 bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a);
+int fhe_smallq_scratch(unsigned log_n, uint64_t rows, hipStream_t st, fhe::SmallQArgs *a);   // a->mid for n > 2^14
 bool fhe_ext32_enabled();                              // FHE_EXT32=0 keeps every product on the 61-bit kernels
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
 int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);

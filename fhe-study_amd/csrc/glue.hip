@@ -153,6 +153,7 @@ static int fwd(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *i
     fhe::SmallQArgs sq{};
     if (fhe_smallq_args(plan, dp, &sq)) {
         sq.a = in; sq.out = out; sq.rows = rows;
+        if (int rc = fhe_smallq_scratch(dp.log_n, rows, st, &sq)) return rc;
         hipError_t se = fhe::launch_sq_forward(sq, (int)dp.log_n, st);
         return se == hipSuccess ? FHE_OK : fhe_hip_fail(se, "glue forward NTT (32-bit)");
     }
@@ -163,6 +164,7 @@ static int inv(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const u64 *i
     fhe::SmallQArgs sq{};
     if (fhe_smallq_args(plan, dp, &sq)) {
         sq.a = in; sq.out = out; sq.rows = rows;
+        if (int rc = fhe_smallq_scratch(dp.log_n, rows, st, &sq)) return rc;
         hipError_t se = fhe::launch_sq_inverse(sq, (int)dp.log_n, st);
         return se == hipSuccess ? FHE_OK : fhe_hip_fail(se, "glue inverse NTT (32-bit)");
     }

@@ -46,14 +46,32 @@ __device__ __forceinline__ void exchange_big(u32 (&v)[Big32<LP>::VT][16], u32 *l
 // Forward stages with ct32_loose: the bound of the values grows by 2p per stage from B·p and must stay below 25p, so
 // the values are brought below 2p (barrett2p_32) before a round that would pass it.  Round 0 starts at stage I0.
 // Ends with the values in window [0,4) (16 consecutive points per logical thread), below 25p.
+// Block (s0, blk): the 2^LP points are block `blk` of a larger transform whose first s0 stages were done elsewhere
+// (smallq.hip's two-pass sizes); `ltw` is then the block's LOCAL table (stage_tw32_block), indexed as if the block were a
+// transform of its own, and the global table is indexed at (1 << (s0 + ls)) + (blk << ls) + H.  (0, 0): a whole transform.
+template <int LP, int J>
+__device__ __forceinline__ u32 big_t0(u32 s0, u32 blk, u32 H) {
+    using C = Big32<LP>;
+    constexpr int LS = C::ls0_of(J);
+    return C::in_lds(J) ? (1u << LS) + H : (1u << (s0 + LS)) + (blk << LS) + H;
+}
+template <int TH>
+__device__ __forceinline__ void stage_tw32_block(Tw32 *ltw, const Tw32 *__restrict__ tw, int count, u32 tid, u32 s0, u32 blk) {
+    for (u32 li = tid; li < (u32)count; li += TH) {
+        const u32 ls = 31u - (u32)__builtin_clz(li | 1u);       // entry 0 is never used: a copy of entry 1
+        const u32 l1 = li | (li == 0);
+        ltw[li] = tw[(1u << (s0 + ls)) + (blk << ls) + (l1 - (1u << ls))];
+    }
+}
 template <int LP, int J, int B>
-__device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq) {
+__device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq,
+                                              u32 s0 = 0, u32 blk = 0) {
     using C = Big32<LP>;
     if constexpr (J < C::NR) {
-        constexpr int A = C::a_of(J), LS = C::ls0_of(J);
+        constexpr int A = C::a_of(J);
         Tw32 t[C::VT][15];                                      // requested before the exchange: see load_tw32
 #pragma unroll
-        for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J) ? ltw : gtw, (1u << LS) + ((tf + s * C::TH) >> A));
+        for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A));
         exchange_big<LP, C::a_of(J - 1), A>(v, lds, tf);
         constexpr bool RED = B + 8 > 25;
 #pragma unroll
@@ -64,42 +82,45 @@ __device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *
             }
             round_fwd32_tw<4, 0, true>(v[s], t[s], p, p2);
         }
-        fwd_round_big<LP, J + 1, (RED ? 2 : B) + 8>(v, lds, ltw, gtw, tf, p, p2, bq);
+        fwd_round_big<LP, J + 1, (RED ? 2 : B) + 8>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
     }
 }
-template <int LP, int I0>
-__device__ __forceinline__ void fwd_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq) {
+// B0: the bound (in p) of the values on entry
+template <int LP, int I0, int B0 = 1>
+__device__ __forceinline__ void fwd_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq,
+                                        u32 s0 = 0, u32 blk = 0) {
     using C = Big32<LP>;
 #pragma unroll
     for (int s = 0; s < C::VT; s++) round_fwd32<C::R0, I0, true>(v[s], ltw, 1u, p, p2);
-    fwd_round_big<LP, 1, 1 + 2 * C::R0>(v, lds, ltw, gtw, tf, p, p2, bq);
+    fwd_round_big<LP, 1, B0 + 2 * C::R0>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
 }
 // Inverse stages (gs32: values below 2p throughout): window [0,4) -> window [LP-4, LP), not yet scaled.  `t` holds the
 // twiddles of round J on entry (requested by the caller / the round before, ahead of the exchange).
 template <int LP, int J>
 __device__ __forceinline__ void inv_round_big(u32 (&v)[Big32<LP>::VT][16], Tw32 (&t)[Big32<LP>::VT][15], u32 *lds, const Tw32 *ltw, const Tw32 *gtw,
-                                              u32 tf, u32 p, u32 p2) {
+                                              u32 tf, u32 p, u32 p2, u32 s0, u32 blk) {
     using C = Big32<LP>;
     constexpr int A = C::a_of(J);
 #pragma unroll
     for (int s = 0; s < C::VT; s++) round_inv32_tw<4>(v[s], t[s], p, p2);
     if constexpr (J > 1) {
-        constexpr int AN = C::a_of(J - 1), LSN = C::ls0_of(J - 1);
+        constexpr int AN = C::a_of(J - 1);
 #pragma unroll
-        for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J - 1) ? ltw : gtw, (1u << LSN) + ((tf + s * C::TH) >> AN));
+        for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J - 1) ? ltw : gtw, big_t0<LP, J - 1>(s0, blk, (tf + s * C::TH) >> AN));
     }
     exchange_big<LP, A, C::a_of(J - 1)>(v, lds, tf);
 }
 template <int LP>
-__device__ __forceinline__ void inv_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2) {
+__device__ __forceinline__ void inv_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2,
+                                        u32 s0 = 0, u32 blk = 0) {
     using C = Big32<LP>;
     Tw32 t[C::VT][15];
     constexpr int JT = C::NR - 1;
 #pragma unroll
-    for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(JT) ? ltw : gtw, (1u << C::ls0_of(JT)) + ((tf + s * C::TH) >> C::a_of(JT)));
-    if constexpr (C::NR > 3) inv_round_big<LP, 3>(v, t, lds, ltw, gtw, tf, p, p2);
-    inv_round_big<LP, 2>(v, t, lds, ltw, gtw, tf, p, p2);
-    inv_round_big<LP, 1>(v, t, lds, ltw, gtw, tf, p, p2);
+    for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(JT) ? ltw : gtw, big_t0<LP, JT>(s0, blk, (tf + s * C::TH) >> C::a_of(JT)));
+    if constexpr (C::NR > 3) inv_round_big<LP, 3>(v, t, lds, ltw, gtw, tf, p, p2, s0, blk);
+    inv_round_big<LP, 2>(v, t, lds, ltw, gtw, tf, p, p2, s0, blk);
+    inv_round_big<LP, 1>(v, t, lds, ltw, gtw, tf, p, p2, s0, blk);
 #pragma unroll
     for (int s = 0; s < C::VT; s++) round_inv32<C::R0>(v[s], ltw, 1u, p, p2);
 }

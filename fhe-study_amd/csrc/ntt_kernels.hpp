@@ -19,7 +19,7 @@ struct DevicePlan {
     const Tw *tw_fwd = nullptr;
     const Tw *tw_inv = nullptr;
     const u64 *digit_lut = nullptr;   // tables for transforms of 0/1 polynomials (ntt_rounds.hpp: round0_bits)
-    const Tw32 *tw32_fwd = nullptr;   // the same tables in 32-bit words when q < 2^32 / 25 and 2^8 <= n <= 2^14 (smallq.hip)
+    const Tw32 *tw32_fwd = nullptr;   // the same tables in 32-bit words when q < 2^32 / 25 and 2^8 <= n <= 2^17 (smallq.hip)
     const Tw32 *tw32_inv = nullptr;
     Mod mod{};
     Tw ninv{};    // n^-1                     (ntt.rs:27-30)

@@ -5,7 +5,7 @@
 // transform (same psi, same tables, same bit-reversed layout: the plan's) runs in one word per coefficient with the
 // butterflies of ntt32_rounds.hpp: 3 multiplies + 3 additions, no conditional subtraction on the forward side.  The
 // interface stays 64-bit words; a transform is then bound by its 16 n bytes of traffic instead of by multiplier issue.
-// Single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
+// Two passes with a u32 intermediate for 2^15 <= n <= 2^17 (transforms only); single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
 // one workgroup of n / 16 threads around a whole-transform LDS tile, ntt32_big.hpp); everything else (and FHE_EXT32=0)
 // keeps the 61-bit kernels (2^15 points — 1024 threads x 32 coefficients in 128 registers — were tried: 64-143 registers
 // spilled, 3.8 M NTT/s against 4.8 M on the 61-bit two-pass kernels).  Same values, word for word: every result is canonical
@@ -314,10 +314,110 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQAr
     for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(mul_shoup32(va[0][k], a.ninv_mont, q), q);
 }
 
+// ---- two-pass sizes 2^15 <= n <= 2^17 ----------------------------------------------------------------------------------
+// The first LA = log2(n) - 14 stages pair rows of the 2^LA x 2^14 view (uniform twiddles per row pair: an element-wise
+// pass, lanes along the columns); the remaining 14 stages are 2^LA independent 2^14-point blocks (s0 = LA, blk = row:
+// ntt32_big.hpp).  The intermediate between the passes is u32: 24 n bytes per transform instead of 32 n.
+constexpr int kSqBlockLog = 14;
+template <int LA>
+__global__ __launch_bounds__(256) void sq2_strided_fwd_kernel(SmallQArgs a) {
+    constexpr u32 M = 1u << kSqBlockLog, R = 1u << LA;
+    const u64 row = blockIdx.x / (M / 256);
+    const u32 c = (blockIdx.x % (M / 256)) * 256 + threadIdx.x;
+    const u64 *__restrict__ src = a.a + (row << (kSqBlockLog + LA)) + c;
+    const u32 q = a.q, q2 = 2u * q;
+    u32 v[R];
+#pragma unroll
+    for (u32 r = 0; r < R; r++) v[r] = csub_u32(barrett2p_32((u32)src[(u64)r * M], q, a.bq), q);
+#pragma unroll
+    for (int s = 0; s < LA; s++) {
+        const int span = (int)R >> (s + 1);
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            const Tw32 t = a.tw_fwd[(1u << s) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) ct32_loose(v[g * 2 * span + l], v[g * 2 * span + l + span], t, q, q2);
+        }
+    }
+    u32 *__restrict__ dst = a.mid + (row << (kSqBlockLog + LA)) + c;
+#pragma unroll
+    for (u32 r = 0; r < R; r++) dst[(u64)r * M] = csub_u32(barrett2p_32(v[r], q, a.bq), q);      // below (1 + 2 LA) q before
+}
+template <int LA>
+__global__ __launch_bounds__(256) void sq2_strided_inv_kernel(SmallQArgs a) {
+    constexpr u32 M = 1u << kSqBlockLog, R = 1u << LA;
+    const u64 row = blockIdx.x / (M / 256);
+    const u32 c = (blockIdx.x % (M / 256)) * 256 + threadIdx.x;
+    const u32 *__restrict__ src = a.mid + (row << (kSqBlockLog + LA)) + c;
+    const u32 q = a.q, q2 = 2u * q;
+    u32 v[R];
+#pragma unroll
+    for (u32 r = 0; r < R; r++) v[r] = src[(u64)r * M];          // canonical
+#pragma unroll
+    for (int s = LA - 1; s >= 0; s--) {
+        const int span = (int)R >> (s + 1);
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            const Tw32 t = a.tw_inv[(1u << s) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) gs32(v[g * 2 * span + l], v[g * 2 * span + l + span], t, q, q2);
+        }
+    }
+    u64 *__restrict__ dst = a.out + (row << (kSqBlockLog + LA)) + c;
+#pragma unroll
+    for (u32 r = 0; r < R; r++) dst[(u64)r * M] = csub_u32(mul_shoup32(v[r], a.ninv, q), q);
+}
+// block `blk` of row `row`: u32 intermediate (natural order) -> 14 stages -> the block's 2^14 output words
+__global__ __launch_bounds__((Big32<kSqBlockLog>::TH)) void sq2_block_fwd_kernel(SmallQArgs a, u32 la) {
+    using C = Big32<kSqBlockLog>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *lds = reinterpret_cast<u32 *>(smem_raw);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + C::TILE_BYTES);
+    const u32 tf = threadIdx.x;
+    const u32 blk = blockIdx.x & ((1u << la) - 1u);
+    const u64 base = ((u64)(blockIdx.x >> la) << (kSqBlockLog + la)) + ((u64)blk << kSqBlockLog);
+    stage_tw32_block<C::TH>(ltw, a.tw_fwd, C::LTW_N, tf, la, blk);
+    __syncthreads();
+    u32 v[1][16];
+    const u32 *__restrict__ src = a.mid + base;
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[0][k] = src[(u32)k * C::TH + tf];
+    fwd_big<kSqBlockLog, 0>(v, lds, ltw, a.tw_fwd, tf, a.q, 2u * a.q, a.bq, la, blk);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16(tf * 16u + k)] = csub_u32(barrett2p_32(v[0][k], a.q, a.bq), a.q);
+    __syncthreads();
+    u64 *__restrict__ dst = a.out + base;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = lds[pad16((u32)k * C::TH + tf)];
+}
+__global__ __launch_bounds__((Big32<kSqBlockLog>::TH)) void sq2_block_inv_kernel(SmallQArgs a, u32 la) {
+    using C = Big32<kSqBlockLog>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *lds = reinterpret_cast<u32 *>(smem_raw);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + C::TILE_BYTES);
+    const u32 tf = threadIdx.x;
+    const u32 blk = blockIdx.x & ((1u << la) - 1u);
+    const u64 base = ((u64)(blockIdx.x >> la) << (kSqBlockLog + la)) + ((u64)blk << kSqBlockLog);
+    stage_tw32_block<C::TH>(ltw, a.tw_inv, C::LTW_N, tf, la, blk);
+    const u64 *__restrict__ src = a.a + base;
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16((u32)k * C::TH + tf)] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TH + tf], a.q, a.bq), a.q);
+    __syncthreads();
+    u32 v[1][16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[0][k] = lds[pad16(tf * 16u + k)];
+    inv_big<kSqBlockLog>(v, lds, ltw, a.tw_inv, tf, a.q, 2u * a.q, la, blk);
+    u32 *__restrict__ dst = a.mid + base;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(v[0][k], a.q);       // below 2q after the Gentleman-Sande rounds
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 bool smallq_supported(uint64_t q, unsigned log_n) {
-    return q >= 3 && (q & 1) && q * 25 < (1ull << 32) && log_n >= 8 && log_n <= 14;
+    return q >= 3 && (q & 1) && q * 25 < (1ull << 32) && log_n >= 8 && log_n <= 17;
 }
+size_t smallq_scratch_bytes(unsigned log_n, uint64_t rows) { return log_n > 14 ? (rows << log_n) * 4 : 0; }
 
 template <typename K>
 static hipError_t sq_launch(K kernel, const char *name, int lp, size_t lds, unsigned units, const SmallQArgs &a, hipStream_t st) {
@@ -352,11 +452,41 @@ static hipError_t sq_big_launch(K kernel, const char *name, int lp, size_t lds, 
     if (log_n == 13) return sq_big_launch(KERNEL<13>, NAME, 13, Big32<13>::TILE_BYTES + TWS * Big32<13>::TW_BYTES, Big32<13>::TH, a, st); \
     if (log_n == 14) return sq_big_launch(KERNEL<14>, NAME, 14, Big32<14>::TILE_BYTES + TWS * Big32<14>::TW_BYTES, Big32<14>::TH, a, st);
 
+template <typename KS, typename KB>
+static hipError_t sq2_launch(KS strided, KB block, bool forward, int log_n, const SmallQArgs &a, hipStream_t st) {
+    using C = Big32<kSqBlockLog>;
+    const unsigned la = (unsigned)(log_n - kSqBlockLog);
+    if (a.rows == 0) return hipSuccess;
+    if (!a.mid) return hipErrorInvalidValue;
+    const u64 gs = a.rows * ((1u << kSqBlockLog) / 256), gb = a.rows << la;
+    if (gs > 0x7fffffffull || gb > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr size_t lds = C::TILE_BYTES + C::TW_BYTES;
+    if (hipError_t e = allow_big_lds((const void *)block, lds)) return e;
+    auto run_strided = [&]() {
+        KernelTimer kt(forward ? "sq2_strided_fwd" : "sq2_strided_inv", log_n, st);
+        hipLaunchKernelGGL(strided, dim3((unsigned)gs), dim3(256), 0, st, a);
+        return hipGetLastError();
+    };
+    auto run_block = [&]() {
+        KernelTimer kt(forward ? "sq2_block_fwd" : "sq2_block_inv", log_n, st);
+        hipLaunchKernelGGL(block, dim3((unsigned)gb), dim3(C::TH), lds, st, a, la);
+        return hipGetLastError();
+    };
+    if (forward) { if (hipError_t e = run_strided()) return e; return run_block(); }
+    if (hipError_t e = run_block()) return e;
+    return run_strided();
+}
 hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st) {
+    if (log_n == 15) return sq2_launch(sq2_strided_fwd_kernel<1>, sq2_block_fwd_kernel, true, log_n, a, st);
+    if (log_n == 16) return sq2_launch(sq2_strided_fwd_kernel<2>, sq2_block_fwd_kernel, true, log_n, a, st);
+    if (log_n == 17) return sq2_launch(sq2_strided_fwd_kernel<3>, sq2_block_fwd_kernel, true, log_n, a, st);
     FHE_SQ_BIG(sq_big_forward_kernel, "sq_forward", 1)
     FHE_SQ_SWITCH(sq_forward_kernel, "sq_forward", 1, 1)
 }
 hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) {
+    if (log_n == 15) return sq2_launch(sq2_strided_inv_kernel<1>, sq2_block_inv_kernel, false, log_n, a, st);
+    if (log_n == 16) return sq2_launch(sq2_strided_inv_kernel<2>, sq2_block_inv_kernel, false, log_n, a, st);
+    if (log_n == 17) return sq2_launch(sq2_strided_inv_kernel<3>, sq2_block_inv_kernel, false, log_n, a, st);
     FHE_SQ_BIG(sq_big_inverse_kernel, "sq_inverse", 1)
     FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1)
 }

@@ -423,6 +423,44 @@ def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
     assert torch.equal(c2, c)
 
 
+@pytest.mark.parametrize("q,n,batch", [(Q16, 32768, 3), (786433, 65536, 2), (786433, 131072, 1)])
+def test_small_modulus_two_pass_transforms(pkg, oracle, q, n, batch):
+    """2^15 <= n <= 2^17 at q < 2^32 / 25 (q = 65537's largest n; 786433 = 3 * 2^18 + 1): strided 32-bit pass + 2^14-point
+    blocks with a u32 intermediate (smallq.hip).  Forward words == the oracle's, round trip == identity, in place too; the
+    product at these sizes stays on the 61-bit kernels and consumes / agrees with these transforms."""
+    import torch
+
+    B = pkg.binding
+    plan = pkg.Plan(q, n)
+    rng = np.random.default_rng(q + n)
+    a = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    b = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).cuda()
+    da, db = dev(a), dev(b)
+    A, r = torch.empty_like(da), torch.empty_like(da)
+    B.kernel_timing_reset(); B.kernel_timing_enable(True)
+    plan.forward_dev(da.data_ptr(), A.data_ptr(), batch)
+    plan.inverse_dev(A.data_ptr(), r.data_ptr(), batch)
+    torch.cuda.synchronize()
+    names = set(B.kernel_timing_read())
+    B.kernel_timing_enable(False)
+    lg = n.bit_length() - 1
+    assert {f"sq2_strided_fwd_{lg}", f"sq2_block_fwd_{lg}", f"sq2_block_inv_{lg}", f"sq2_strided_inv_{lg}"} <= names, names
+    assert np.array_equal(_u64(A), oracle.ntt(q, n, a).reshape(batch, n))
+    assert np.array_equal(_u64(r), a)
+    x = da.clone()
+    plan.forward_dev(x.data_ptr(), x.data_ptr(), batch)                  # in place
+    assert torch.equal(x, A)
+    plan.inverse_dev(x.data_ptr(), x.data_ptr(), batch)
+    assert torch.equal(x, da)
+    c, Bv, c2 = torch.empty_like(da), torch.empty_like(db), torch.empty_like(da)
+    plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch)
+    assert np.array_equal(_u64(c), oracle.rq_mul(q, n, a, b)[0].reshape(batch, n))
+    plan.forward_dev(db.data_ptr(), Bv.data_ptr(), batch)
+    plan.rq_mul_dev(A.data_ptr(), Bv.data_ptr(), c2.data_ptr(), batch, a_is_evals=True, b_is_evals=True)
+    assert torch.equal(c2, c)
+
+
 def test_small_prime_products_on_random_shapes(pkg, oracle):
     """A seeded sweep over the shapes digit32.hip serves (k = 1; n = 2^8 .. 2^12; any 1 <= l <= 64; batches that do and do
     not fill whole steps / parts / tail workgroups): external product and key switch, plain and prepared keys, word for

@@ -5,16 +5,18 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fhe_study_amd as pkg
-q = 65537
 rng = np.random.default_rng(1)
-for n, batch in ((1024, 262144), (4096, 65536), (8192, 32768), (16384, 16384)):
+for q, n, batch in ((65537, 1024, 262144), (65537, 4096, 65536), (65537, 8192, 32768), (65537, 16384, 16384), (65537, 32768, 8192),
+                    (786433, 65536, 4096), (786433, 131072, 2048)):
     plan = pkg.Plan(q, n)
     a = torch.from_numpy(rng.integers(0, q, (batch, n), dtype=np.int64)).cuda()
     b = torch.from_numpy(rng.integers(0, q, (batch, n), dtype=np.int64)).cuda()
     o = torch.empty_like(a)
-    for name, f in (("forward", lambda: plan.forward_dev(a.data_ptr(), o.data_ptr(), batch)),
-                    ("inverse", lambda: plan.inverse_dev(a.data_ptr(), o.data_ptr(), batch)),
-                    ("Rq x Rq", lambda: plan.rq_mul_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), batch))):
+    ops = [("forward", lambda: plan.forward_dev(a.data_ptr(), o.data_ptr(), batch)),
+           ("inverse", lambda: plan.inverse_dev(a.data_ptr(), o.data_ptr(), batch))]
+    if n <= 16384:
+        ops.append(("Rq x Rq", lambda: plan.rq_mul_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), batch)))
+    for name, f in ops:
         for _ in range(3): f()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -315,10 +315,14 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQAr
 }
 
 // ---- two-pass sizes 2^15 <= n <= 2^17 ----------------------------------------------------------------------------------
-// The first LA = log2(n) - 14 stages pair rows of the 2^LA x 2^14 view (uniform twiddles per row pair: an element-wise
-// pass, lanes along the columns); the remaining 14 stages are 2^LA independent 2^14-point blocks (s0 = LA, blk = row:
-// ntt32_big.hpp).  The intermediate between the passes is u32: 24 n bytes per transform instead of 32 n.
-constexpr int kSqBlockLog = 14;
+// The first LA = log2(n) - 12 stages pair rows of the 2^LA x 4096 view (uniform twiddles per row pair: an element-wise
+// pass of 2^LA registers per thread, lanes along the columns — bound by its traffic); the remaining 12 stages are 2^LA
+// independent 4096-point blocks (256 threads each; block `blk` after s0 = LA stages reads the table at
+// (1 << (s0 + ls)) + (blk << ls) + H, as the contiguous pass of the 61-bit transforms does).  The intermediate between
+// the passes is u32: 24 n bytes per transform instead of 32 n.  (2^14-point blocks — 1024 threads, one workgroup per CU —
+// were built first: N = 2^16 forward 1.42 ms per 4096 polynomials (their block pass bound by butterflies: 0.84 ms) against
+// 1.21 ms with 4096-point blocks, where both passes run at the memory system's rate.)
+constexpr int kSqBlockLog = 12;
 template <int LA>
 __global__ __launch_bounds__(256) void sq2_strided_fwd_kernel(SmallQArgs a) {
     constexpr u32 M = 1u << kSqBlockLog, R = 1u << LA;
@@ -367,50 +371,88 @@ __global__ __launch_bounds__(256) void sq2_strided_inv_kernel(SmallQArgs a) {
 #pragma unroll
     for (u32 r = 0; r < R; r++) dst[(u64)r * M] = csub_u32(mul_shoup32(v[r], a.ninv, q), q);
 }
-// block `blk` of row `row`: u32 intermediate (natural order) -> 14 stages -> the block's 2^14 output words
-__global__ __launch_bounds__((Big32<kSqBlockLog>::TH)) void sq2_block_fwd_kernel(SmallQArgs a, u32 la) {
-    using C = Big32<kSqBlockLog>;
+
+// the table index of round J of block (s0, blk): local table (staged per block) or the global one
+template <int LP, int J>
+__device__ __forceinline__ u32 sq_block_t0(u32 s0, u32 blk, u32 H) {
+    using C = ContigCfg<LP>;
+    constexpr int LS = C::ls0_of(J);
+    return C::in_lds(J) ? (1u << LS) + H : (1u << (s0 + LS)) + (blk << LS) + H;
+}
+__device__ __forceinline__ void sq_stage_block(Tw32 *ltw, const Tw32 *__restrict__ tw, int count, u32 tid, u32 s0, u32 blk) {
+    for (u32 li = tid; li < (u32)count; li += 256) {
+        const u32 ls = 31u - (u32)__builtin_clz(li | 1u);       // entry 0 is never used: a copy of entry 1
+        const u32 l1 = li | (li == 0);
+        ltw[li] = tw[(1u << (s0 + ls)) + (blk << ls) + (l1 - (1u << ls))];
+    }
+}
+// block `blk` of row `row`: u32 intermediate (natural order) -> 12 stages -> the block's 4096 output words
+__global__ __launch_bounds__(256) void sq2_block_fwd_kernel(SmallQArgs a, u32 la) {
+    constexpr int LP = kSqBlockLog;
+    using C = ContigCfg<LP>;
+    using K = SqCfg<LP>;
+    static_assert(C::W == 1 && C::NR == 3, "one 4096-point block per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32 *lds = reinterpret_cast<u32 *>(smem_raw);
-    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + C::TILE_BYTES);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + K::TILE_BYTES);
     const u32 tf = threadIdx.x;
     const u32 blk = blockIdx.x & ((1u << la) - 1u);
-    const u64 base = ((u64)(blockIdx.x >> la) << (kSqBlockLog + la)) + ((u64)blk << kSqBlockLog);
-    stage_tw32_block<C::TH>(ltw, a.tw_fwd, C::LTW_N, tf, la, blk);
+    const u64 base = ((u64)(blockIdx.x >> la) << (LP + la)) + ((u64)blk << LP);
+    sq_stage_block(ltw, a.tw_fwd, C::LTW_N, tf, la, blk);
     __syncthreads();
-    u32 v[1][16];
+    const u32 q = a.q, q2 = 2u * q;
+    u32 v[16];
     const u32 *__restrict__ src = a.mid + base;
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[0][k] = src[(u32)k * C::TH + tf];
-    fwd_big<kSqBlockLog, 0>(v, lds, ltw, a.tw_fwd, tf, a.q, 2u * a.q, a.bq, la, blk);
+    for (int k = 0; k < 16; k++) v[k] = src[(u32)k * C::TPB + tf];
+    Tw32 t[15];
+    load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
+    round_fwd32_tw<C::R0, 0, true>(v, t, q, q2);
+    load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
+    exchange32<LP, C::A0, C::a_of(1), true>(v, lds, 0u, tf);
+    round_fwd32_tw<4, 0, true>(v, t, q, q2);
+    load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
+    exchange32<LP, C::a_of(1), C::a_of(2), false>(v, lds, 0u, tf);
+    round_fwd32_tw<4, 0, true>(v, t, q, q2);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) lds[pad16(tf * 16u + k)] = csub_u32(barrett2p_32(v[0][k], a.q, a.bq), a.q);
+    for (int k = 0; k < 16; k++) lds[pad16(tf * 16u + k)] = csub_u32(barrett2p_32(v[k], q, a.bq), q);
     __syncthreads();
     u64 *__restrict__ dst = a.out + base;
 #pragma unroll
-    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = lds[pad16((u32)k * C::TH + tf)];
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = lds[pad16((u32)k * C::TPB + tf)];
 }
-__global__ __launch_bounds__((Big32<kSqBlockLog>::TH)) void sq2_block_inv_kernel(SmallQArgs a, u32 la) {
-    using C = Big32<kSqBlockLog>;
+__global__ __launch_bounds__(256) void sq2_block_inv_kernel(SmallQArgs a, u32 la) {
+    constexpr int LP = kSqBlockLog;
+    using C = ContigCfg<LP>;
+    using K = SqCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32 *lds = reinterpret_cast<u32 *>(smem_raw);
-    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + C::TILE_BYTES);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + K::TILE_BYTES);
     const u32 tf = threadIdx.x;
     const u32 blk = blockIdx.x & ((1u << la) - 1u);
-    const u64 base = ((u64)(blockIdx.x >> la) << (kSqBlockLog + la)) + ((u64)blk << kSqBlockLog);
-    stage_tw32_block<C::TH>(ltw, a.tw_inv, C::LTW_N, tf, la, blk);
+    const u64 base = ((u64)(blockIdx.x >> la) << (LP + la)) + ((u64)blk << LP);
+    sq_stage_block(ltw, a.tw_inv, C::LTW_N, tf, la, blk);
+    const u32 q = a.q, q2 = 2u * q;
     const u64 *__restrict__ src = a.a + base;
 #pragma unroll
-    for (int k = 0; k < 16; k++) lds[pad16((u32)k * C::TH + tf)] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TH + tf], a.q, a.bq), a.q);
+    for (int k = 0; k < 16; k++) lds[pad16((u32)k * C::TPB + tf)] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TPB + tf], q, a.bq), q);
     __syncthreads();
-    u32 v[1][16];
+    u32 v[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[0][k] = lds[pad16(tf * 16u + k)];
-    inv_big<kSqBlockLog>(v, lds, ltw, a.tw_inv, tf, a.q, 2u * a.q, la, blk);
+    for (int k = 0; k < 16; k++) v[k] = lds[pad16(tf * 16u + k)];
+    Tw32 t[15];
+    load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_inv, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
+    round_inv32_tw<4>(v, t, q, q2);
+    load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_inv, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
+    exchange32<LP, C::a_of(2), C::a_of(1), false>(v, lds, 0u, tf);
+    round_inv32_tw<4>(v, t, q, q2);
+    load_tw32<C::R0>(t, a.tw_inv, (1u << la) + blk);
+    exchange32<LP, C::a_of(1), C::A0, false>(v, lds, 0u, tf);
+    round_inv32_tw<C::R0>(v, t, q, q2);
     u32 *__restrict__ dst = a.mid + base;
 #pragma unroll
-    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(v[0][k], a.q);       // below 2q after the Gentleman-Sande rounds
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = csub_u32(v[k], q);       // below 2q after the Gentleman-Sande rounds
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -454,14 +496,12 @@ static hipError_t sq_big_launch(K kernel, const char *name, int lp, size_t lds, 
 
 template <typename KS, typename KB>
 static hipError_t sq2_launch(KS strided, KB block, bool forward, int log_n, const SmallQArgs &a, hipStream_t st) {
-    using C = Big32<kSqBlockLog>;
     const unsigned la = (unsigned)(log_n - kSqBlockLog);
     if (a.rows == 0) return hipSuccess;
     if (!a.mid) return hipErrorInvalidValue;
     const u64 gs = a.rows * ((1u << kSqBlockLog) / 256), gb = a.rows << la;
     if (gs > 0x7fffffffull || gb > 0x7fffffffull) return hipErrorInvalidValue;
-    constexpr size_t lds = C::TILE_BYTES + C::TW_BYTES;
-    if (hipError_t e = allow_big_lds((const void *)block, lds)) return e;
+    constexpr size_t lds = SqCfg<kSqBlockLog>::TILE_BYTES + SqCfg<kSqBlockLog>::TW_BYTES;
     auto run_strided = [&]() {
         KernelTimer kt(forward ? "sq2_strided_fwd" : "sq2_strided_inv", log_n, st);
         hipLaunchKernelGGL(strided, dim3((unsigned)gs), dim3(256), 0, st, a);
@@ -469,7 +509,7 @@ static hipError_t sq2_launch(KS strided, KB block, bool forward, int log_n, cons
     };
     auto run_block = [&]() {
         KernelTimer kt(forward ? "sq2_block_fwd" : "sq2_block_inv", log_n, st);
-        hipLaunchKernelGGL(block, dim3((unsigned)gb), dim3(C::TH), lds, st, a, la);
+        hipLaunchKernelGGL(block, dim3((unsigned)gb), dim3(256), lds, st, a, la);
         return hipGetLastError();
     };
     if (forward) { if (hipError_t e = run_strided()) return e; return run_block(); }
@@ -477,16 +517,16 @@ static hipError_t sq2_launch(KS strided, KB block, bool forward, int log_n, cons
     return run_strided();
 }
 hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st) {
-    if (log_n == 15) return sq2_launch(sq2_strided_fwd_kernel<1>, sq2_block_fwd_kernel, true, log_n, a, st);
-    if (log_n == 16) return sq2_launch(sq2_strided_fwd_kernel<2>, sq2_block_fwd_kernel, true, log_n, a, st);
-    if (log_n == 17) return sq2_launch(sq2_strided_fwd_kernel<3>, sq2_block_fwd_kernel, true, log_n, a, st);
+    if (log_n == 15) return sq2_launch(sq2_strided_fwd_kernel<3>, sq2_block_fwd_kernel, true, log_n, a, st);
+    if (log_n == 16) return sq2_launch(sq2_strided_fwd_kernel<4>, sq2_block_fwd_kernel, true, log_n, a, st);
+    if (log_n == 17) return sq2_launch(sq2_strided_fwd_kernel<5>, sq2_block_fwd_kernel, true, log_n, a, st);
     FHE_SQ_BIG(sq_big_forward_kernel, "sq_forward", 1)
     FHE_SQ_SWITCH(sq_forward_kernel, "sq_forward", 1, 1)
 }
 hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) {
-    if (log_n == 15) return sq2_launch(sq2_strided_inv_kernel<1>, sq2_block_inv_kernel, false, log_n, a, st);
-    if (log_n == 16) return sq2_launch(sq2_strided_inv_kernel<2>, sq2_block_inv_kernel, false, log_n, a, st);
-    if (log_n == 17) return sq2_launch(sq2_strided_inv_kernel<3>, sq2_block_inv_kernel, false, log_n, a, st);
+    if (log_n == 15) return sq2_launch(sq2_strided_inv_kernel<3>, sq2_block_inv_kernel, false, log_n, a, st);
+    if (log_n == 16) return sq2_launch(sq2_strided_inv_kernel<4>, sq2_block_inv_kernel, false, log_n, a, st);
+    if (log_n == 17) return sq2_launch(sq2_strided_inv_kernel<5>, sq2_block_inv_kernel, false, log_n, a, st);
     FHE_SQ_BIG(sq_big_inverse_kernel, "sq_inverse", 1)
     FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1)
 }

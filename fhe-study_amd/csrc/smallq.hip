@@ -5,7 +5,7 @@
 // transform (same psi, same tables, same bit-reversed layout: the plan's) runs in one word per coefficient with the
 // butterflies of ntt32_rounds.hpp: 3 multiplies + 3 additions, no conditional subtraction on the forward side.  The
 // interface stays 64-bit words; a transform is then bound by its 16 n bytes of traffic instead of by multiplier issue.
-// Two passes with a u32 intermediate for 2^15 <= n <= 2^17 (transforms only); single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
+// Two passes with a u32 intermediate for 2^15 <= n <= 2^17; single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
 // one workgroup of n / 16 threads around a whole-transform LDS tile, ntt32_big.hpp); everything else (and FHE_EXT32=0)
 // keeps the 61-bit kernels (2^15 points — 1024 threads x 32 coefficients in 128 registers — were tried: 64-143 registers
 // spilled, 3.8 M NTT/s against 4.8 M on the 61-bit two-pass kernels).  Same values, word for word: every result is canonical
@@ -455,11 +455,60 @@ __global__ __launch_bounds__(256) void sq2_block_inv_kernel(SmallQArgs a, u32 la
     for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = csub_u32(v[k], q);       // below 2q after the Gentleman-Sande rounds
 }
 
+// the MIDDLE of Rq x Rq at the two-pass sizes: block-forward(a), block-forward(b) in lockstep, pointwise Montgomery
+// product, block-inverse — on one 4096-point block; reads the two u32 intermediates of the strided forward passes, leaves
+// the u32 intermediate the strided inverse pass consumes (in place of a's)
+__global__ __launch_bounds__(256) void sq2_block_mul_kernel(SmallQArgs a, u32 la) {
+    constexpr int LP = kSqBlockLog;
+    using C = ContigCfg<LP>;
+    using K = SqCfg<LP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *la_tile = reinterpret_cast<u32 *>(smem_raw), *lb_tile = reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES), *ltw_inv = ltw + C::LTW_N;
+    const u32 tf = threadIdx.x;
+    const u32 blk = blockIdx.x & ((1u << la) - 1u);
+    const u64 base = ((u64)(blockIdx.x >> la) << (LP + la)) + ((u64)blk << LP);
+    sq_stage_block(ltw, a.tw_fwd, C::LTW_N, tf, la, blk);
+    sq_stage_block(ltw_inv, a.tw_inv, C::LTW_N, tf, la, blk);
+    __syncthreads();
+    const u32 q = a.q, q2 = 2u * q;
+    u32 va[16], vb[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        va[k] = a.mid[base + (u32)k * C::TPB + tf];
+        vb[k] = a.mid_b[base + (u32)k * C::TPB + tf];
+    }
+    Tw32 t[15];
+    load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
+    round_fwd32_tw<C::R0, 0, true>(va, t, q, q2);
+    round_fwd32_tw<C::R0, 0, true>(vb, t, q, q2);
+    load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
+    sq_exchange2<LP, C::A0, C::a_of(1), true>(va, vb, la_tile, lb_tile, 0u, tf);
+    round_fwd32_tw<4, 0, true>(va, t, q, q2);
+    round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+    load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
+    sq_exchange2<LP, C::a_of(1), C::a_of(2), false>(va, vb, la_tile, lb_tile, 0u, tf);
+    round_fwd32_tw<4, 0, true>(va, t, q, q2);
+    round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; k++) va[k] = sq_mont(barrett2p_32(va[k], q, a.bq), barrett2p_32(vb[k], q, a.bq), q, a.qinv_neg);
+    load_tw32<4>(t, C::in_lds(2) ? ltw_inv : a.tw_inv, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
+    round_inv32_tw<4>(va, t, q, q2);
+    load_tw32<4>(t, C::in_lds(1) ? ltw_inv : a.tw_inv, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
+    exchange32<LP, C::a_of(2), C::a_of(1), false>(va, la_tile, 0u, tf);
+    round_inv32_tw<4>(va, t, q, q2);
+    load_tw32<C::R0>(t, a.tw_inv, (1u << la) + blk);
+    exchange32<LP, C::a_of(1), C::A0, false>(va, la_tile, 0u, tf);
+    round_inv32_tw<C::R0>(va, t, q, q2);
+#pragma unroll
+    for (int k = 0; k < 16; k++) a.mid[base + (u32)k * C::TPB + tf] = csub_u32(va[k], q);
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 bool smallq_supported(uint64_t q, unsigned log_n) {
     return q >= 3 && (q & 1) && q * 25 < (1ull << 32) && log_n >= 8 && log_n <= 17;
 }
-size_t smallq_scratch_bytes(unsigned log_n, uint64_t rows) { return log_n > 14 ? (rows << log_n) * 4 : 0; }
+size_t smallq_scratch_bytes(unsigned log_n, uint64_t rows) { return log_n > 14 ? (rows << log_n) * 4 : 0; }      // per operand
 
 template <typename K>
 static hipError_t sq_launch(K kernel, const char *name, int lp, size_t lds, unsigned units, const SmallQArgs &a, hipStream_t st) {
@@ -530,7 +579,36 @@ hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) {
     FHE_SQ_BIG(sq_big_inverse_kernel, "sq_inverse", 1)
     FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1)
 }
+template <typename KF, typename KI>
+static hipError_t sq2_mul_launch(KF sfwd, KI sinv, int log_n, const SmallQArgs &a, hipStream_t st) {
+    const unsigned la = (unsigned)(log_n - kSqBlockLog);
+    if (a.rows == 0) return hipSuccess;
+    if (!a.mid || !a.mid_b) return hipErrorInvalidValue;
+    const u64 gs = a.rows * ((1u << kSqBlockLog) / 256), gb = a.rows << la;
+    if (gs > 0x7fffffffull || gb > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr size_t lds = 2 * SqCfg<kSqBlockLog>::TILE_BYTES + 2 * SqCfg<kSqBlockLog>::TW_BYTES;
+    SmallQArgs fa = a, fb = a, inv = a;
+    fb.a = a.b; fb.mid = a.mid_b;                               // strided forward of b into its own intermediate
+    inv.ninv = a.ninv_mont;                                     // the Montgomery product's 2^-32 leaves with n^-1
+    {
+        KernelTimer kt("sq2_strided_fwd", log_n, st);
+        hipLaunchKernelGGL(sfwd, dim3((unsigned)gs), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(sfwd, dim3((unsigned)gs), dim3(256), 0, st, fb);
+    }
+    if (hipError_t e = hipGetLastError()) return e;
+    {
+        KernelTimer kt("sq2_block_mul", log_n, st);
+        hipLaunchKernelGGL(sq2_block_mul_kernel, dim3((unsigned)gb), dim3(256), lds, st, a, la);
+    }
+    if (hipError_t e = hipGetLastError()) return e;
+    KernelTimer kt("sq2_strided_inv", log_n, st);
+    hipLaunchKernelGGL(sinv, dim3((unsigned)gs), dim3(256), 0, st, inv);
+    return hipGetLastError();
+}
 hipError_t launch_sq_rq_mul(const SmallQArgs &a, int log_n, hipStream_t st) {
+    if (log_n == 15) return sq2_mul_launch(sq2_strided_fwd_kernel<3>, sq2_strided_inv_kernel<3>, log_n, a, st);
+    if (log_n == 16) return sq2_mul_launch(sq2_strided_fwd_kernel<4>, sq2_strided_inv_kernel<4>, log_n, a, st);
+    if (log_n == 17) return sq2_mul_launch(sq2_strided_fwd_kernel<5>, sq2_strided_inv_kernel<5>, log_n, a, st);
     FHE_SQ_BIG(sq_big_rq_mul_kernel, "sq_rq_mul", 2)
     FHE_SQ_SWITCH(sq_rq_mul_kernel, "sq_rq_mul", 2, 2)
 }

@@ -14,11 +14,11 @@ struct SmallQArgs {
     Tw32 ninv, ninv_mont;          // n^-1 mod q; n^-1 * 2^32 mod q (after a Montgomery product)
     const u64 *a, *b;              // rows of n 64-bit words (b: the product's second operand)
     u64 *out;
-    uint32_t *mid;                 // two-pass sizes (n > 2^14): rows * n u32 words between the passes (smallq_scratch_bytes)
+    uint32_t *mid, *mid_b;         // two-pass sizes (n > 2^14): rows * n u32 words between the passes, per operand (smallq_scratch_bytes)
     u64 rows;
 };
 
-bool smallq_supported(uint64_t q, unsigned log_n);            // transforms; the product: log_n <= 14
+bool smallq_supported(uint64_t q, unsigned log_n);
 size_t smallq_scratch_bytes(unsigned log_n, uint64_t rows);
 hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st);
 hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st);

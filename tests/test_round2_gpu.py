@@ -427,7 +427,8 @@ def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
 def test_small_modulus_two_pass_transforms(pkg, oracle, q, n, batch):
     """2^15 <= n <= 2^17 at q < 2^32 / 25 (q = 65537's largest n; 786433 = 3 * 2^18 + 1): strided 32-bit pass + 2^14-point
     blocks with a u32 intermediate (smallq.hip).  Forward words == the oracle's, round trip == identity, in place too; the
-    product at these sizes stays on the 61-bit kernels and consumes / agrees with these transforms."""
+    plain product is strided(a), strided(b), one middle kernel per block, strided inverse; the cached-evals product (61-bit
+    kernels) consumes these transforms and agrees."""
     import torch
 
     B = pkg.binding
@@ -454,7 +455,11 @@ def test_small_modulus_two_pass_transforms(pkg, oracle, q, n, batch):
     plan.inverse_dev(x.data_ptr(), x.data_ptr(), batch)
     assert torch.equal(x, da)
     c, Bv, c2 = torch.empty_like(da), torch.empty_like(db), torch.empty_like(da)
+    B.kernel_timing_reset(); B.kernel_timing_enable(True)
     plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch)
+    torch.cuda.synchronize()
+    assert f"sq2_block_mul_{lg}" in set(B.kernel_timing_read())
+    B.kernel_timing_enable(False)
     assert np.array_equal(_u64(c), oracle.rq_mul(q, n, a, b)[0].reshape(batch, n))
     plan.forward_dev(db.data_ptr(), Bv.data_ptr(), batch)
     plan.rq_mul_dev(A.data_ptr(), Bv.data_ptr(), c2.data_ptr(), batch, a_is_evals=True, b_is_evals=True)

@@ -14,8 +14,7 @@ for q, n, batch in ((65537, 1024, 262144), (65537, 4096, 65536), (65537, 8192, 3
     o = torch.empty_like(a)
     ops = [("forward", lambda: plan.forward_dev(a.data_ptr(), o.data_ptr(), batch)),
            ("inverse", lambda: plan.inverse_dev(a.data_ptr(), o.data_ptr(), batch))]
-    if n <= 16384:
-        ops.append(("Rq x Rq", lambda: plan.rq_mul_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), batch)))
+    ops.append(("Rq x Rq", lambda: plan.rq_mul_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), batch)))
     for name, f in ops:
         for _ in range(3): f()
         torch.cuda.synchronize()

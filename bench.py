@@ -171,17 +171,24 @@ def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
                 "value_1core": 1.0 / per_ntt}
 
     transforms = 2 if inverse_too else 1
+    small_q = q * 25 < (1 << 32) and 8 <= log_n <= 17      # smallq.hip: 32-bit words (NOT the BASELINE modulus: --q given)
     name = (f"batched forward+inverse negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
             "(BASELINE.json configs[1] shape), device-resident" if inverse_too else
             f"batched forward negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
             "(BASELINE.json configs[4] shape), device-resident in->out")
+    metric = ("NTT/s (N=4096, 64-bit q, forward+inverse) per node; achieved HBM GB/s vs roofline" if inverse_too
+              else "NTT/s (N=2^16, 64-bit q) per node; achieved HBM GB/s vs roofline")
+    if small_q:
+        metric = (f"NTT/s (N=2^{log_n}, q={q}: a {q.bit_length()}-bit modulus given with --q, NOT BASELINE.json's 64-bit q) per node; "
+                  "achieved HBM GB/s vs roofline")
     return {
-        "metric": ("NTT/s (N=4096, 64-bit q, forward+inverse) per node; achieved HBM GB/s vs roofline" if inverse_too
-                   else "NTT/s (N=2^16, 64-bit q) per node; achieved HBM GB/s vs roofline"),
+        "metric": metric,
         "unit": "NTT/s", "units_per_step": transforms * batch, "step": step, "parity": parity, "cpu": cpu,
         "alg_bytes_per_unit": 16 * n,            # read N + write N coefficients of 8 B
         "bfly_per_unit": (n // 2) * log_n,
-        "pass_bytes_per_launch_per_unit": 16 * n,  # every pass kernel reads and writes each coefficient once
+        "bfly_bits": 32 if small_q else 64, "dtype": "u32" if small_q else "u64",
+        # every pass kernel reads and writes each coefficient once (the small-modulus two-pass sizes keep u32 in between)
+        "pass_bytes_per_launch_per_unit": 12 * n if (small_q and log_n > 14) else 16 * n,
         "config": {"workload": name, "n": n, "q": q, "batch_per_gpu": batch, "global_batch": world * batch,
                    "parallelism": f"batch-sharded x{world}, no collective"},
         "plan": plan, "x": x, "y": y, "n": n, "q": q, "batch": batch, "seed": seed,
@@ -433,7 +440,7 @@ def main():
             "metric": W["metric"], "value": value, "unit": W["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": W.get("scaling", "weak"), "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic", "config": W["config"], "roofline": roofline,
+            "dtype": W.get("dtype", "u64"), "data": "synthetic", "config": W["config"], "roofline": roofline,
         }
 
     # ---- parity against the CPU oracle (checker only; never inside the timed region) ----------

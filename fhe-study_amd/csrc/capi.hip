@@ -702,7 +702,8 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
     fhe::SmallQArgs sq{};
     if (!a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out && fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_a; sq.b = (const u64 *)d_b; sq.out = (u64 *)d_c; sq.rows = batch;
-        if ((rc = fhe_smallq_scratch(dp.log_n, 2 * batch, st, &sq)) != FHE_OK) return rc;     // two operands' intermediates
+        if (d_work && dp.log_n > 14) sq.mid = (uint32_t *)d_work;                                // caller-owned scratch (e.g. inside a capture): 2 * batch * n * 8 bytes hold both
+        else if ((rc = fhe_smallq_scratch(dp.log_n, 2 * batch, st, &sq)) != FHE_OK) return rc;  // two operands' u32 intermediates
         if (sq.mid) sq.mid_b = sq.mid + ((u64)batch << dp.log_n);
         hipError_t se = fhe::launch_sq_rq_mul(sq, (int)dp.log_n, st);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_rq_mul_kernel");

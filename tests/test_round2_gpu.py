@@ -464,6 +464,10 @@ def test_small_modulus_two_pass_transforms(pkg, oracle, q, n, batch):
     plan.forward_dev(db.data_ptr(), Bv.data_ptr(), batch)
     plan.rq_mul_dev(A.data_ptr(), Bv.data_ptr(), c2.data_ptr(), batch, a_is_evals=True, b_is_evals=True)
     assert torch.equal(c2, c)
+    work = torch.empty(pkg.load_library().fhe_rq_mul_workspace_bytes(plan.handle, batch) // 8, dtype=torch.int64, device="cuda")
+    c2.zero_()
+    plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c2.data_ptr(), batch, d_work=work.data_ptr())     # caller-owned scratch
+    assert torch.equal(c2, c)
 
 
 def test_small_prime_products_on_random_shapes(pkg, oracle):

@@ -12,6 +12,11 @@
  *   - Polynomials are `batch × n` row-major arrays of uint64_t coefficient
  *     VALUES (the `v` of `Zq{q,v}`, arith/src/zq.rs:6-10), canonical: v < q.
  *   - The caller owns every buffer; `out` may alias `in` (in-place).
+ *   - The arithmetic behind an entry point is the library's choice and never
+ *     shows in the words: moduli up to 2^62 run on 64-bit Shoup butterflies; a
+ *     modulus below 2^32 / 25 (e.g. the reference's test moduli 65537, 12289)
+ *     and the keyed products whose integers are small run in 32-bit words on
+ *     the same tables (env FHE_EXT32=0 disables that; results are identical).
  *   - No function unwinds or aborts: every failure is a negative FHE_E_* code
  *     and a message retrievable with fhe_last_error() (thread-local).  The
  *     reference panics in the same situations; the Rust shim turns a non-zero

@@ -606,6 +606,7 @@ bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::S
     a->ninv = fhe::Tw32{(uint32_t)plan->n_inv, (uint32_t)((plan->n_inv << 32) / q)};
     const u64 nm = (plan->n_inv << 32) % q;
     a->ninv_mont = fhe::Tw32{(uint32_t)nm, (uint32_t)((nm << 32) / q)};
+    a->mu = ~0ull / q;
     return true;
 }
 // the u32 buffer between the passes of the two-pass sizes: its own workspace slot (the callers' slots 0 / 1 stay theirs)
@@ -700,8 +701,12 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
 
     // small modulus, plain product (no cached evals in or out): the whole product in 32-bit words (smallq.hip)
     fhe::SmallQArgs sq{};
-    if (!a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out && fhe_smallq_args(plan, dp, &sq)) {
+    const bool plain = !a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out;
+    // (cached evals in or out: the single-workgroup sizes n <= 4096 of smallq.hip; larger n with evals keep the 61-bit kernels)
+    if ((plain || dp.log_n <= 12) && fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_a; sq.b = (const u64 *)d_b; sq.out = (u64 *)d_c; sq.rows = batch;
+        sq.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
+        sq.c_evals = (u64 *)d_c_evals; sq.a_evals = (u64 *)d_a_evals_out; sq.b_evals = (u64 *)d_b_evals_out;
         if (d_work && dp.log_n > 14) sq.mid = (uint32_t *)d_work;                                // caller-owned scratch (e.g. inside a capture): 2 * batch * n * 8 bytes hold both
         else if ((rc = fhe_smallq_scratch(dp.log_n, 2 * batch, st, &sq)) != FHE_OK) return rc;  // two operands' u32 intermediates
         if (sq.mid) sq.mid_b = sq.mid + ((u64)batch << dp.log_n);

@@ -201,38 +201,76 @@ __global__ __launch_bounds__(256) void sq_inverse_kernel(SmallQArgs a) {
 }
 
 // ---- Rq x Rq: forward(a), forward(b), pointwise product, inverse — one kernel -------------------------------------------
+// ring_nq.rs:586-607 with its cached evals: an operand flagged as evals (flags bit 0 / 1) is read as such (no forward
+// transform); c_evals / a_evals / b_evals, when given, receive the canonical transforms of the product and of the operands
+// (ring_nq.rs:568-573,606).  NTT-domain rows move through the tile so that a wave touches 512 contiguous bytes.
 template <int LP>
 __global__ __launch_bounds__(256) void sq_rq_mul_kernel(SmallQArgs a) {
     using C = ContigCfg<LP>;
+    using K = SqCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
-    SqLds l;
-    {
-        using K = SqCfg<LP>;
-        l.tile_a = reinterpret_cast<u32 *>(smem_raw);
-        l.tile_b = reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES);
-        l.ltw = reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES);
-        Tw32 *ltw_inv = l.ltw + C::LTW_N;
-        stage_tw32(l.ltw, a.tw_fwd, C::LTW_N, tid);
-        stage_tw32(ltw_inv, a.tw_inv, C::LTW_N, tid);
-        __syncthreads();
-    }
-    const Tw32 *ltw_inv = l.ltw + C::LTW_N;
+    u32 *tile_a = reinterpret_cast<u32 *>(smem_raw), *tile_b = reinterpret_cast<u32 *>(smem_raw + K::TILE_BYTES);
+    Tw32 *ltw = reinterpret_cast<Tw32 *>(smem_raw + 2 * K::TILE_BYTES), *ltw_inv = ltw + C::LTW_N;
+    stage_tw32(ltw, a.tw_fwd, C::LTW_N, tid);
+    stage_tw32(ltw_inv, a.tw_inv, C::LTW_N, tid);
+    __syncthreads();
     const u64 R0 = (u64)blockIdx.x * C::W;
-    const u64 row = min(R0 + w, a.rows - 1);
+    const bool active = R0 + w < a.rows;
+    const u64 row = min(R0 + w, a.rows - 1);                    // idle units redo the last row and store nothing
     const u32 q = a.q, q2 = 2u * q;
-    u32 va[16], vb[16];
-    sq_load_natural<LP>(va, a.a + row * C::M, tf, q, a.bq);
-    sq_load_natural<LP>(vb, a.b + row * C::M, tf, q, a.bq);
-    sq_fwd2<LP>(va, vb, l.tile_a, l.tile_b, l.ltw, a.tw_fwd, w, tf, q, q2);
+    // evals in: coalesced words into the (free) tile, then the thread's 16 consecutive values — window [0,4)
+    auto load_evals = [&](u32 (&v)[16], const u64 *__restrict__ src, u32 *tile) {
 #pragma unroll
-    for (int k = 0; k < 16; k++)                                // both below 2q: the product is below q * 2^32
-        va[k] = sq_mont(barrett2p_32(va[k], q, a.bq), barrett2p_32(vb[k], q, a.bq), q, a.qinv_neg);
-    sq_inv1<LP, false>(va, l.tile_a, ltw_inv, a.tw_inv, w, tf, q, q2);
-    if (R0 + w < a.rows) {
+        for (int k = 0; k < 16; k++) tile[pad16(w * C::M + (u32)k * C::TPB + tf)] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TPB + tf], q, a.bq), q);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = tile[pad16(w * C::M + tf * 16u + k)];
+    };
+    // evals out (canonical window-[0,4) values): barrier first — the tile may still be gathered from
+    auto store_evals = [&](u64 *__restrict__ dst, const u32 (&v)[16], u32 *tile) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) tile[pad16(w * C::M + tf * 16u + k)] = v[k];
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[row * C::M + (u32)k * C::TPB + tf] = tile[pad16(w * C::M + (u32)k * C::TPB + tf)];
+        }
+    };
+    u32 va[16], vb[16];
+    if (a.flags == 0u) {
+        sq_load_natural<LP>(va, a.a + row * C::M, tf, q, a.bq);
+        sq_load_natural<LP>(vb, a.b + row * C::M, tf, q, a.bq);
+        sq_fwd2<LP>(va, vb, tile_a, tile_b, ltw, a.tw_fwd, w, tf, q, q2);
+    } else {
+        if (a.flags & 1u) load_evals(va, a.a + row * C::M, tile_a);
+        else { sq_load_natural<LP>(va, a.a + row * C::M, tf, q, a.bq); sq_fwd1<LP>(va, tile_a, ltw, a.tw_fwd, w, tf, q, q2); }
+        if (a.flags & 2u) load_evals(vb, a.b + row * C::M, tile_b);
+        else { sq_load_natural<LP>(vb, a.b + row * C::M, tf, q, a.bq); sq_fwd1<LP>(vb, tile_b, ltw, a.tw_fwd, w, tf, q, q2); }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                              // canonical: what the evals outputs hold
+        va[k] = csub_u32(barrett2p_32(va[k], q, a.bq), q);
+        vb[k] = csub_u32(barrett2p_32(vb[k], q, a.bq), q);
+    }
+    if (a.a_evals) store_evals(a.a_evals, va, tile_a);
+    if (a.b_evals) store_evals(a.b_evals, vb, tile_b);
+    Tw32 scale = a.ninv_mont;
+    if (a.c_evals) {                                            // the product itself, canonical (zip_eq(l,r).map(l*r), ring_nq.rs:601-604)
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = reduce64_32((u64)va[k] * vb[k], q, a.mu);
+        store_evals(a.c_evals, va, tile_b);
+        scale = a.ninv;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = sq_mont(va[k], vb[k], q, a.qinv_neg);       // * 2^-32: leaves with n^-1 below
+    }
+    sq_inv1<LP, false>(va, tile_a, ltw_inv, a.tw_inv, w, tf, q, q2);
+    if (active) {
         u64 *__restrict__ dst = a.out + row * C::M;
 #pragma unroll
-        for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = csub_u32(mul_shoup32(va[k], a.ninv_mont, q), q);   // * n^-1 * 2^32
+        for (int k = 0; k < 16; k++) dst[(u32)k * C::TPB + tf] = csub_u32(mul_shoup32(va[k], scale, q), q);
     }
 }
 

@@ -14,6 +14,10 @@ struct SmallQArgs {
     Tw32 ninv, ninv_mont;          // n^-1 mod q; n^-1 * 2^32 mod q (after a Montgomery product)
     const u64 *a, *b;              // rows of n 64-bit words (b: the product's second operand)
     u64 *out;
+    // the product's cached evals (ring_nq.rs:586-607): flags bit 0 / 1 = a / b hold NTT-domain values; optional evals outputs
+    uint32_t flags;
+    u64 *c_evals, *a_evals, *b_evals;
+    u64 mu;                        // floor(2^64 / q)
     uint32_t *mid, *mid_b;         // two-pass sizes (n > 2^14): rows * n u32 words between the passes, per operand (smallq_scratch_bytes)
     u64 rows;
 };

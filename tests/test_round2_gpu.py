@@ -423,6 +423,36 @@ def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
     assert torch.equal(c2, c)
 
 
+@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 19), (Q16, 4096, 3), (12289, 1024, 5)])
+def test_small_modulus_product_with_cached_evals(pkg, oracle, q, n, batch):
+    """ring_nq.rs:586-607 at a small modulus, n <= 4096 (sq_rq_mul_kernel): every combination of operands given as cached
+    evals, with the three evals outputs — the words of the oracle's mul / mul_mut, through the 32-bit kernel (timer name)."""
+    import torch
+
+    B = pkg.binding
+    plan = pkg.Plan(q, n)
+    rng = np.random.default_rng(3 * q + n)
+    a = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    b = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    wc, wce, wae, wbe = (x.reshape(batch, n) for x in oracle.rq_mul(q, n, a, b))
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda()
+    for a_ev in (False, True):
+        for b_ev in (False, True):
+            da, db = dev(wae if a_ev else a), dev(wbe if b_ev else b)
+            c, ce, ae, be = (torch.zeros((batch, n), dtype=torch.int64, device="cuda") for _ in range(4))
+            B.kernel_timing_reset(); B.kernel_timing_enable(True)
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch, a_is_evals=a_ev, b_is_evals=b_ev,
+                            d_c_evals=ce.data_ptr(), d_a_evals=ae.data_ptr(), d_b_evals=be.data_ptr())
+            torch.cuda.synchronize()
+            assert f"sq_rq_mul_{n.bit_length() - 1}" in set(B.kernel_timing_read())
+            B.kernel_timing_enable(False)
+            assert np.array_equal(_u64(c), wc) and np.array_equal(_u64(ce), wce), (a_ev, b_ev)
+            assert np.array_equal(_u64(ae), wae) and np.array_equal(_u64(be), wbe), (a_ev, b_ev)
+            c2 = torch.zeros_like(c)                            # no evals outputs: the Montgomery form of the product
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c2.data_ptr(), batch, a_is_evals=a_ev, b_is_evals=b_ev)
+            assert torch.equal(c2, c), (a_ev, b_ev)
+
+
 @pytest.mark.parametrize("q,n,batch", [(Q16, 32768, 3), (786433, 65536, 2), (786433, 131072, 1)])
 def test_small_modulus_two_pass_transforms(pkg, oracle, q, n, batch):
     """2^15 <= n <= 2^17 at q < 2^32 / 25 (q = 65537's largest n; 786433 = 3 * 2^18 + 1): strided 32-bit pass + 2^14-point

@@ -339,17 +339,49 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQAr
     __syncthreads();
     const u64 row = blockIdx.x;
     const u32 q = a.q, q2 = 2u * q;
-    u32 va[1][16], vb[1][16];
-    sq_big_load<LP>(va, a.a + row * C::M, tf, q, a.bq);
-    fwd_big<LP, 0>(va, lds, ltw, a.tw_fwd, tf, q, q2, a.bq);
-    sq_big_load<LP>(vb, a.b + row * C::M, tf, q, a.bq);
-    fwd_big<LP, 0>(vb, lds, ltw, a.tw_fwd, tf, q, q2, a.bq);
+    // cached evals (see sq_rq_mul_kernel): NTT-domain rows through the tile, barrier first (it may still be gathered from)
+    auto load_evals = [&](u32 (&v)[1][16], const u64 *__restrict__ src) {
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) va[0][k] = sq_mont(barrett2p_32(va[0][k], q, a.bq), barrett2p_32(vb[0][k], q, a.bq), q, a.qinv_neg);
+        for (int k = 0; k < 16; k++) lds[pad16((u32)k * C::TH + tf)] = csub_u32(barrett2p_32((u32)src[(u32)k * C::TH + tf], q, a.bq), q);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[0][k] = lds[pad16(tf * 16u + k)];
+    };
+    auto store_evals = [&](u64 *__restrict__ dst, const u32 (&v)[1][16]) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[pad16(tf * 16u + k)] = v[0][k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = lds[pad16((u32)k * C::TH + tf)];
+    };
+    u32 va[1][16], vb[1][16];
+    if (a.flags & 1u) load_evals(va, a.a + row * C::M);
+    else { sq_big_load<LP>(va, a.a + row * C::M, tf, q, a.bq); fwd_big<LP, 0>(va, lds, ltw, a.tw_fwd, tf, q, q2, a.bq); }
+    if (a.flags & 2u) load_evals(vb, a.b + row * C::M);
+    else { sq_big_load<LP>(vb, a.b + row * C::M, tf, q, a.bq); fwd_big<LP, 0>(vb, lds, ltw, a.tw_fwd, tf, q, q2, a.bq); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        va[0][k] = csub_u32(barrett2p_32(va[0][k], q, a.bq), q);
+        vb[0][k] = csub_u32(barrett2p_32(vb[0][k], q, a.bq), q);
+    }
+    if (a.a_evals) store_evals(a.a_evals + row * C::M, va);
+    if (a.b_evals) store_evals(a.b_evals + row * C::M, vb);
+    Tw32 scale = a.ninv_mont;
+    if (a.c_evals) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[0][k] = reduce64_32((u64)va[0][k] * vb[0][k], q, a.mu);
+        store_evals(a.c_evals + row * C::M, va);
+        scale = a.ninv;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[0][k] = sq_mont(va[0][k], vb[0][k], q, a.qinv_neg);
+    }
     inv_big<LP>(va, lds, ltw_inv, a.tw_inv, tf, q, q2);
     u64 *__restrict__ dst = a.out + row * C::M;
 #pragma unroll
-    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(mul_shoup32(va[0][k], a.ninv_mont, q), q);
+    for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(mul_shoup32(va[0][k], scale, q), q);
 }
 
 // ---- two-pass sizes 2^15 <= n <= 2^17 ----------------------------------------------------------------------------------

@@ -423,9 +423,9 @@ def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
     assert torch.equal(c2, c)
 
 
-@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 19), (Q16, 4096, 3), (12289, 1024, 5)])
+@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 19), (Q16, 4096, 3), (12289, 1024, 5), (Q16, 8192, 2), (Q16, 16384, 2)])
 def test_small_modulus_product_with_cached_evals(pkg, oracle, q, n, batch):
-    """ring_nq.rs:586-607 at a small modulus, n <= 4096 (sq_rq_mul_kernel): every combination of operands given as cached
+    """ring_nq.rs:586-607 at a small modulus, n <= 16384 (sq_rq_mul_kernel, sq_big_rq_mul_kernel): every combination of operands given as cached
     evals, with the three evals outputs — the words of the oracle's mul / mul_mut, through the 32-bit kernel (timer name)."""
     import torch
 

@@ -701,9 +701,7 @@ extern "C" int fhe_rq_mul_dev(const fhe_ntt_plan *plan, const void *d_a, int a_i
 
     // small modulus, plain product (no cached evals in or out): the whole product in 32-bit words (smallq.hip)
     fhe::SmallQArgs sq{};
-    const bool plain = !a_is_evals && !b_is_evals && !d_c_evals && !d_a_evals_out && !d_b_evals_out;
-    // (cached evals in or out: the single-workgroup sizes n <= 16384 of smallq.hip; the two-pass sizes with evals keep the 61-bit kernels)
-    if ((plain || dp.log_n <= 14) && fhe_smallq_args(plan, dp, &sq)) {
+    if (fhe_smallq_args(plan, dp, &sq)) {
         sq.a = (const u64 *)d_a; sq.b = (const u64 *)d_b; sq.out = (u64 *)d_c; sq.rows = batch;
         sq.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
         sq.c_evals = (u64 *)d_c_evals; sq.a_evals = (u64 *)d_a_evals_out; sq.b_evals = (u64 *)d_b_evals_out;

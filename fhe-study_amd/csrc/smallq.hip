@@ -542,26 +542,77 @@ __global__ __launch_bounds__(256) void sq2_block_mul_kernel(SmallQArgs a, u32 la
     sq_stage_block(ltw_inv, a.tw_inv, C::LTW_N, tf, la, blk);
     __syncthreads();
     const u32 q = a.q, q2 = 2u * q;
+    // cached evals (ring_nq.rs:586-607): a block of an operand's / the product's evals IS the block's 4096 NTT-domain words
+    auto load_evals = [&](u32 (&v)[16], const u64 *__restrict__ src, u32 *tile) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) tile[pad16((u32)k * C::TPB + tf)] = csub_u32(barrett2p_32((u32)src[base + (u32)k * C::TPB + tf], q, a.bq), q);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = tile[pad16(tf * 16u + k)];
+    };
+    auto store_evals = [&](u64 *__restrict__ dst, const u32 (&v)[16], u32 *tile) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) tile[pad16(tf * 16u + k)] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[base + (u32)k * C::TPB + tf] = tile[pad16((u32)k * C::TPB + tf)];
+    };
+    // one operand's block: u32 intermediate of its strided pass -> the 12 block stages, alone on its tile
+    auto forward1 = [&](u32 (&v)[16], const u32 *__restrict__ mid, u32 *tile) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = mid[base + (u32)k * C::TPB + tf];
+        Tw32 t[15];
+        load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
+        round_fwd32_tw<C::R0, 0, true>(v, t, q, q2);
+        load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
+        exchange32<LP, C::A0, C::a_of(1), true>(v, tile, 0u, tf);
+        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+        load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
+        exchange32<LP, C::a_of(1), C::a_of(2), false>(v, tile, 0u, tf);
+        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+    };
     u32 va[16], vb[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        va[k] = a.mid[base + (u32)k * C::TPB + tf];
-        vb[k] = a.mid_b[base + (u32)k * C::TPB + tf];
-    }
     Tw32 t[15];
-    load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
-    round_fwd32_tw<C::R0, 0, true>(va, t, q, q2);
-    round_fwd32_tw<C::R0, 0, true>(vb, t, q, q2);
-    load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
-    sq_exchange2<LP, C::A0, C::a_of(1), true>(va, vb, la_tile, lb_tile, 0u, tf);
-    round_fwd32_tw<4, 0, true>(va, t, q, q2);
-    round_fwd32_tw<4, 0, true>(vb, t, q, q2);
-    load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
-    sq_exchange2<LP, C::a_of(1), C::a_of(2), false>(va, vb, la_tile, lb_tile, 0u, tf);
-    round_fwd32_tw<4, 0, true>(va, t, q, q2);
-    round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+    if (a.flags == 0u) {                                        // both from their strided passes, in lockstep
 #pragma unroll
-    for (int k = 0; k < 16; k++) va[k] = sq_mont(barrett2p_32(va[k], q, a.bq), barrett2p_32(vb[k], q, a.bq), q, a.qinv_neg);
+        for (int k = 0; k < 16; k++) {
+            va[k] = a.mid[base + (u32)k * C::TPB + tf];
+            vb[k] = a.mid_b[base + (u32)k * C::TPB + tf];
+        }
+        load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
+        round_fwd32_tw<C::R0, 0, true>(va, t, q, q2);
+        round_fwd32_tw<C::R0, 0, true>(vb, t, q, q2);
+        load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
+        sq_exchange2<LP, C::A0, C::a_of(1), true>(va, vb, la_tile, lb_tile, 0u, tf);
+        round_fwd32_tw<4, 0, true>(va, t, q, q2);
+        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+        load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
+        sq_exchange2<LP, C::a_of(1), C::a_of(2), false>(va, vb, la_tile, lb_tile, 0u, tf);
+        round_fwd32_tw<4, 0, true>(va, t, q, q2);
+        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+    } else {
+        if (a.flags & 1u) load_evals(va, a.a, la_tile); else forward1(va, a.mid, la_tile);
+        if (a.flags & 2u) load_evals(vb, a.b, lb_tile); else forward1(vb, a.mid_b, lb_tile);
+    }
+    const bool keep = a.c_evals || a.a_evals || a.b_evals;
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            va[k] = csub_u32(barrett2p_32(va[k], q, a.bq), q);
+            vb[k] = csub_u32(barrett2p_32(vb[k], q, a.bq), q);
+        }
+        if (a.a_evals) store_evals(a.a_evals, va, la_tile);
+        if (a.b_evals) store_evals(a.b_evals, vb, lb_tile);
+    }
+    if (a.c_evals) {                                            // canonical product: the strided inverse then scales by n^-1 alone
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = reduce64_32((u64)va[k] * vb[k], q, a.mu);
+        store_evals(a.c_evals, va, lb_tile);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = sq_mont(barrett2p_32(va[k], q, a.bq), barrett2p_32(vb[k], q, a.bq), q, a.qinv_neg);
+    }
     load_tw32<4>(t, C::in_lds(2) ? ltw_inv : a.tw_inv, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
     round_inv32_tw<4>(va, t, q, q2);
     load_tw32<4>(t, C::in_lds(1) ? ltw_inv : a.tw_inv, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
@@ -659,11 +710,11 @@ static hipError_t sq2_mul_launch(KF sfwd, KI sinv, int log_n, const SmallQArgs &
     constexpr size_t lds = 2 * SqCfg<kSqBlockLog>::TILE_BYTES + 2 * SqCfg<kSqBlockLog>::TW_BYTES;
     SmallQArgs fa = a, fb = a, inv = a;
     fb.a = a.b; fb.mid = a.mid_b;                               // strided forward of b into its own intermediate
-    inv.ninv = a.ninv_mont;                                     // the Montgomery product's 2^-32 leaves with n^-1
+    if (!a.c_evals) inv.ninv = a.ninv_mont;                     // the Montgomery product's 2^-32 leaves with n^-1
     {
-        KernelTimer kt("sq2_strided_fwd", log_n, st);
-        hipLaunchKernelGGL(sfwd, dim3((unsigned)gs), dim3(256), 0, st, fa);
-        hipLaunchKernelGGL(sfwd, dim3((unsigned)gs), dim3(256), 0, st, fb);
+        KernelTimer kt("sq2_strided_fwd", log_n, st);           // operands given as evals have no strided pass
+        if (!(a.flags & 1u)) hipLaunchKernelGGL(sfwd, dim3((unsigned)gs), dim3(256), 0, st, fa);
+        if (!(a.flags & 2u)) hipLaunchKernelGGL(sfwd, dim3((unsigned)gs), dim3(256), 0, st, fb);
     }
     if (hipError_t e = hipGetLastError()) return e;
     {

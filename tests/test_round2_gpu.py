@@ -423,9 +423,10 @@ def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
     assert torch.equal(c2, c)
 
 
-@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 19), (Q16, 4096, 3), (12289, 1024, 5), (Q16, 8192, 2), (Q16, 16384, 2)])
+@pytest.mark.parametrize("q,n,batch", [(Q16, 256, 19), (Q16, 4096, 3), (12289, 1024, 5), (Q16, 8192, 2), (Q16, 16384, 2),
+                                        (Q16, 32768, 2), (786433, 65536, 1)])                      # two-pass sizes: the middle kernel
 def test_small_modulus_product_with_cached_evals(pkg, oracle, q, n, batch):
-    """ring_nq.rs:586-607 at a small modulus, n <= 16384 (sq_rq_mul_kernel, sq_big_rq_mul_kernel): every combination of operands given as cached
+    """ring_nq.rs:586-607 at a small modulus (sq_rq_mul_kernel, sq_big_rq_mul_kernel, sq2_block_mul_kernel): every combination of operands given as cached
     evals, with the three evals outputs — the words of the oracle's mul / mul_mut, through the 32-bit kernel (timer name)."""
     import torch
 
@@ -444,7 +445,7 @@ def test_small_modulus_product_with_cached_evals(pkg, oracle, q, n, batch):
             plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch, a_is_evals=a_ev, b_is_evals=b_ev,
                             d_c_evals=ce.data_ptr(), d_a_evals=ae.data_ptr(), d_b_evals=be.data_ptr())
             torch.cuda.synchronize()
-            assert f"sq_rq_mul_{n.bit_length() - 1}" in set(B.kernel_timing_read())
+            assert {f"sq_rq_mul_{n.bit_length() - 1}", f"sq2_block_mul_{n.bit_length() - 1}"} & set(B.kernel_timing_read())
             B.kernel_timing_enable(False)
             assert np.array_equal(_u64(c), wc) and np.array_equal(_u64(ce), wce), (a_ev, b_ev)
             assert np.array_equal(_u64(ae), wae) and np.array_equal(_u64(be), wbe), (a_ev, b_ev)

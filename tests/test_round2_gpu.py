@@ -452,6 +452,16 @@ def test_small_modulus_product_with_cached_evals(pkg, oracle, q, n, batch):
             c2 = torch.zeros_like(c)                            # no evals outputs: the Montgomery form of the product
             plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c2.data_ptr(), batch, a_is_evals=a_ev, b_is_evals=b_ev)
             assert torch.equal(c2, c), (a_ev, b_ev)
+    # aliasing the reference's mul_mut / in-place uses produce: c over a; c over an evals input; a's evals over a
+    da, db = dev(a), dev(b)
+    plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), da.data_ptr(), batch)
+    assert np.array_equal(_u64(da), wc)
+    da, db = dev(wae), dev(b)
+    plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), da.data_ptr(), batch, a_is_evals=True)
+    assert np.array_equal(_u64(da), wc)
+    da, db, c = dev(a), dev(b), torch.zeros((batch, n), dtype=torch.int64, device="cuda")
+    plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch, d_a_evals=da.data_ptr())
+    assert np.array_equal(_u64(da), wae) and np.array_equal(_u64(c), wc)
 
 
 @pytest.mark.parametrize("q,n,batch", [(Q16, 32768, 3), (786433, 65536, 2), (786433, 131072, 1)])

@@ -131,3 +131,16 @@ def mul_mut(lhs, rhs):
     if rhs.evals is None:
         rhs.evals = b_evals.reshape(shape)
     return Rq(lhs.param, c.reshape(shape), c_evals.reshape(shape))
+
+
+def pm_params(q):
+    """The pseudo-Mersenne form the engine detects at plan time (csrc/capi.hip: build_plan, csrc/zq_device.hpp):
+    q = 2^k - delta with 56 <= k <= 61 and delta <= 2^(k-39).  Such a modulus (2^61 - 2^21 + 1 is one) runs the
+    five-multiply butterflies on tables {w, w 2^32 mod q}; returns the kernels' constants, or None.  Host-side
+    restatement for the tests and for callers choosing a modulus; the library decides on its own."""
+    k = int(q).bit_length()
+    delta = (1 << k) - q
+    if not (56 <= k <= 61 and delta <= 1 << (k - 39)):
+        return None
+    return {"k": k, "delta": delta, "c2": 2 * delta, "sh": k - 31, "mask": (1 << (k - 31)) - 1,
+            "rsh": k - 32, "rmask": (1 << (k - 32)) - 1}

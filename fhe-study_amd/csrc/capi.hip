@@ -128,6 +128,27 @@ static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
     p->ninv.wp = shoup(p->n_inv, q);
     p->s_ninv.w = mulmod(p->roots_inv[1], p->n_inv, q);
     p->s_ninv.wp = shoup(p->s_ninv.w, q);
+    // Pseudo-Mersenne form q = 2^k - delta, 56 <= k <= 61, delta <= 2^(k-39) (zq_device.hpp): the transforms then run the
+    // five-multiply butterflies on {w, w 2^32 mod q}.  2^61 - 2^21 + 1 (SURVEY.md section 8's modulus) qualifies.
+    p->mod.q3p1 = 3 * q + 1;
+    {
+        unsigned k = 0;
+        while ((q >> k) != 0) k++;                       // 2^(k-1) <= q < 2^k
+        const u64 delta = (k < 64 ? (1ull << k) : 0ull) - q;
+        if (k >= 56 && k <= 61 && delta <= (1ull << (k - 39))) {
+            p->mod.pm_k = k;
+            p->mod.pm_delta = (uint32_t)delta;
+            p->mod.pm_c2 = (uint32_t)(2 * delta);
+            p->mod.pm_sh = k - 31;
+            p->mod.pm_mask = (1u << (k - 31)) - 1u;
+            p->mod.pm_rsh = k - 32;
+            p->mod.pm_rmask = (1u << (k - 32)) - 1u;
+            p->ninv_pm.w = p->ninv.w;
+            p->ninv_pm.wp = mulmod(p->ninv.w, 1ull << 32, q);
+            p->s_ninv_pm.w = p->s_ninv.w;
+            p->s_ninv_pm.wp = mulmod(p->s_ninv.w, 1ull << 32, q);
+        }
+    }
     return FHE_OK;
 }
 
@@ -257,6 +278,29 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
                 return hip_fail(e, "uploading the 32-bit twiddle tables");
             }
         }
+        // pseudo-Mersenne moduli: the second pair of tables, {w, w 2^32 mod q}
+        fhe::Tw *pf = nullptr, *pi = nullptr;
+        if (plan->mod.pm_k != 0) {
+            for (u64 k = 0; k < n; k++) {
+                f[k].wp = mulmod(plan->roots[k], 1ull << 32, q);
+                i[k].wp = mulmod(plan->roots_inv[k], 1ull << 32, q);
+            }
+            e = hipMalloc((void **)&pf, n * sizeof(fhe::Tw));
+            if (e == hipSuccess) e = hipMalloc((void **)&pi, n * sizeof(fhe::Tw));
+            if (e == hipSuccess) e = hipMemcpy(pf, f.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(pi, i.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (pf) (void)hipFree(pf);
+                if (pi) (void)hipFree(pi);
+                if (sf) (void)hipFree(sf);
+                if (si) (void)hipFree(si);
+                (void)hipFree(df); (void)hipFree(di);
+                if (dl) (void)hipFree(dl);
+                return hip_fail(e, "uploading the pseudo-Mersenne twiddle tables");
+            }
+        }
+        t.tw_fwd_pm = pf;
+        t.tw_inv_pm = pi;
         t.tw_fwd = df;
         t.tw_inv = di;
         t.digit_lut = dl;
@@ -274,7 +318,18 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     dp->s_ninv = plan->s_ninv;
     dp->log_n = plan->log_n;
     dp->wide = (plan->q >> 61) == 0;
+    dp->tw_fwd_pm = t.tw_fwd_pm;
+    dp->tw_inv_pm = t.tw_inv_pm;
+    dp->ninv_pm = plan->ninv_pm;
+    dp->s_ninv_pm = plan->s_ninv_pm;
+    dp->arith = (t.tw_fwd_pm && fhe_pm_enabled()) ? 2 : dp->wide ? 1 : 0;
     return FHE_OK;
+}
+
+// FHE_PM=0 (read once): pseudo-Mersenne moduli stay on the Shoup kernels — how the A/B numbers of DESIGN.md were taken
+bool fhe_pm_enabled() {
+    static const bool on = [] { const char *e = getenv("FHE_PM"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 extern "C" int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan) {
@@ -979,6 +1034,8 @@ extern "C" int fhe_ntt_shutdown(void) {
             if (t.digit_lut) (void)hipFree(t.digit_lut);
             if (t.tw32_fwd) (void)hipFree(t.tw32_fwd);
             if (t.tw32_inv) (void)hipFree(t.tw32_inv);
+            if (t.tw_fwd_pm) (void)hipFree(t.tw_fwd_pm);
+            if (t.tw_inv_pm) (void)hipFree(t.tw_inv_pm);
             t = DeviceTables();
         }
     }

@@ -17,6 +17,7 @@ struct DeviceTables {
     fhe::Tw *tw_inv = nullptr;
     fhe::u64 *digit_lut = nullptr;   // 136 words, n >= 8 (ntt_rounds.hpp: round0_bits)
     fhe::Tw32 *tw32_fwd = nullptr, *tw32_inv = nullptr;   // small moduli (smallq.hip)
+    fhe::Tw *tw_fwd_pm = nullptr, *tw_inv_pm = nullptr;   // pseudo-Mersenne moduli: {w, w 2^32 mod q} (zq_device.hpp)
     bool ready = false;
 };
 
@@ -26,6 +27,7 @@ struct fhe_ntt_plan {
     std::vector<fhe::u64> roots, roots_inv;  // as the reference's CACHE value (ntt.rs:18)
     fhe::Mod mod{};
     fhe::Tw ninv{}, s_ninv{};
+    fhe::Tw ninv_pm{}, s_ninv_pm{};   // the same two constants as {w, w 2^32 mod q} when mod.pm_k != 0
     mutable std::mutex dev_lock;
     mutable DeviceTables dev[kMaxDevices];
 };
@@ -51,6 +53,7 @@ namespace fhe { struct SmallQArgs; }
 // fills the modulus-dependent fields when the plan has a 32-bit form on this device (smallq.hip) and FHE_EXT32 is on
 bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a);
 int fhe_smallq_scratch(unsigned log_n, uint64_t rows, hipStream_t st, fhe::SmallQArgs *a);   // a->mid for n > 2^14
+bool fhe_pm_enabled();                                 // FHE_PM=0 keeps pseudo-Mersenne moduli on the Shoup kernels
 bool fhe_ext32_enabled();                              // FHE_EXT32=0 keeps every product on the 61-bit kernels
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
 int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);

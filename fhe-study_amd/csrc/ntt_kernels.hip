@@ -33,8 +33,12 @@ namespace fhe {
 // polynomials never exist in memory.
 // SRC_REDUCE (single-pass sizes only; the two-pass sizes do it in the strided pass): the input
 // rows are 2^src_log_n arbitrary 64-bit words, reduced mod q and zero-padded to n in the load.
-template <int LP, bool FINAL, bool WIDE, int SRC = SRC_PLAIN>
+// AR: 0 = q < 2^62 (Harvey [0,4q)), 1 = q < 2^61 (Shoup, compile-time bounds), 2 = pseudo-Mersenne q (zq_device.hpp:
+// five-multiply butterflies; `a.tw` then holds {w, w 2^32 mod q}; SRC_PLAIN only).
+template <int LP, bool FINAL, int AR, int SRC = SRC_PLAIN>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
+    constexpr bool WIDE = AR == 1;
+    static_assert(AR != 2 || SRC == SRC_PLAIN, "transforming loads run on the Shoup tables");
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -105,6 +109,8 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
         for (u32 i = tid; i < (u32)kDigitLutWords; i += C::TH) llut[i] = a.lut[i];
         __syncthreads();
         fwd_rounds_contig<LP, WIDE, FINAL, 2, true, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, llut);
+    } else if constexpr (AR == 2) {
+        fwd_rounds_contig_pm<LP, kPmPassBound, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
     } else {
         fwd_rounds_contig<LP, WIDE, FINAL, kPassBound, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
     }
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u64 x = FINAL ? canon4(v[k], m) : v[k];   // FINAL: < 4q in both modes
+        const u64 x = !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : canon4(v[k], m);   // FINAL: < 4q in both Shoup modes
         lds[pad16(w * C::M + field_of<ALAST>(tf, k))] = x;
     }
     __syncthreads();
@@ -130,8 +136,9 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
 // MUL_IN: the input is the pointwise product in .* in2 (fused
 // zip_eq(l,r).map(l*r), ring_nq.rs:601-604); if a.out2 != nullptr the product
 // (the `evals` of the result, ring_nq.rs:606) is also written there.
-template <int LP, bool FINAL, bool MUL_IN, bool WIDE>
+template <int LP, bool FINAL, bool MUL_IN, int AR>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassArgs a) {
+    constexpr bool WIDE = AR == 1;
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -181,12 +188,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
 
     __syncthreads();
     // inputs are canonical (evals, or their product); a non-FINAL pass hands values below 4q (WIDE) / 2q on
-    inv_rounds_contig<LP, WIDE, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) inv_rounds_contig_pm<LP, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    else inv_rounds_contig<LP, WIDE, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
 
     if (active) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, FINAL ? canon2(v[k], m) : v[k]);
+            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : canon2(v[k], m));
     }
 }
 
@@ -248,8 +256,9 @@ __device__ __forceinline__ void inv_rounds_single(u64 (&v)[16], u64 *lds, const 
     round_inv_sel<C::R0, true, WIDE, (C::NR == 1 ? BF : BN)>(v, TW(C::in_lds(0)), 1u, m, ninv, s_ninv);
 }
 
-template <int LP, bool WIDE>
+template <int LP, int AR>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArgs a) {
+    constexpr bool WIDE = AR == 1;
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -280,7 +289,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = ld_c<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
-            fwd_rounds_single<LP, WIDE, decltype(fresh)::value>(v, lds, ltw_f, a.tw, w, tf, m);
+            if constexpr (AR == 2) {
+                fwd_rounds_contig_pm<LP, kPmOne, decltype(fresh)::value>(v, lds, ltw_f, a.tw, 0u, 0u, w, tf, m);
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = pm_canon(v[k], m);
+            } else {
+                fwd_rounds_single<LP, WIDE, decltype(fresh)::value>(v, lds, ltw_f, a.tw, w, tf, m);
+            }
         }
     };
     auto store_evals = [&](u64 *dst, const u64 (&v)[16]) {
@@ -299,11 +314,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
     for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);   // zip_eq(l,r).map(l*r), ring_nq.rs:601-604
     store_evals(a.out2, va);
     if constexpr (C::NR == 1) { /* twiddles published above */ } else if (a.flags == 3u) __syncthreads();   // no forward exchange ran
-    inv_rounds_single<LP, WIDE>(va, lds, ltw_i, a.tw_inv, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) inv_rounds_contig_pm<LP, true, false>(va, lds, ltw_i, a.tw_inv, 0u, 0u, w, tf, m, a.ninv, a.s_ninv);
+    else inv_rounds_single<LP, WIDE>(va, lds, ltw_i, a.tw_inv, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
 #pragma unroll
-        for (int k = 0; k < 16; k++) st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, canon2(va[k], m));
+        for (int k = 0; k < 16; k++)
+            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, AR == 2 ? pm_canon(va[k], m) : canon2(va[k], m));
     }
 }
 
@@ -320,8 +337,9 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
 // canonical values per thread, no forward stages.  out2 / out3 / out4: the evals of the product and
 // of the two operands (ring_nq.rs:568-573,606), optional.
 // ---------------------------------------------------------------------------
-template <int LP, bool WIDE>
+template <int LP, int AR>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs a) {
+    constexpr bool WIDE = AR == 1;
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -355,10 +373,11 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
-            fwd_rounds_contig<LP, WIDE, true, kPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
+            if constexpr (AR == 2) fwd_rounds_contig_pm<LP, kPmPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
+            else fwd_rounds_contig<LP, WIDE, true, kPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
             if (keep) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = canon4(v[k], m);
+                for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : canon4(v[k], m);
             }
         }
     };
@@ -380,7 +399,8 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     // the inverse rounds' first exchange follows a forward exchange's gather unless both operands were
     // evals; its leading barrier (FRESH = false) also publishes the inverse twiddle tile in that case
     if (a.flags == 3u) __syncthreads();   // no forward exchange ran: publish the twiddle tiles here
-    inv_rounds_contig<LP, WIDE, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) inv_rounds_contig_pm<LP, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    else inv_rounds_contig<LP, WIDE, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
 #pragma unroll
@@ -390,8 +410,10 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
 
 // RSRC: the input rows are 2^src_log_n arbitrary words, reduced mod q and zero-padded in the load
 // (see SRC_REDUCE above).
-template <int LA, int CW, bool WIDE, bool RSRC = false>
+template <int LA, int CW, int AR, bool RSRC = false>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kernel(PassArgs a) {
+    constexpr bool WIDE = AR == 1;
+    static_assert(AR != 2 || !RSRC, "reducing loads run on the Shoup tables");
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -428,24 +450,30 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     // inputs are canonical (bound 2 leaves slack); the pass ends below kPassBound*q (END6)
     constexpr int B0 = 2, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1);
     static_assert(kPassBound == 6, "END6 ends a pass below 6q");
-    round_fwd<C::R0, WIDE, B0, false, C::NR == 1>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
+    constexpr int P0 = kPmOne, P1 = pm_fwd_bound_out(C::R0, P0), P2 = pm_fwd_bound_out(4, P1), P3 = pm_fwd_bound_out(4, P2);
+    static_assert((C::NR == 1 ? P1 : C::NR == 2 ? P2 : P3) <= kPmPassBound, "AR == 2: a strided pass ends below kPmPassBound");
+    if constexpr (AR == 2) round_fwd_pm<C::R0, P0, true>(v, a.tw, 1u, m);
+    else round_fwd<C::R0, WIDE, B0, false, C::NR == 1>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         exchange_strided<CW, C::A0, A, true>(v, lds, c, tf);   // its barrier also publishes ltw
-        round_fwd<4, WIDE, B1, false, C::NR == 2>(v, tw, (1u << LS) + (tf >> A), m);
+        if constexpr (AR == 2) round_fwd_pm<4, P1, false>(v, tw, (1u << LS) + (tf >> A), m);
+        else round_fwd<4, WIDE, B1, false, C::NR == 2>(v, tw, (1u << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         exchange_strided<CW, C::a_of(1), A, false>(v, lds, c, tf);
-        round_fwd<4, WIDE, B2, false, C::NR == 3>(v, tw, (1u << LS) + (tf >> A), m);
+        if constexpr (AR == 2) round_fwd_pm<4, P2, false>(v, tw, (1u << LS) + (tf >> A), m);
+        else round_fwd<4, WIDE, B2, false, C::NR == 3>(v, tw, (1u << LS) + (tf >> A), m);
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) st_at(pout, ((field_of<ALAST>(tf, k) << lb) + c) * 8u, v[k]);  // lazy: < 4q, or < 6q (WIDE)
 }
 
-template <int LA, int CW, bool WIDE>
+template <int LA, int CW, int AR>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kernel(PassArgs a) {
+    constexpr bool WIDE = AR == 1;
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -471,17 +499,21 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     // the contiguous pass before this one hands values below 4q (WIDE) / 2q: every round starts from 4
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        if constexpr (AR == 2) round_inv_pm<4, false, kPmInvBound, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        else round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::a_of(1), true>(v, lds, c, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        if constexpr (AR == 2) round_inv_pm<4, false, kPmInvBound, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        else round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::A0, (C::NR <= 2)>(v, lds, c, tf);
     }
-    round_inv_sel<C::R0, true, WIDE, 4>(v, tw, 1u, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) round_inv_pm<C::R0, true, kPmInvBound, true>(v, a.tw, 1u, m, a.ninv, a.s_ninv);   // uniform: scalar loads
+    else round_inv_sel<C::R0, true, WIDE, 4>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
-    for (int k = 0; k < 16; k++) st_at(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, canon2(v[k], m));
+    for (int k = 0; k < 16; k++)
+        st_at(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, AR == 2 ? pm_canon(v[k], m) : canon2(v[k], m));
 }
 
 // ---------------------------------------------------------------------------
@@ -568,7 +600,7 @@ __global__ __launch_bounds__(256) void check_canonical_kernel(const u64 *__restr
 static inline hipError_t post_launch() { return hipGetLastError(); }
 
 
-template <int LP, bool FINAL, bool WIDE, int SRC = SRC_PLAIN>
+template <int LP, bool FINAL, int AR, int SRC = SRC_PLAIN>
 static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 nb = 1ull << (a.log_n - LP);
@@ -577,14 +609,14 @@ static hipError_t launch_fwd_contig(const PassArgs &a, hipStream_t st) {
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     constexpr size_t lds_bytes = (SRC == SRC_DIGITS || SRC == SRC_ZQBITS) ? C::LDS_BYTES_BITS : C::LDS_BYTES;
-    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>, lds_bytes)) return e;
+    if (hipError_t e = allow_big_lds((const void *)ntt_fwd_contig_kernel<LP, FINAL, AR, SRC>, lds_bytes)) return e;
     KernelTimer kt(SRC == SRC_DIGITS ? "ntt_fwd_digits" : SRC == SRC_ZQBITS ? "ntt_fwd_zqbits" : SRC == SRC_REDUCE ? "ntt_fwd_reduce" : (FINAL ? "ntt_fwd_contig_final" : "ntt_fwd_contig"), LP, st);
-    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, WIDE, SRC>), dim3((unsigned)grid), dim3(C::TH),
+    hipLaunchKernelGGL((ntt_fwd_contig_kernel<LP, FINAL, AR, SRC>), dim3((unsigned)grid), dim3(C::TH),
                        lds_bytes, st, a);
     return post_launch();
 }
 
-template <int LP, bool FINAL, bool MUL_IN, bool WIDE>
+template <int LP, bool FINAL, bool MUL_IN, int AR>
 static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 nb = 1ull << (a.log_n - LP);
@@ -592,82 +624,104 @@ static hipError_t launch_inv_contig(const PassArgs &a, hipStream_t st) {
     const u64 grid = nb * groups;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds((const void *)ntt_inv_contig_kernel<LP, FINAL, MUL_IN, WIDE>, C::LDS_BYTES)) return e;
+    if (hipError_t e = allow_big_lds((const void *)ntt_inv_contig_kernel<LP, FINAL, MUL_IN, AR>, C::LDS_BYTES)) return e;
     KernelTimer kt(MUL_IN ? "ntt_inv_contig_mul" : (FINAL ? "ntt_inv_contig_final" : "ntt_inv_contig"), LP, st);
-    hipLaunchKernelGGL((ntt_inv_contig_kernel<LP, FINAL, MUL_IN, WIDE>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((ntt_inv_contig_kernel<LP, FINAL, MUL_IN, AR>), dim3((unsigned)grid),
                        dim3(C::TH), C::LDS_BYTES, st, a);
     return post_launch();
 }
 
-template <int LA, int CW, bool INV, bool WIDE, bool RSRC = false>
+template <int LA, int CW, bool INV, int AR, bool RSRC = false>
 static hipError_t launch_strided(const PassArgs &a, hipStream_t st, unsigned operands = 1) {
     using C = StridedCfg<LA, CW>;
     const u64 ncg = (1ull << (a.log_n - LA)) / CW;
     const u64 grid = ncg * a.batch;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (hipError_t e = allow_big_lds(INV ? (const void *)ntt_inv_strided_kernel<LA, CW, WIDE>
-                                         : (const void *)ntt_fwd_strided_kernel<LA, CW, WIDE, RSRC>, C::LDS_BYTES)) return e;
+    if (hipError_t e = allow_big_lds(INV ? (const void *)ntt_inv_strided_kernel<LA, CW, AR>
+                                         : (const void *)ntt_fwd_strided_kernel<LA, CW, AR, RSRC>, C::LDS_BYTES)) return e;
     KernelTimer kt(INV ? "ntt_inv_strided" : (RSRC ? "ntt_fwd_strided_reduce" : "ntt_fwd_strided"), LA, st);
     if (INV)
-        hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW, WIDE>), dim3((unsigned)grid), dim3(C::TH),
+        hipLaunchKernelGGL((ntt_inv_strided_kernel<LA, CW, AR>), dim3((unsigned)grid), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     else
-        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, WIDE, RSRC>), dim3((unsigned)grid, operands), dim3(C::TH),
+        hipLaunchKernelGGL((ntt_fwd_strided_kernel<LA, CW, AR, RSRC>), dim3((unsigned)grid, operands), dim3(C::TH),
                            C::LDS_BYTES, st, a);
     return post_launch();
 }
 
 #define CONTIG_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 
-static hipError_t fwd_contig_dispatch(int lp, bool final, bool wide, const PassArgs &a, hipStream_t st) {
+// ar: the kernels' AR (0 / 1 = Shoup tables, 2 = pseudo-Mersenne tables: DevicePlan::arith)
+static hipError_t fwd_contig_dispatch(int lp, bool final, int ar, const PassArgs &a, hipStream_t st) {
     switch (lp) {
 #define X(LP_)                                                                                   \
     case LP_:                                                                                    \
-        if (wide) return final ? launch_fwd_contig<LP_, true, true>(a, st) : launch_fwd_contig<LP_, false, true>(a, st); \
-        return final ? launch_fwd_contig<LP_, true, false>(a, st) : launch_fwd_contig<LP_, false, false>(a, st);
+        if (ar == 2) return final ? launch_fwd_contig<LP_, true, 2>(a, st) : launch_fwd_contig<LP_, false, 2>(a, st); \
+        if (ar == 1) return final ? launch_fwd_contig<LP_, true, 1>(a, st) : launch_fwd_contig<LP_, false, 1>(a, st); \
+        return final ? launch_fwd_contig<LP_, true, 0>(a, st) : launch_fwd_contig<LP_, false, 0>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
     return hipErrorInvalidValue;
 }
 
-template <bool WIDE>
-static hipError_t inv_contig_dispatch(int lp, bool final, bool mul_in, const PassArgs &a,
-                                      hipStream_t st) {
+template <int AR>
+static hipError_t inv_contig_dispatch_ar(int lp, bool final, bool mul_in, const PassArgs &a,
+                                         hipStream_t st) {
     switch (lp) {
 #define X(LP_)                                                                                   \
     case LP_:                                                                                    \
-        if (final) return mul_in ? launch_inv_contig<LP_, true, true, WIDE>(a, st)               \
-                                 : launch_inv_contig<LP_, true, false, WIDE>(a, st);             \
-        return mul_in ? launch_inv_contig<LP_, false, true, WIDE>(a, st)                         \
-                      : launch_inv_contig<LP_, false, false, WIDE>(a, st);
+        if (final) return mul_in ? launch_inv_contig<LP_, true, true, AR>(a, st)                 \
+                                 : launch_inv_contig<LP_, true, false, AR>(a, st);               \
+        return mul_in ? launch_inv_contig<LP_, false, true, AR>(a, st)                           \
+                      : launch_inv_contig<LP_, false, false, AR>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
     return hipErrorInvalidValue;
 }
+static hipError_t inv_contig_dispatch(int ar, int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st) {
+    return ar == 2 ? inv_contig_dispatch_ar<2>(lp, final, mul_in, a, st)
+         : ar == 1 ? inv_contig_dispatch_ar<1>(lp, final, mul_in, a, st)
+                   : inv_contig_dispatch_ar<0>(lp, final, mul_in, a, st);
+}
 
-template <bool INV, bool WIDE>
-static hipError_t strided_dispatch(int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
+template <bool INV, int AR>
+static hipError_t strided_dispatch_ar(int la, const PassArgs &a, hipStream_t st, unsigned operands) {
     switch (la) {
-        case 6: return launch_strided<6, 128, INV, WIDE>(a, st, operands);
-        case 7: return launch_strided<7, 64, INV, WIDE>(a, st, operands);
-        case 8: return launch_strided<8, 32, INV, WIDE>(a, st, operands);   // 16 / 64 columns measured equal / slower
+        case 6: return launch_strided<6, 128, INV, AR>(a, st, operands);
+        case 7: return launch_strided<7, 64, INV, AR>(a, st, operands);
+        case 8: return launch_strided<8, 32, INV, AR>(a, st, operands);   // 16 / 64 columns measured equal / slower
     }
     return hipErrorInvalidValue;
+}
+template <bool INV>
+static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
+    return ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands)
+         : ar == 1 ? strided_dispatch_ar<INV, 1>(la, a, st, operands)
+                   : strided_dispatch_ar<INV, 0>(la, a, st, operands);
+}
+// the tables and n^-1 constants a pass runs on: {w, w 2^32 mod q} for pseudo-Mersenne plans, {w, floor(w 2^64 / q)} otherwise
+static inline void set_tables(PassArgs &a, const DevicePlan &p, bool inverse) {
+    const bool pm = p.arith == 2;
+    a.tw = inverse ? (pm ? p.tw_inv_pm : p.tw_inv) : (pm ? p.tw_fwd_pm : p.tw_fwd);
+    a.mod = p.mod;
+    a.ninv = pm ? p.ninv_pm : p.ninv;
+    a.s_ninv = pm ? p.s_ninv_pm : p.s_ninv;
+    a.log_n = p.log_n;
 }
 
 
 hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
                               u64 batch_tile, hipStream_t st) {
     PassArgs a{};
-    a.tw = p.tw_fwd;
-    a.mod = p.mod;
-    a.ninv = p.ninv;
-    a.s_ninv = p.s_ninv;
-    a.log_n = p.log_n;
     const int L = p.log_n;
+    // n < 16: one thread per polynomial on the Shoup tables
+    const int ar = L < 4 ? (p.wide ? 1 : 0) : p.arith;
+    DevicePlan pt = p;
+    pt.arith = ar;
+    set_tables(a, pt, false);
     if (batch == 0) return hipSuccess;
     if (L < 4) {
         a.in = in; a.out = out; a.batch = batch;
@@ -677,7 +731,7 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
     }
     if (L <= kMaxSinglePassLog) {
         a.in = in; a.out = out; a.batch = batch;
-        return fwd_contig_dispatch(L, true, p.wide, a, st);
+        return fwd_contig_dispatch(L, true, ar, a, st);
     }
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
@@ -685,25 +739,25 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
     for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
         const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile;
         a.in = in + b0 * n; a.out = out + b0 * n; a.batch = nb;
-        hipError_t e = p.wide ? strided_dispatch<false, true>(LA, a, st) : strided_dispatch<false, false>(LA, a, st);
+        hipError_t e = strided_dispatch<false>(ar, LA, a, st);
         if (e != hipSuccess) return e;
         a.in = out + b0 * n;
-        e = fwd_contig_dispatch(LB, true, p.wide, a, st);
+        e = fwd_contig_dispatch(LB, true, ar, a, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-template <int LP, bool WIDE>
+template <int LP, int AR>
 static hipError_t launch_rq_mul_fused_lp(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 grid = (a.batch + C::W - 1) / C::W;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     constexpr size_t lds_bytes = C::LDS_BYTES + (size_t)C::LTW_N * sizeof(Tw);   // a second twiddle tile
-    if (hipError_t e = allow_big_lds((const void *)rq_mul_fused_kernel<LP, WIDE>, lds_bytes)) return e;
+    if (hipError_t e = allow_big_lds((const void *)rq_mul_fused_kernel<LP, AR>, lds_bytes)) return e;
     KernelTimer kt("rq_mul_fused", LP, st);
-    hipLaunchKernelGGL((rq_mul_fused_kernel<LP, WIDE>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
+    hipLaunchKernelGGL((rq_mul_fused_kernel<LP, AR>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
     return post_launch();
 }
 
@@ -713,24 +767,20 @@ hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_eva
     if (L < 4 || L > kMaxSinglePassLog) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     PassArgs a{};
-    a.tw = p.tw_fwd;
-    a.tw_inv = p.tw_inv;
-    a.mod = p.mod;
-    a.ninv = p.ninv;
-    a.s_ninv = p.s_ninv;
-    a.log_n = p.log_n;
+    set_tables(a, p, false);
+    a.tw_inv = p.arith == 2 ? p.tw_inv_pm : p.tw_inv;
     a.in = a_; a.in2 = b_; a.out = c; a.out2 = c_evals; a.out3 = a_evals; a.out4 = b_evals;
     a.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
     a.batch = batch;
     switch (L) {
-#define X(LP_) case LP_: return p.wide ? launch_rq_mul_fused_lp<LP_, true>(a, st) : launch_rq_mul_fused_lp<LP_, false>(a, st);
+#define X(LP_) case LP_: return p.arith == 2 ? launch_rq_mul_fused_lp<LP_, 2>(a, st) : p.arith == 1 ? launch_rq_mul_fused_lp<LP_, 1>(a, st) : launch_rq_mul_fused_lp<LP_, 0>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
     return hipErrorInvalidValue;
 }
 
-template <int LP, bool WIDE>
+template <int LP, int AR>
 static hipError_t launch_rq_mul_mid_lp(const PassArgs &a, hipStream_t st) {
     using C = ContigCfg<LP>;
     const u64 nb = 1ull << (a.log_n - LP);
@@ -738,9 +788,9 @@ static hipError_t launch_rq_mul_mid_lp(const PassArgs &a, hipStream_t st) {
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     constexpr size_t lds_bytes = C::LDS_BYTES + (size_t)C::LTW_N * sizeof(Tw);   // a second twiddle tile
-    if (hipError_t e = allow_big_lds((const void *)rq_mul_mid_kernel<LP, WIDE>, lds_bytes)) return e;
+    if (hipError_t e = allow_big_lds((const void *)rq_mul_mid_kernel<LP, AR>, lds_bytes)) return e;
     KernelTimer kt("rq_mul_mid", LP, st);
-    hipLaunchKernelGGL((rq_mul_mid_kernel<LP, WIDE>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
+    hipLaunchKernelGGL((rq_mul_mid_kernel<LP, AR>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
     return post_launch();
 }
 
@@ -758,39 +808,39 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
     if (batch_tile == 0) batch_tile = batch;
     for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
         const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile, o = b0 * n;
+        const int ar = p.arith;
         PassArgs f{};
-        f.tw = p.tw_fwd; f.mod = p.mod; f.log_n = p.log_n; f.batch = nb;
+        set_tables(f, p, false); f.batch = nb;
         hipError_t e = hipSuccess;
         if (!a_is_evals && !b_is_evals) {
             f.in = a_ + o; f.out = wa + o; f.in2 = b_ + o; f.out2 = wb + o;
-            e = p.wide ? strided_dispatch<false, true>(LA, f, st, 2) : strided_dispatch<false, false>(LA, f, st, 2);
+            e = strided_dispatch<false>(ar, LA, f, st, 2);
         } else if (!a_is_evals) {
             f.in = a_ + o; f.out = wa + o;
-            e = p.wide ? strided_dispatch<false, true>(LA, f, st) : strided_dispatch<false, false>(LA, f, st);
+            e = strided_dispatch<false>(ar, LA, f, st);
         } else if (!b_is_evals) {
             f.in = b_ + o; f.out = wb + o;
-            e = p.wide ? strided_dispatch<false, true>(LA, f, st) : strided_dispatch<false, false>(LA, f, st);
+            e = strided_dispatch<false>(ar, LA, f, st);
         }
         if (e != hipSuccess) return e;
         PassArgs m{};
-        m.tw = p.tw_fwd; m.tw_inv = p.tw_inv; m.mod = p.mod; m.ninv = p.ninv; m.s_ninv = p.s_ninv;
-        m.log_n = p.log_n; m.batch = nb;
+        set_tables(m, p, false); m.tw_inv = ar == 2 ? p.tw_inv_pm : p.tw_inv; m.batch = nb;
         m.in = (a_is_evals ? a_ : wa) + o; m.in2 = (b_is_evals ? b_ : wb) + o;
         m.out = c + o; m.out2 = c_evals ? c_evals + o : nullptr;
         m.out3 = (keep_a_evals && !a_is_evals) ? wa + o : nullptr;
         m.out4 = (keep_b_evals && !b_is_evals) ? wb + o : nullptr;
         m.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
         switch (LB) {
-#define X(LP_) case LP_: e = p.wide ? launch_rq_mul_mid_lp<LP_, true>(m, st) : launch_rq_mul_mid_lp<LP_, false>(m, st); break;
+#define X(LP_) case LP_: e = ar == 2 ? launch_rq_mul_mid_lp<LP_, 2>(m, st) : ar == 1 ? launch_rq_mul_mid_lp<LP_, 1>(m, st) : launch_rq_mul_mid_lp<LP_, 0>(m, st); break;
             X(8) X(9) X(10) X(11) X(12)
 #undef X
             default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;
         PassArgs i{};
-        i.tw = p.tw_inv; i.mod = p.mod; i.ninv = p.ninv; i.s_ninv = p.s_ninv; i.log_n = p.log_n; i.batch = nb;
+        set_tables(i, p, true); i.batch = nb;
         i.in = c + o; i.out = c + o;
-        e = p.wide ? strided_dispatch<true, true>(LA, i, st) : strided_dispatch<true, false>(LA, i, st);
+        e = strided_dispatch<true>(ar, LA, i, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -865,7 +915,7 @@ hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *ou
         }
         if (e != hipSuccess) return e;
         a.in = out + b0 * n;
-        if ((e = fwd_contig_dispatch(LB, true, true, a, st)) != hipSuccess) return e;
+        if ((e = fwd_contig_dispatch(LB, true, 1, a, st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -875,12 +925,11 @@ hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *ou
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st) {
     PassArgs a{};
-    a.tw = p.tw_inv;
-    a.mod = p.mod;
-    a.ninv = p.ninv;
-    a.s_ninv = p.s_ninv;
-    a.log_n = p.log_n;
     const int L = p.log_n;
+    const int ar = L < 4 ? (p.wide ? 1 : 0) : p.arith;
+    DevicePlan pt = p;
+    pt.arith = ar;
+    set_tables(a, pt, true);
     if (batch == 0) return hipSuccess;
     if (L < 4) {
         const u64 *src = in;
@@ -897,8 +946,7 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
     }
     if (L <= kMaxSinglePassLog) {
         a.in = in; a.in2 = in2; a.out2 = evals_out; a.out = out; a.batch = batch;
-        return p.wide ? inv_contig_dispatch<true>(L, true, in2 != nullptr, a, st)
-                      : inv_contig_dispatch<false>(L, true, in2 != nullptr, a, st);
+        return inv_contig_dispatch(ar, L, true, in2 != nullptr, a, st);
     }
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
@@ -908,11 +956,10 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
         a.in = in + b0 * n; a.in2 = in2 ? in2 + b0 * n : nullptr;
         a.out2 = evals_out ? evals_out + b0 * n : nullptr;
         a.out = out + b0 * n; a.batch = nb;
-        hipError_t e = p.wide ? inv_contig_dispatch<true>(LB, false, in2 != nullptr, a, st)
-                              : inv_contig_dispatch<false>(LB, false, in2 != nullptr, a, st);
+        hipError_t e = inv_contig_dispatch(ar, LB, false, in2 != nullptr, a, st);
         if (e != hipSuccess) return e;
         a.in = out + b0 * n; a.in2 = nullptr; a.out2 = nullptr;
-        e = p.wide ? strided_dispatch<true, true>(LA, a, st) : strided_dispatch<true, false>(LA, a, st);
+        e = strided_dispatch<true>(ar, LA, a, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -927,8 +974,8 @@ hipError_t launch_ntt_inverse_first_pass(const DevicePlan &p, const u64 *in, u64
     PassArgs a{};
     a.tw = p.tw_inv; a.mod = p.mod; a.ninv = p.ninv; a.s_ninv = p.s_ninv; a.log_n = p.log_n;
     a.in = in; a.out = out; a.batch = batch;
-    return p.wide ? inv_contig_dispatch<true>(contig_bits(L), false, false, a, st)
-                  : inv_contig_dispatch<false>(contig_bits(L), false, false, a, st);
+    // always on the Shoup tables: the caller's own last pass (zring.hip) continues from them
+    return inv_contig_dispatch(p.wide ? 1 : 0, contig_bits(L), false, false, a, st);
 }
 
 static inline unsigned ew_grid(u64 count) {

@@ -26,6 +26,13 @@ struct DevicePlan {
     Tw s_ninv{};  // roots_inv[1] * n^-1      (last GS stage folded with ntt.rs:100-102)
     uint32_t log_n = 0;
     bool wide = false;  // q < 2^61: forward butterflies correct every other stage
+    // Pseudo-Mersenne q = 2^k - delta (zq_device.hpp; the headline modulus 2^61 - 2^21 + 1): the transforms and the
+    // products run five-multiply butterflies on a second pair of tables {w, w 2^32 mod q}.  The kernels that
+    // transform WHILE loading (digits, reducing loads, zring.hip's epilogues) keep the Shoup tables above.
+    const Tw *tw_fwd_pm = nullptr;
+    const Tw *tw_inv_pm = nullptr;
+    Tw ninv_pm{}, s_ninv_pm{};
+    int arith = 0;      // the transform kernels' AR: 0 = q < 2^62, 1 = wide, 2 = pseudo-Mersenne
 };
 
 struct PassArgs {

@@ -191,6 +191,121 @@ __device__ __forceinline__ void round_inv_sel(u64 (&v)[16], const Tw *__restrict
     else round_inv<R, FOLD>(v, tw, T0, m, ninv, s_ninv);
 }
 
+
+// ---- rounds for pseudo-Mersenne moduli (zq_device.hpp: ct_bfly_pm / gs_bfly_pm) ----------------------------------
+// Bounds are tracked in SIXTEENTHS of q (kPmOne = 16).  A forward stage takes x < B to x' = u + r < B + 33 and
+// y' = u - r + 3q < B + 48, whatever y was; x is reduced first (x -> (x mod 2^k) + (x >> k) delta, below 17) when
+// B + 48 would pass 8q: every other stage.  A pass hands the next one values below kPmPassBound.
+constexpr bool pm_fwd_needs_red(int b) { return b + 3 * kPmOne > kPmCap; }
+constexpr int pm_fwd_bound_out(int R, int bin) {
+    int b = bin;
+    for (int i = 0; i < R; i++) b = (pm_fwd_needs_red(b) ? kPmRed : b) + 3 * kPmOne;
+    return b;
+}
+constexpr int kPmPassBound = 113;   // what 8 stages from canonical inputs (and from 113 again) end with
+
+template <int R, int BIN, bool SGPR_TW>
+__device__ __forceinline__ void round_fwd_pm(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m) {
+    static_assert(BIN >= kPmOne && BIN <= kPmCap, "input bound out of range");
+    static_assert(pm_fwd_bound_out(R, BIN) <= kPmCap, "a stage would overflow");
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int span = 8 >> i;
+        const bool red = pm_fwd_needs_red(pm_fwd_bound_out(i, BIN));
+#ifdef FHE_ABLATE_NO_BUTTERFLIES
+        if (i >= 0) continue;
+#endif
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            const Tw t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l;
+                if (red) v[k] = pm_reduce(v[k], m);
+                ct_bfly_pm<SGPR_TW>(v[k], v[k + span], t.w, t.wp, m);
+            }
+        }
+    }
+}
+
+// Inverse rounds: a Gentleman-Sande butterfly needs x + y < 8q and x - y + K q < 8q with K q >= the bound of y
+// (K = ceil(by / 16)); the sum leaves with bx + by, the product with 33.  The bounds of the 16 registers are followed
+// at compile time (as inv_sched does for the Shoup rounds) and a register is reduced only where a pair would not fit;
+// a round ends by bringing every register below BOUT (after the LDS transpose a register may come from any register).
+struct PmInvSched {
+    unsigned char rx[4][8];   // stage (execution order), butterfly: reduce x first
+    unsigned char ry[4][8];   // reduce y first
+    unsigned char ky[4][8];   // K of d = x - y + K q
+    unsigned char fin[16];    // final reduction of the register
+};
+constexpr bool pm_gs_fits(int bx, int by) { return bx + by <= kPmCap && bx + kPmOne * ((by + kPmOne - 1) / kPmOne) <= kPmCap; }
+constexpr PmInvSched pm_inv_sched(int R, int bin, bool fold, int bout) {
+    PmInvSched s{};
+    int B[16] = {};
+    for (int k = 0; k < 16; k++) B[k] = bin;
+    int st = 0;
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+        int j = 0;
+        for (int g = 0; g < (1 << i); g++)
+            for (int l = 0; l < span; l++, j++) {
+                const int k = g * 2 * span + l, k2 = k + span;
+                int bx = B[k], by = B[k2];
+                bool rx = false, ry = false;
+                if (!pm_gs_fits(bx, by)) {
+                    if (bx >= by) { rx = true; bx = kPmRed; } else { ry = true; by = kPmRed; }
+                }
+                if (!pm_gs_fits(bx, by)) {
+                    if (!rx) { rx = true; bx = kPmRed; } else { ry = true; by = kPmRed; }
+                }
+                s.rx[st][j] = rx;
+                s.ry[st][j] = ry;
+                s.ky[st][j] = (unsigned char)((by + kPmOne - 1) / kPmOne);
+                B[k] = (fold && i == 0) ? kPmMul : bx + by;
+                B[k2] = kPmMul;
+            }
+    }
+    for (int k = 0; k < 16; k++) s.fin[k] = B[k] > bout;
+    return s;
+}
+constexpr int kPmInvBound = 33;   // what an inverse round (and pass) hands on: products are below it as they are
+
+template <int R, bool FOLD, int BIN, bool SGPR_TW>
+__device__ __forceinline__ void round_inv_pm(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
+                                             const Tw ninv, const Tw s_ninv) {
+    constexpr PmInvSched S = pm_inv_sched(R, BIN, FOLD, kPmInvBound);
+    int st = 0;
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            Tw t{};
+            if (!(FOLD && i == 0)) t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l, j = g * span + l;
+                u64 x = v[k], y = v[k + span];
+                if (S.rx[st][j]) x = pm_reduce(x, m);
+                if (S.ry[st][j]) y = pm_reduce(y, m);
+                const u64 kq1 = (u64)S.ky[st][j] * m.q + 1ull;
+                if (FOLD && i == 0) {
+                    const u64 s = x + y, d = x + kq1 + ~y;
+                    x = mul_pm<true>(s, ninv.w, ninv.wp, m);        // kernel arguments: wave-uniform
+                    y = mul_pm<true>(d, s_ninv.w, s_ninv.wp, m);
+                } else {
+                    gs_bfly_pm<SGPR_TW>(x, y, t.w, t.wp, kq1, m);
+                }
+                v[k] = x;
+                v[k + span] = y;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (S.fin[k]) v[k] = pm_reduce(v[k], m);
+}
+
 // ---- round 0 of a transform whose inputs are BITS (gadget digits, base 2) -------------------------
 // The first stages of the transform of a 0/1 polynomial need no multiplication at all: stages 0 and 1
 // act on the four registers {c, c+4, c+8, c+12} of a thread, whose 4 input bits select one of 16
@@ -421,6 +536,71 @@ __device__ __forceinline__ void inv_rounds_contig(u64 (&v)[16], u64 *lds, const 
     }
     // FOLD implies s0 == 0 (this pass holds the m = 1 stage)
     round_inv_sel<C::R0, FOLD, WIDE, (C::NR == 1 ? BF : BN)>(v, TW(C::in_lds(0)), T0(C::in_lds(0), 0, 0), m, ninv, s_ninv);
+}
+
+
+// The same two drivers for pseudo-Mersenne moduli (round_fwd_pm / round_inv_pm): `ltw` / `gtw` then hold {w, w 2^32 mod q}.
+// Round 0 of a forward pass and the last round of an inverse pass have workgroup-uniform twiddles (H = 0): global
+// table, scalar loads, SGPR operands.  The forward driver leaves values below pm_fwd_bound_out over its rounds
+// (<= kPmPassBound from BIN = 16 or kPmPassBound); the inverse driver below kPmInvBound.
+template <int LP, int BIN, bool FRESH>
+__device__ __forceinline__ void fwd_rounds_contig_pm(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
+                                                     u32 w, u32 tf, const Mod &m) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
+    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
+        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    };
+    constexpr int B0 = BIN, B1 = pm_fwd_bound_out(C::R0, B0), B2 = pm_fwd_bound_out(4, B1), B3 = pm_fwd_bound_out(4, B2);
+    round_fwd_pm<C::R0, B0, true>(v, gtw, (1u << s0) + blk, m);
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        constexpr bool L = C::in_lds(1);
+        exchange_contig<LP, C::A0, A, FRESH>(v, lds, w, tf);
+        round_fwd_pm<4, B1, false>(v, TW(L), T0(L, LS, tf >> A), m);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        constexpr bool L = C::in_lds(2);
+        exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
+        round_fwd_pm<4, B2, false>(v, TW(L), T0(L, LS, tf >> A), m);
+    }
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        constexpr bool L = C::in_lds(3);
+        exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
+        round_fwd_pm<4, B3, false>(v, TW(L), T0(L, LS, tf >> A), m);
+    }
+}
+
+template <int LP, bool FOLD, bool FRESH>
+__device__ __forceinline__ void inv_rounds_contig_pm(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
+                                                     u32 w, u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
+    using C = ContigCfg<LP>;
+    auto TW = [&](bool lds_round) -> const Tw * { return lds_round ? ltw : gtw; };
+    auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
+        return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
+    };
+    constexpr int BF = kPmOne, BN = kPmInvBound;   // canonical inputs for the first round that runs
+    if constexpr (C::NR > 3) {
+        constexpr int A = C::a_of(3), LS = C::ls0_of(3);
+        constexpr bool L = C::in_lds(3);
+        round_inv_pm<4, false, BF, false>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::a_of(2), FRESH>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 2) {
+        constexpr int A = C::a_of(2), LS = C::ls0_of(2);
+        constexpr bool L = C::in_lds(2);
+        round_inv_pm<4, false, (C::NR == 3 ? BF : BN), false>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::a_of(1), FRESH && (C::NR <= 3)>(v, lds, w, tf);
+    }
+    if constexpr (C::NR > 1) {
+        constexpr int A = C::a_of(1), LS = C::ls0_of(1);
+        constexpr bool L = C::in_lds(1);
+        round_inv_pm<4, false, (C::NR == 2 ? BF : BN), false>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        exchange_contig<LP, A, C::A0, FRESH && (C::NR <= 2)>(v, lds, w, tf);
+    }
+    round_inv_pm<C::R0, FOLD, (C::NR == 1 ? BF : BN), true>(v, gtw, (1u << s0) + blk, m, ninv, s_ninv);
 }
 
 // ---------------------------------------------------------------------------

@@ -46,6 +46,15 @@ struct Mod {
     u64 r64;    // 2^64 mod q            (for the variable x variable product)
     u64 r64p;   // floor(r64 * 2^64 / q)
     u64 onep;   // floor(2^64 / q)       (Shoup companion of w = 1)
+    // pseudo-Mersenne moduli q = 2^k - delta (pm_k != 0; see "pseudo-Mersenne" below)
+    u64 q3p1;       // 3q + 1
+    u32 pm_c2;      // 2 delta = 2^(k+1) mod q
+    u32 pm_delta;   // delta   = 2^k mod q
+    u32 pm_sh;      // k - 31:  T >> (k+1) = (T >> 32) >> (k - 31)
+    u32 pm_mask;    // 2^(k-31) - 1
+    u32 pm_rsh;     // k - 32:  x >> k = (x >> 32) >> (k - 32)
+    u32 pm_rmask;   // 2^(k-32) - 1
+    u32 pm_k;       // k, or 0 when q is not of this form
 };
 
 // ---- single-instruction wrappers (register allocation stays with the compiler) ----
@@ -144,6 +153,131 @@ __device__ __forceinline__ u64 canon2(u64 x, const Mod &m) { return csub_neg(x, 
 __device__ __forceinline__ u64 canon4(u64 x, const Mod &m) { return canon2(csub_neg(x, m.neg2q), m); }
 // [0,8q) -> [0,q)   (q < 2^61)
 __device__ __forceinline__ u64 canon8(u64 x, const Mod &m) { return canon4(csub_neg(x, m.neg4q), m); }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pseudo-Mersenne moduli: q = 2^k - delta with 56 <= k <= 61 and delta <= 2^(k-39) — the headline modulus
+// 2^61 - 2^21 + 1 is one.  Zq::mul (arith/src/zq.rs:315-328) by a KNOWN w then needs FIVE 32x32 multiplies instead of
+// the ten of the Shoup form above, and no quotient at all:
+//   y = y1 2^32 + y0,   y w  =  y0 w + y1 W2  (mod q),   W2 = w 2^32 mod q   (the table holds {w, W2} instead of {w, w'})
+//   T = y0 w + y1 W2 < 2^33 q              four multiplies: two v_mad_u64_u32 chains, one carry between them
+//   2^(k+1) = 2 delta (mod q):  r = (T mod 2^(k+1)) + (T >> (k+1)) * 2 delta       one more; T >> (k+1) < 2^32
+// r = y w (mod q) and r < 2^(k+1) + 2^33 delta <= 2q + q/16 for ANY 64-bit y.  Values are brought down, when their
+// bound asks for it, by x -> (x mod 2^k) + (x >> k) delta < q + q/16 (three instructions, against four for a
+// conditional subtraction that only halves).  Measured in registers (tools/ubench_bfly.hip v17 against v8,
+// profiles/r03_ubench_bfly.txt): 59.9 against 87.6 cycles per butterfly-wave.
+//
+// The 14 instructions of a butterfly are ONE asm statement: between two dependent asm statements the compiler inserts an
+// s_nop (it must assume a dst-forwarding hazard inside any inline asm), five per butterfly when each instruction is its
+// own statement.  Sub-registers of a 64-bit asm operand cannot be named, so the temporaries are the physical registers
+// v[2:7], listed as clobbers (the compiler keeps nothing there across a butterfly; inputs and outputs are its own).
+// SGPR_TW: the twiddle words are wave-uniform (scalar loads): "s" operands, no copies into VGPRs.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPmMul = 33;    // bounds in SIXTEENTHS of q: a product r < 2q + q/16
+constexpr int kPmRed = 17;    // pm_reduce(x) < q + q/16
+constexpr int kPmOne = 16;    // canonical
+constexpr int kPmCap = 128;   // 8q <= 2^64: every value stays below
+
+// x -> (x mod 2^k) + (x >> k) delta  =  x (mod q),  < 2^k + 2^(64-k) delta.  Plain C on purpose (the compiler emits
+// v_lshrrev / v_and / v_mad_u64_u32): a non-asm producer in front of a butterfly's asm statement needs no s_nop.
+__device__ __forceinline__ u64 pm_reduce(u64 x, const Mod &m) {
+    const u32 x1 = (u32)(x >> 32);
+    const u64 lo = ((u64)(x1 & m.pm_rmask) << 32) | (u32)x;
+    return (u64)(x1 >> m.pm_rsh) * (u64)m.pm_delta + lo;
+}
+// any value below 2^64 -> canonical
+__device__ __forceinline__ u64 pm_canon(u64 x, const Mod &m) { return csub_neg(pm_reduce(x, m), m.nq); }
+
+#define FHE_PM_PRODUCT(Y0, Y1, OUT)                                                                    \
+    "v_mad_u64_u32 v[2:3], vcc, " Y0 ", %[a0], 0\n\t"                                                  \
+    "v_mad_u64_u32 v[2:3], vcc, " Y1 ", %[b0], v[2:3]\n\t"      /* carry -> vcc */                    \
+    "v_mov_b32 v6, v3\n\t"                                                                             \
+    "v_addc_co_u32 v7, vcc, 0, 0, vcc\n\t"                       /* {T >> 32 so far} = {n1, carry} */  \
+    "v_mad_u64_u32 v[6:7], vcc, " Y0 ", %[a1], v[6:7]\n\t"                                             \
+    "v_mad_u64_u32 v[6:7], vcc, " Y1 ", %[b1], v[6:7]\n\t"      /* T >> 32 */                          \
+    "v_and_b32 v3, %[mask], v6\n\t"                              /* T mod 2^(k+1) = {n0, b0 & mask} */ \
+    "v_alignbit_b32 v6, v7, v6, %[sh]\n\t"                       /* T >> (k+1) */                      \
+    "v_mad_u64_u32 " OUT ", vcc, v6, %[c2], v[2:3]\n\t"
+
+// y * w mod q, lazily: < 2q + q/16, for any 64-bit y
+template <bool SGPR_TW>
+__device__ __forceinline__ u64 mul_pm(u64 y, u64 w, u64 w2, const Mod &m) {
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+    const u32 a0 = (u32)w, a1 = (u32)(w >> 32), b0 = (u32)w2, b1 = (u32)(w2 >> 32);
+    u64 r;
+    if constexpr (SGPR_TW)
+        asm(FHE_PM_PRODUCT("%[y0]", "%[y1]", "%[r]")
+            : [r] "=&v"(r)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1),
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh)
+            : "vcc", "v2", "v3", "v6", "v7");
+    else
+        asm(FHE_PM_PRODUCT("%[y0]", "%[y1]", "%[r]")
+            : [r] "=&v"(r)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh)
+            : "vcc", "v2", "v3", "v6", "v7");
+    return r;
+}
+
+// Forward butterfly (ntt.rs:57-62): x' = u + r, y' = u - r + 3q  (r = y w < 2q + q/16), u = x < B q  ->  both below
+// (B + 3) q; the caller reduces x first when B + 3 would pass 8.
+template <bool SGPR_TW>
+__device__ __forceinline__ void ct_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, const Mod &m) {
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+    const u32 a0 = (u32)w, a1 = (u32)(w >> 32), b0 = (u32)w2, b1 = (u32)(w2 >> 32);
+    u64 yo;
+#define FHE_PM_CT_BODY                                                                                 \
+    "v_lshl_add_u64 %[yo], %[x], 0, %[k3]\n\t"                   /* u + 3q + 1 */                      \
+    FHE_PM_PRODUCT("%[y0]", "%[y1]", "v[2:3]")                                                         \
+    "v_lshl_add_u64 %[x], %[x], 0, v[2:3]\n\t"                   /* x' = u + r */                      \
+    "v_not_b32 v2, v2\n\t"                                                                             \
+    "v_not_b32 v3, v3\n\t"                                                                             \
+    "v_lshl_add_u64 %[yo], %[yo], 0, v[2:3]"                     /* y' = u + 3q + 1 + ~r */
+    if constexpr (SGPR_TW)
+        asm(FHE_PM_CT_BODY
+            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1),
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [k3] "s"(m.q3p1)
+            : "vcc", "v2", "v3", "v6", "v7");
+    else
+        asm(FHE_PM_CT_BODY
+            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [k3] "s"(m.q3p1)
+            : "vcc", "v2", "v3", "v6", "v7");
+#undef FHE_PM_CT_BODY
+    y = yo;
+}
+
+// Inverse butterfly (ntt.rs:91-96): x' = x + y, y' = (x - y + K q) w.  kq1 = K q + 1 with K q >= the bound of y.
+template <bool SGPR_TW>
+__device__ __forceinline__ void gs_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, u64 kq1, const Mod &m) {
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+    const u32 a0 = (u32)w, a1 = (u32)(w >> 32), b0 = (u32)w2, b1 = (u32)(w2 >> 32);
+    u64 yo;
+#define FHE_PM_GS_BODY                                                                                 \
+    "v_not_b32 v2, %[y0]\n\t"                                                                          \
+    "v_not_b32 v3, %[y1]\n\t"                                                                          \
+    "v_lshl_add_u64 v[4:5], %[x], 0, %[kq1]\n\t"                                                       \
+    "v_lshl_add_u64 v[4:5], v[4:5], 0, v[2:3]\n\t"               /* d = x - y + K q */                 \
+    "v_lshl_add_u64 %[x], %[x], 0, %[y]\n\t"                     /* x' = x + y */                      \
+    FHE_PM_PRODUCT("v4", "v5", "%[yo]")
+    if constexpr (SGPR_TW)
+        asm(FHE_PM_GS_BODY
+            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [y] "v"(y), [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1),
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [kq1] "s"(kq1)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
+    else
+        asm(FHE_PM_GS_BODY
+            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [y] "v"(y), [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [kq1] "s"(kq1)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
+#undef FHE_PM_GS_BODY
+    y = yo;
+}
 
 // Rust `f64 as i64` (saturating, NaN -> 0)
 __device__ __forceinline__ long long f64_as_i64(double x) {

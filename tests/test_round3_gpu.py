@@ -1,0 +1,219 @@
+"""Round 3: the five-multiply butterflies for pseudo-Mersenne moduli (csrc/zq_device.hpp, `AR == 2` kernels).
+
+q = 2^k - delta with 56 <= k <= 61 and delta <= 2^(k-39) — SURVEY.md section 8's modulus 2^61 - 2^21 + 1 is one — runs
+`NTT::ntt` / `intt` / `Rq x Rq` (arith/src/ntt.rs:44-110, ring_nq.rs:586-607) on a second pair of tables
+{w, w 2^32 mod q}.  The CPU part restates that arithmetic in Python integers and checks the identities and the value
+bounds the kernels rely on; the GPU part is word-for-word parity with the oracle at every such modulus shape, and
+identity with the Shoup kernels (FHE_PM=0) on the same inputs.
+"""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import Q61, ROOT
+
+# NTT-friendly primes (q = 1 mod 2^17) of the pseudo-Mersenne form, and two that are NOT eligible
+PM_PRIMES = [
+    (2305843009211596801, 61),   # 2^61 - 2^21 + 1      (delta = 2^21 - 1)
+    (2305843009210023937, 61),   # 2^61 - 28 * 2^17 + 1 (delta just under 2^22, the limit for k = 61)
+    (1152921504606584833, 60),   # 2^60 - 2^18 + 1
+    (144115188075593729, 57),    # 2^57 - 2^18 + 1      (delta = 2^18 - 1 <= 2^(57-39))
+]
+NOT_PM = [
+    2305843009208713217,         # 2^61 - 38 * 2^17 + 1: delta > 2^22
+    576460752300015617,          # 2^59 - 26 * 2^17 + 1: delta > 2^20
+]
+
+
+def test_eligibility_rule_matches_the_library_statement():
+    from fhe_study_amd.arith import pm_params
+
+    for q, k in PM_PRIMES:
+        p = pm_params(q)
+        assert p is not None and p["k"] == k and p["delta"] == (1 << k) - q
+        assert p["delta"] <= 1 << (k - 39)
+    for q in NOT_PM + [65537, 12289, 4611686018425815041, 0x1fffffffff000001]:
+        assert pm_params(q) is None
+
+
+def _mul_pm(y, w, w2, p):
+    """the nine instructions of FHE_PM_PRODUCT (zq_device.hpp) in Python integers, word for word"""
+    M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+    y0, y1 = y & M32, y >> 32
+    a0, a1, b0, b1 = w & M32, w >> 32, w2 & M32, w2 >> 32
+    N = y0 * a0
+    N = N + y1 * b0
+    carry, N = N >> 64, N & M64                       # v_mad_u64_u32 ... carry -> vcc
+    B = (N >> 32) | (carry << 32)                     # v_mov / v_addc: {n1, carry}
+    B = B + y0 * a1
+    B = B + y1 * b1
+    assert B <= M64                                   # T >> 32 fits 64 bits
+    lo = (N & M32) | ((B & M32 & p["mask"]) << 32)    # T mod 2^(k+1)
+    th = (B >> p["sh"])
+    assert th <= M32                                  # T >> (k+1) fits 32 bits (v_alignbit takes the low word)
+    r = th * p["c2"] + lo
+    assert r <= M64
+    return r
+
+
+def test_five_multiply_product_identity_and_bounds():
+    """r = y w (mod q) and r < 2q + q/16 for ANY 64-bit y; the reduction lands below q + q/16; a butterfly's outputs
+    stay below 2^64 under the schedule of ntt_rounds.hpp (bounds in sixteenths of q)."""
+    from fhe_study_amd.arith import pm_params
+
+    rnd = random.Random(0xF4E5_0300)
+    for q, k in PM_PRIMES:
+        p = pm_params(q)
+        ys = [0, 1, (1 << 64) - 1, (1 << 63), q - 1, q, 8 * q - 1 if 8 * q - 1 < (1 << 64) else (1 << 64) - 1,
+              (1 << 32) - 1, 1 << 32, ((1 << 32) - 1) << 32]
+        ws = [0, 1, q - 1, q // 2, (1 << 32) - 1, 1 << 32]
+        for _ in range(300):
+            ys.append(rnd.getrandbits(64))
+            ws.append(rnd.randrange(q))
+        for y in ys:
+            for w in ws[:6] + rnd.sample(ws[6:], 12):
+                w2 = (w << 32) % q
+                r = _mul_pm(y, w, w2, p)
+                assert r % q == (y * w) % q
+                assert 16 * r < 33 * q                 # kPmMul
+            # pm_reduce
+            x1 = y >> 32
+            red = (x1 >> p["rsh"]) * p["delta"] + (((x1 & p["rmask"]) << 32) | (y & 0xFFFFFFFF))
+            assert red % q == y % q and 16 * red < 17 * q      # kPmRed
+        # forward stage: x < 5q (80 sixteenths) needs no reduction: x' = u + r, y' = u - r + 3q stay below 2^64
+        assert 5 * q + (33 * q) // 16 + 1 < 1 << 64 and 5 * q + 3 * q <= 1 << 64
+        # inverse stage: d = x - y + K q with K q >= bound of y: the largest pair the schedule admits
+        assert 8 * q <= 1 << 64
+
+
+def test_round_schedules_never_pass_the_cap():
+    """the compile-time schedules of ntt_rounds.hpp restated: forward bounds per stage, inverse per register"""
+    CAP, MUL, RED, ONE = 128, 33, 17, 16
+
+    def fwd_out(R, b):
+        for _ in range(R):
+            b = (RED if b + 3 * ONE > CAP else b) + 3 * ONE
+            assert b <= CAP
+        return b
+
+    assert fwd_out(8, ONE) == 113 and fwd_out(8, 113) == 113        # kPmPassBound, for every split of 8 stages into rounds
+    for r0 in (2, 3, 4):
+        assert fwd_out(4, fwd_out(r0, ONE)) <= 113                   # strided passes of 6 / 7 / 8 stages
+    for lp in range(4, 14):                                          # contiguous passes from either input bound
+        assert fwd_out(lp, 113) <= 113 and fwd_out(lp, ONE) <= 113
+
+    def fits(bx, by):
+        return bx + by <= CAP and bx + ONE * ((by + ONE - 1) // ONE) <= CAP
+
+    def inv_round(R, bin_, fold):
+        B = [bin_] * 16
+        for i in range(R - 1, -1, -1):
+            span = 8 >> i
+            for g in range(1 << i):
+                for l in range(span):
+                    k = g * 2 * span + l
+                    k2 = k + span
+                    bx, by = B[k], B[k2]
+                    rx = ry = False
+                    if not fits(bx, by):
+                        if bx >= by:
+                            rx, bx = True, RED
+                        else:
+                            ry, by = True, RED
+                    if not fits(bx, by):
+                        if not rx:
+                            bx = RED
+                        else:
+                            by = RED
+                    assert fits(bx, by)
+                    B[k] = MUL if (fold and i == 0) else bx + by
+                    B[k2] = MUL
+        return [min(b, MUL) if b > 33 else b for b in B]              # the final reductions bring every register below 33
+
+    for R in (1, 2, 3, 4):
+        for bin_ in (ONE, 33):
+            for fold in (False, True):
+                assert max(inv_round(R, bin_, fold)) <= 33
+
+
+# ---- GPU --------------------------------------------------------------------------------------------------------------
+
+
+@pytest.fixture()
+def need_gpu(pkg):
+    assert pkg.binding.device_count() >= 1, "no HIP device: -m gpu tests need a real MI355X"
+
+
+def _extreme_rows(oracle, q, n, seed):
+    rows = [np.zeros(n, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64)]
+    alt = np.zeros(n, dtype=np.uint64); alt[::2] = q - 1; rows.append(alt)
+    e = np.zeros(n, dtype=np.uint64); e[n - 1] = q - 1; rows.append(e)
+    rows.append(oracle.fill_synthetic(q, seed, 0, n))
+    rows.append(oracle.fill_synthetic(q, seed + 1, 0, n))
+    return np.stack(rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [p[0] for p in PM_PRIMES] + NOT_PM)
+def test_pseudo_mersenne_moduli_every_kernel_shape(pkg, oracle, need_gpu, q):
+    """tiny (n < 16: Shoup tables), every single-pass round structure (R0 = 1..4, 1..4 rounds), the two-pass sizes
+    with 6, 7 and 8 strided stages and a contiguous pass longer than 8 stages; forward, inverse, product with every
+    evals combination, on inputs that maximise the lazy representation"""
+    for n in (4, 16, 32, 128, 512, 2048, 8192, 1 << 14, 1 << 15, 1 << 16):
+        if (q - 1) % (2 * n):
+            continue
+        a = _extreme_rows(oracle, q, n, 3000 + n)
+        b = a[::-1].copy()
+        plan = pkg.Plan(q, n)
+        A = plan.forward(a)
+        assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.inverse(A).reshape(-1), a.reshape(-1)), (q, n)
+        want = oracle.rq_mul(q, n, a, b)
+        ae, be = want[2], want[3]
+        for got in (plan.rq_mul(a, b), plan.rq_mul(ae, b, a_is_evals=True), plan.rq_mul(a, be, b_is_evals=True),
+                    plan.rq_mul(ae, be, a_is_evals=True, b_is_evals=True)):
+            assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, want)), (q, n)
+
+
+@pytest.mark.gpu
+def test_largest_size_on_the_pseudo_mersenne_tables(pkg, oracle, need_gpu):
+    q, n = Q61, 1 << 18            # 8 strided + 10 contiguous stages
+    a = _extreme_rows(oracle, q, n, 77)[1:5]
+    plan = pkg.Plan(q, n)
+    A = plan.forward(a)
+    assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1))
+    assert np.array_equal(plan.inverse(A).reshape(-1), a.reshape(-1))
+
+
+@pytest.mark.gpu
+def test_shoup_and_pseudo_mersenne_kernels_give_the_same_words(pkg, oracle, need_gpu):
+    """FHE_PM=0 keeps the modulus on the ten-multiply Shoup kernels: same words as the default build, and as the
+    oracle, for the transform, its inverse and the product — at the bench's shape too (N = 2^16)."""
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "import fhe_study_amd as pkg\n"
+        "from oracle import load_oracle\n"
+        "O = load_oracle()\n"
+        "q = pkg.Q61\n"
+        "for n, batch in ((64, 9), (4096, 5), (16384, 3), (65536, 18)):\n"
+        "    a = O.fill_synthetic(q, 9, 0, batch * n); b = O.fill_synthetic(q, 10, 0, batch * n)\n"
+        "    P = pkg.Plan(q, n)\n"
+        "    A = P.forward(a); I = P.inverse(b); c, ce, ae, be = P.rq_mul(a, b)\n"
+        "    if n < 65536 or True:\n"
+        "        assert np.array_equal(A, O.ntt(q, n, a)) and np.array_equal(I, O.intt(q, n, b))\n"
+        "    h = hashlib.sha256()\n"
+        "    for x in (A, I, c, ce, ae, be): h.update(np.ascontiguousarray(x).tobytes())\n"
+        "    print('digest', n, h.hexdigest())\n" % ROOT)
+    outs = {}
+    for pm in ("0", "1"):
+        env = dict(os.environ, FHE_PM=pm)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, pm + r.stdout + r.stderr
+        outs[pm] = [l for l in r.stdout.splitlines() if l.startswith("digest")]
+        assert len(outs[pm]) == 4
+    assert outs["0"] == outs["1"]

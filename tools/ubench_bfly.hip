@@ -255,6 +255,131 @@ __device__ __forceinline__ void bf_v12(u64& x, u64& y, const T12& t, const Q& c)
   x = s;
 }
 
+
+// ---- round 3: FIVE-multiply butterflies ------------------------------------------------------------------------------
+// Split multiplicand WITHOUT a quotient.  y = y1*2^32 + y0, y*w = y0*w + y1*W2 (mod q) with W2 = w*2^32 mod q kept in the
+// table instead of the Shoup companion: T = y0*w + y1*W2 < 2^33 q is four 32x32 products.  What reduces T:
+//   v15 (pseudo-Mersenne q = 2^k - delta, the headline modulus 2^61 - 2^21 + 1): 2^(k+1) = 2 delta (mod q), so
+//       r = (T mod 2^(k+1)) + (T >> (k+1)) * 2 delta  — ONE more multiply (T >> (k+1) < 2^32), r < 2q + q/64;
+//   v14 (q = qh*2^32 + 1, the verdict's Montgomery case; table holds w*2^32, w*2^64 mod q): one word round with
+//       m = T0 and q^-1 = 1 (mod 2^32): r = (T >> 32) - T0*qh + q  — one more multiply, r in (0, 3q);
+//   v16 (any odd q < 2^62, word Montgomery): m = T0 * (-q^-1 mod 2^32), r = (T + m q) >> 32 — three more, r < 3q.
+// All three: x' = u + r, y' = u - r + 3q, so a stage takes x < B q to < (B + 3) q and (q < 2^61) x is brought down before
+// every other stage: v15 by k = x >> 61, x = (x mod 2^61) + k delta (three instructions, < q + 8 delta), v14 / v16 by
+// a conditional subtraction of 4q then 2q... (here: csub 4q every stage for v14 / v16, the cheaper schedule measured).
+__device__ __forceinline__ u64 mad64co(u32 a, u32 b, u64 c, u64& carry) {   // carry-out kept (SGPR pair)
+  u64 d; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ u32 carry01(u64 carry) {   // 0 / 1 per lane
+  u32 d; asm("v_addc_co_u32 %0, vcc, 0, 0, %1" : "=v"(d) : "s"(carry) : "vcc"); return d;
+}
+__device__ __forceinline__ u32 carry_add(u32 a, u64 carry) {   // a + carry
+  u32 d; asm("v_addc_co_u32 %0, vcc, 0, %1, %2" : "=v"(d) : "v"(a), "s"(carry) : "vcc"); return d;
+}
+__device__ __forceinline__ u32 sub32(u32 a, u32 b) { u32 d; asm("v_sub_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+struct TS { u32 a0, a1, b0, b1; };      // the two table words: a multiplies y0, b multiplies y1
+struct QS { u64 q, q3p1, neg4q; u32 c2, delta, sh, mask, qinv, nqh, q0, q1; };
+
+// T = y0*a + y1*b as (T mod 2^32, T >> 32): four multiplies, one carry
+__device__ __forceinline__ void split_T(u64 y, const TS& t, u32& T0, u64& B) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+  u64 carry;
+  u64 N = mad64z(y0, t.a0);
+  N = mad64co(y1, t.b0, N, carry);
+  B = mad64(y0, t.a1, pack((u32)(N >> 32), carry01(carry)));
+  B = mad64(y1, t.b1, B);
+  T0 = (u32)N;
+}
+__device__ __forceinline__ u64 pm_reduce(u64 x, const QS& c) {   // q = 2^61 - delta: x -> (x mod 2^61) + (x >> 61) delta
+  const u32 x1 = (u32)(x >> 32);
+  return mad64(x1 >> 29, c.delta, pack((u32)x, x1 & 0x1fffffffu));
+}
+__device__ __forceinline__ void bf_v15(u64& x, u64& y, const TS& t, const QS& c, bool red) {
+  const u64 u = red ? pm_reduce(x, c) : x;
+  u32 T0; u64 B;
+  split_T(y, t, T0, B);
+  const u32 th = __builtin_amdgcn_alignbit((u32)(B >> 32), (u32)B, 30);       // T >> 62
+  const u64 r = mad64(th, c.c2, pack(T0, (u32)B & 0x3fffffffu));               // (T mod 2^62) + th * 2 delta
+  x = add64(u, r);
+  y = add64(add64(u, c.q3p1), ~r);
+}
+__device__ __forceinline__ void bf_v14(u64& x, u64& y, const TS& t, const QS& c, bool) {
+  const u64 u = csub32(x, c.neg4q);
+  u32 T0; u64 B;
+  split_T(y, t, T0, B);
+  u64 R = mad64(T0, c.nqh, B);                                                 // B + T0*(2^32 - qh)
+  R = pack((u32)R, sub32((u32)(R >> 32), T0));                                 // B - T0*qh   in (-2^61, 2^62)
+  const u64 rr = add64(R, c.q);                                                // (0, 3q)
+  x = add64(u, rr);
+  y = add64(add64(u, c.q3p1), ~rr);
+}
+__device__ __forceinline__ void bf_v16(u64& x, u64& y, const TS& t, const QS& c, bool) {
+  const u64 u = csub32(x, c.neg4q);
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+  u64 c1, c2;
+  u64 N = mad64z(y0, t.a0);
+  N = mad64co(y1, t.b0, N, c1);
+  u32 m; asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"((u32)N), "v"(c.qinv));
+  N = mad64co(m, c.q0, N, c2);                                                 // low word becomes 0
+  u64 B = mad64(y0, t.a1, pack((u32)(N >> 32), carry_add(carry01(c1), c2)));
+  B = mad64(y1, t.b1, B);
+  B = mad64(m, c.q1, B);                                                       // (T + m q) >> 32  in [0, 3q)
+  x = add64(u, B);
+  y = add64(add64(u, c.q3p1), ~B);
+}
+
+// v17: v15 as ONE asm statement.  Between two dependent asm STATEMENTS the compiler inserts an s_nop (it must assume a
+// dst-forwarding hazard in any inline asm): v15 above carries 5 per butterfly.  Sub-registers of a 64-bit asm operand
+// cannot be named, so the temporaries (N = v[60:61], B = v[62:63]) are physical registers listed as clobbers.
+__device__ __forceinline__ void bf_v17(u64& x, u64& y, const TS& t, const QS& c, bool red) {
+  const u64 u = red ? pm_reduce(x, c) : x;
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+  u64 xo, yo;
+  asm("v_mad_u64_u32 v[60:61], vcc, %[y0], %[a0], 0\n\t"
+        "v_mad_u64_u32 v[60:61], vcc, %[y1], %[b0], v[60:61]\n\t"     // carry -> vcc
+        "v_mov_b32 v62, v61\n\t"
+        "v_addc_co_u32 v63, vcc, 0, 0, vcc\n\t"                        // {n1, carry}
+        "v_mad_u64_u32 v[62:63], vcc, %[y0], %[a1], v[62:63]\n\t"
+        "v_mad_u64_u32 v[62:63], vcc, %[y1], %[b1], v[62:63]\n\t"     // B = T >> 32
+        "v_and_b32 v61, 0x3fffffff, v62\n\t"                           // T mod 2^62 = {n0, b0 & mask}
+        "v_alignbit_b32 v62, v63, v62, 30\n\t"                         // T >> 62
+        "v_mad_u64_u32 v[60:61], vcc, v62, %[c2], v[60:61]\n\t"       // r
+        "v_lshl_add_u64 %[x], %[u], 0, v[60:61]\n\t"
+        "v_not_b32 v60, v60\n\t"
+        "v_not_b32 v61, v61\n\t"
+        "v_lshl_add_u64 %[yo], %[u], 0, %[k3]\n\t"
+        "v_lshl_add_u64 %[yo], %[yo], 0, v[60:61]"
+        : [x] "=&v"(xo), [yo] "=&v"(yo)
+        : [u] "v"(u), [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(t.a0), [a1] "v"(t.a1), [b0] "v"(t.b0), [b1] "v"(t.b1),
+          [c2] "s"(c.c2), [k3] "s"(c.q3p1)
+        : "vcc", "v60", "v61", "v62", "v63");
+  x = xo; y = yo;
+}
+template <int V>
+__global__ void ks(u64* p, QS c, TS t, int iters) {
+  u64 x[4], y[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { x[j] = p[threadIdx.x + 64 * j] % c.q; y[j] = p[threadIdx.x + 64 * j + 256] % c.q; }
+  for (int i = 0; i < iters; i += 2) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (V == 14) bf_v14(x[j], y[j], t, c, false);
+      if (V == 15) bf_v15(x[j], y[j], t, c, false);
+      if (V == 16) bf_v16(x[j], y[j], t, c, false);
+      if (V == 17) bf_v17(x[j], y[j], t, c, false);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (V == 14) bf_v14(x[j], y[j], t, c, true);
+      if (V == 15) bf_v15(x[j], y[j], t, c, true);
+      if (V == 16) bf_v16(x[j], y[j], t, c, true);
+      if (V == 17) bf_v17(x[j], y[j], t, c, true);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { p[threadIdx.x + 64 * j] = x[j]; p[threadIdx.x + 64 * j + 256] = y[j]; }
+}
+
 template <int V>
 __global__ void k(u64* p, Q c, u64 w, u64 wp, int iters) {
   u64 x[4], y[4];
@@ -415,6 +540,46 @@ int main() {
       for (int r = 0; r < 4; r++) {
         hipEventRecord(e0);
         k12<<<blocks, threads>>>(p, c, t, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
+      }
+      double bf = (double)blocks * threads * 4 * iters;
+      printf("   wpS=%d %8.3f ms  %8.1f Gbfly/s  %6.1f cyc/bfly-wave/SIMD(nominal clk)\n", wpS, best, bf / best * 1e-6,
+             best * 1e-3 * clk / ((double)iters * 4 * wpS));
+    }
+  }
+
+  for (int v : {14, 15, 16, 17}) {   // round 3: five-multiply (v14, v15) and seven-multiply (v16) butterflies
+    const u64 qq = v == 14 ? 0x1ffffff900000001ull : q;           // v14 needs q = 1 (mod 2^32)
+    const u64 ww = w % qq;
+    u64 a, b;
+    if (v == 15 || v == 17) { a = ww; b = (u64)((((u128)ww) << 32) % qq); }
+    else { a = (u64)((((u128)ww) << 32) % qq); b = (u64)((((u128)a) << 32) % qq); }
+    TS t{(u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32)};
+    u32 qi = 1; for (int i = 0; i < 5; i++) qi *= 2u - (u32)qq * qi;             // q^-1 mod 2^32
+    const u64 delta = (1ull << 61) - qq;
+    QS cs{qq, 3 * qq + 1, (u64)0 - 4 * qq, (u32)(2 * delta), (u32)delta, 30u, 0x3fffffffu, 0u - qi,
+          (u32)(0u - (u32)(qq >> 32)), (u32)qq, (u32)(qq >> 32)};
+    hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
+    int it = 6;
+    if (v == 14) ks<14><<<1, 64>>>(p, cs, t, it); else if (v == 15) ks<15><<<1, 64>>>(p, cs, t, it); else if (v == 16) ks<16><<<1, 64>>>(p, cs, t, it); else ks<17><<<1, 64>>>(p, cs, t, it);
+    hipMemcpy(o.data(), p, 512 * 8, hipMemcpyDeviceToHost);
+    int bad = 0; u64 mx = 0;
+    for (int tt = 0; tt < 64; tt++) for (int j = 0; j < 4; j++) {
+      u64 yo, xo = href(h[tt + 64 * j] % qq, h[tt + 64 * j + 256] % qq, ww, qq, it, &yo);
+      u64 gx = o[tt + 64 * j], gy = o[tt + 64 * j + 256];
+      if (gx % qq != xo || gy % qq != yo) bad++;
+      if (gx > mx) mx = gx; if (gy > mx) mx = gy;
+    }
+    const char* nm = v == 14 ? "v14 split+Montgomery q=1 mod 2^32 (5 mul)" : v == 15 ? "v15 split+pseudo-Mersenne q61 (5 mul)" : v == 16 ? "v16 split+word Montgomery any q (7 mul)" : "v17 v15 in one asm statement";
+    printf("%-20s correctness: %s (max value / q = %.3f)\n", nm, bad ? "FAIL" : "ok", (double)mx / (double)qq);
+    for (int wpS : {2, 4, 8}) {
+      int blocks = cus * wpS, threads = 256, iters = 2000;
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      float best = 1e30f;
+      for (int r = 0; r < 4; r++) {
+        hipEventRecord(e0);
+        if (v == 14) ks<14><<<blocks, threads>>>(p, cs, t, iters); else if (v == 15) ks<15><<<blocks, threads>>>(p, cs, t, iters); else if (v == 16) ks<16><<<blocks, threads>>>(p, cs, t, iters); else ks<17><<<blocks, threads>>>(p, cs, t, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
       }

@@ -6,11 +6,15 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`
   (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).
 
-Default workload = BASELINE.json configs[4] on one GPU (`--config 5`): forward negacyclic NTT,
-N = 65536, q = 2^61-2^21+1, 65536 polynomials per GPU (32 GiB in + 32 GiB out of the 288 GB HBM),
-synthetic coefficients generated on the device, device-resident in -> out.
-A "step" is one pass of the hot path over one batch.  The batch is block-partitioned over ranks;
-there is no data-path collective, so per-GPU work is fixed as N grows: "weak".
+Default workload = BASELINE.json configs[4] (`--config 5`): forward negacyclic NTT, N = 65536,
+q = 2^61-2^21+1, a GLOBAL batch of 65536 polynomials (32 GiB in + 32 GiB out), synthetic coefficients
+generated on the device, device-resident in -> out.  A "step" is one pass of the
+hot path over the batch.  With N ranks the 65536 polynomials are block-partitioned by fhe_shard_range
+(8192 per GPU, 4 GiB, at N = 8 — what configs[4] and SURVEY.md §8d state): total work is fixed as N
+grows, "scaling": "strong"; at N = 1 that is the whole batch on one GPU.  `--batch-per-gpu B` selects
+the weak variant instead (B polynomials on every rank; `config.workload` says which).  There is no
+data-path collective; `--allgather` times the one optional collective — every rank's
+REAL shard gathered onto every rank through sharding.all_gather_rows — on its own, never in `value`.
 
 `--config {2,3,4}` measure the other BASELINE.json configurations with the same JSON shape
 (their own metric names; the contract line is the default):
@@ -42,12 +46,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Chip-wide ceiling of the 64-bit Shoup/Harvey butterfly in registers, no memory at all:
 # tools/ubench_bfly.hip v8 (the production form) at 8 waves per SIMD, profiles/r01_ubench_bfly.txt.
 VALU_PEAK_GBFLY = 2018.7
+# the five-multiply butterfly of pseudo-Mersenne moduli (zq_device.hpp: ct_bfly_pm), which the headline modulus runs:
+# tools/ubench_bfly.hip v17 at 8 waves per SIMD, profiles/r03_ubench_bfly.txt
+VALU_PEAK_GBFLY_PM = 2627.1
 # the 32-bit butterfly of the small-prime kernels (digit32.hip / bfv32.hip): tools/ubench_bfly.hip v13, registers only
 VALU_PEAK_GBFLY32 = 5730.0
 # HBM traffic per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
 # WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Counters cannot be read from inside this process.
-PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def parse():
@@ -58,9 +65,11 @@ def parse():
     ap.add_argument("--config", type=int, default=5, choices=[2, 3, 4, 5],
                     help="BASELINE.json configuration (1-based; 5 = the headline, the contract line)")
     ap.add_argument("--log-n", type=int, default=None)
-    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="weak scaling: this many units on EVERY rank (config 5 default is the strong form below)")
     ap.add_argument("--global-batch", type=int, default=None,
-                    help="config 4 only: shard exactly this many products over the ranks (strong scaling; 630 = configs[3])")
+                    help="configs 4 and 5: shard exactly this many units over the ranks with fhe_shard_range (strong "
+                         "scaling).  Config 5 defaults to 65536 = configs[4]; config 4: 630 = configs[3]")
     ap.add_argument("--q", type=int, default=None)
     ap.add_argument("--batch-tile", type=int, default=0, help="polynomials per launch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,7 +85,13 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--allgather", action="store_true",
-                    help="also time an RCCL all-gather of a result slab (reported separately)")
+                    help="config 5: also time the all-gather of every rank's result shard onto every rank "
+                         "(sharding.all_gather_rows; RCCL with --backend nccl), reported separately, never in `value`")
+    ap.add_argument("--allgather-chunk-rows", type=int, default=0,
+                    help="gather in chunks of this many rows per rank (0 = ONE collective)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even at WORLD_SIZE 1 (needs the launcher's env): the whole N > 1 "
+                         "code path — process group, barrier, MAX all-reduce, all-gather — through RCCL on one GPU")
     return ap.parse_args()
 
 
@@ -119,16 +134,25 @@ def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
     if inverse_too:   # config 2
         q, log_n, batch = args.q or Q61, args.log_n or 12, args.batch_per_gpu or 4096
         seed = 0xF4E50002
+        total, b0 = world * batch, rank * batch
+        strong = False
     else:             # config 5
-        q, log_n, batch = args.q or Q61, args.log_n or 16, args.batch_per_gpu or 65536
+        q, log_n = args.q or Q61, args.log_n or 16
         seed = 0xF4E50005
+        if args.batch_per_gpu and not args.global_batch:     # weak variant: the same batch on every rank
+            batch, strong = args.batch_per_gpu, False
+            total, b0 = world * batch, rank * batch
+        else:                                                # configs[4]: ONE global batch, block-partitioned
+            total, strong = args.global_batch or 65536, True
+            b0, b1 = B.shard_range(total, world, rank)
+            batch = b1 - b0
     n = 1 << log_n
     plan = pkg.Plan(q, n)
     B._check(pkg.load_library().fhe_ntt_plan_prepare(plan.handle))
     x = torch.empty(batch * n, dtype=torch.int64, device=dev)
     y = torch.empty(batch * n, dtype=torch.int64, device=dev)
     z = torch.empty(batch * n, dtype=torch.int64, device=dev) if inverse_too else None
-    first = rank * batch * n      # rank r owns rows [r*batch, (r+1)*batch) of the global batch
+    first = b0 * n                # this rank owns rows [b0, b0 + batch) of the global batch
     B.fill_synthetic_dev(q, seed, first, batch * n, x.data_ptr(), st)
 
     def step():
@@ -139,7 +163,7 @@ def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
     def parity(O, np):
         rng = np.random.default_rng(7)
         rows = sorted(set(list(range(min(8, batch))) + list(range(max(0, batch - 8), batch)) +
-                          [int(r) for r in rng.integers(0, batch, 48)]))
+                          [int(r) for r in rng.integers(0, batch, 48)])) if batch else []
         Y = y.view(batch, n)
         bad = 0
         for r in rows:
@@ -171,11 +195,18 @@ def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
                 "value_1core": 1.0 / per_ntt}
 
     transforms = 2 if inverse_too else 1
-    small_q = q * 25 < (1 << 32) and 8 <= log_n <= 17      # smallq.hip: 32-bit words (NOT the BASELINE modulus: --q given)
-    name = (f"batched forward+inverse negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
-            "(BASELINE.json configs[1] shape), device-resident" if inverse_too else
-            f"batched forward negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
-            "(BASELINE.json configs[4] shape), device-resident in->out")
+    arith = plan.arithmetic()                              # which exact Zq::mul the kernels run (fhe_ntt_plan_arithmetic)
+    small_q = arith == 3                                   # smallq.hip: 32-bit words (NOT the BASELINE modulus: --q given)
+    if inverse_too:
+        name = (f"batched forward+inverse negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
+                "(BASELINE.json configs[1] shape), device-resident")
+    elif strong:
+        name = (f"batched forward negacyclic NTT, N={n}, q={q}, global batch {total} polynomials block-partitioned over "
+                f"{world} GPU(s) by fhe_shard_range ({batch} on rank 0; BASELINE.json configs[4]; strong scaling), "
+                "device-resident in->out")
+    else:
+        name = (f"batched forward negacyclic NTT, N={n}, q={q}, {batch} polynomials on EVERY GPU (--batch-per-gpu: the WEAK "
+                f"variant of BASELINE.json configs[4], global batch {total}), device-resident in->out")
     metric = ("NTT/s (N=4096, 64-bit q, forward+inverse) per node; achieved HBM GB/s vs roofline" if inverse_too
               else "NTT/s (N=2^16, 64-bit q) per node; achieved HBM GB/s vs roofline")
     if small_q:
@@ -186,12 +217,14 @@ def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
         "unit": "NTT/s", "units_per_step": transforms * batch, "step": step, "parity": parity, "cpu": cpu,
         "alg_bytes_per_unit": 16 * n,            # read N + write N coefficients of 8 B
         "bfly_per_unit": (n // 2) * log_n,
-        "bfly_bits": 32 if small_q else 64, "dtype": "u32" if small_q else "u64",
+        "bfly_bits": 32 if small_q else 64, "dtype": "u32" if small_q else "u64", "arith": arith,
         # every pass kernel reads and writes each coefficient once (the small-modulus two-pass sizes keep u32 in between)
         "pass_bytes_per_launch_per_unit": 12 * n if (small_q and log_n > 14) else 16 * n,
-        "config": {"workload": name, "n": n, "q": q, "batch_per_gpu": batch, "global_batch": world * batch,
+        "config": {"workload": name, "n": n, "q": q, "batch_per_gpu": batch, "global_batch": total,
+                   "arithmetic": pkg.Plan.ARITH_NAMES[arith],
                    "parallelism": f"batch-sharded x{world}, no collective"},
-        "plan": plan, "x": x, "y": y, "n": n, "q": q, "batch": batch, "seed": seed,
+        "global_units_per_step": transforms * total, "scaling": "strong" if strong else "weak",
+        "plan": plan, "x": x, "y": y, "n": n, "q": q, "batch": batch, "seed": seed, "total": total, "b0": b0,
     }
 
 
@@ -318,7 +351,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
 
         dist = dist_mod
@@ -389,7 +422,8 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
         step_achieved = per_gpu * W["alg_bytes_per_unit"] / 1e9      # the whole step, algorithmic GB/s per GPU
         small = W.get("bfly_bits", 64) == 32
-        valu_peak = VALU_PEAK_GBFLY32 if small else VALU_PEAK_GBFLY
+        pm = W.get("arith") == 2
+        valu_peak = VALU_PEAK_GBFLY32 if small else VALU_PEAK_GBFLY_PM if pm else VALU_PEAK_GBFLY
         roofline = {
             "bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": step_achieved / HBM_PEAK_GBS, "traffic": None,
@@ -403,8 +437,11 @@ def main():
                      "peak": valu_peak, "unit": "Gbutterfly/s",
                      "frac": per_gpu * W["bfly_per_unit"] / 1e9 / valu_peak,
                      "butterflies_per_unit": W["bfly_per_unit"],
-                     "butterfly": "32-bit words modulo 27-bit primes (6 instructions)" if small else "64-bit words modulo q < 2^61 (Shoup, 10 multiplies)",
+                     "butterfly": ("32-bit words modulo 27-bit primes (6 instructions)" if small else
+                                   "64-bit words modulo a pseudo-Mersenne q = 2^k - delta (split multiplicand, 5 multiplies, 14 instructions)" if pm else
+                                   "64-bit words modulo q < 2^61 (Shoup, 10 multiplies)"),
                      "peak_source": ("tools/ubench_bfly.hip v13 (registers only), profiles/r02_ubench_bfly.txt" if small else
+                                     "tools/ubench_bfly.hip v17 (production butterfly, registers only), profiles/r03_ubench_bfly.txt" if pm else
                                      "tools/ubench_bfly.hip v8 (production butterfly, registers only), profiles/r01_ubench_bfly.txt")},
         }
         if dom and W["pass_bytes_per_launch_per_unit"]:
@@ -467,7 +504,7 @@ def main():
         import numpy as np
 
         n, q, batch, plan, seed = W["n"], W["q"], W["batch"], W["plan"], W["seed"]
-        gbatch = world * batch
+        gbatch = W["total"]
 
         def transform(rows):     # the per-rank engine: Plan.forward_dev on device tensors
             d = rows.to(dev)
@@ -488,20 +525,36 @@ def main():
             whole = transform(rows_fn(0, gbatch))
             out["gather_check"] = {"rows": gbatch, "equal_to_single_rank_transform": bool(torch.equal(full, whole))}
 
-    if args.allgather and dist is not None and args.backend == "nccl" and args.config == 5:
-        # optional: the one collective of SURVEY.md §8e, timed on its own (not part of `value`)
-        y, n, batch = W["y"], W["n"], W["batch"]
-        slab = min(batch, 1024) * n
-        gathered = torch.empty(world * slab, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gathered, y[:slab])
+    if args.allgather and dist is not None and args.config == 5:
+        # optional: the one collective of SURVEY.md §8e — every rank's REAL result shard onto every rank — timed on its
+        # own (never part of `value`).  nccl = RCCL on device tensors; gloo (rehearsals) moves host copies.
+        n, batch, total = W["n"], W["batch"], W["total"]
+        shard = W["y"].view(batch, n)
+        if args.backend != "nccl":
+            shard = shard.cpu()
+        chunk = args.allgather_chunk_rows
+        gathered = pkg.sharding.all_gather_rows(shard, total, chunk_rows=chunk)     # warm-up: connections, buffers
+        ok = None
+        if rank == 0:     # the gathered batch holds this rank's rows in this rank's place (the others checked by --gather-check)
+            ok = bool(torch.equal(gathered[W["b0"]:W["b0"] + batch], shard))
+        del gathered
         fence()
         t0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, y[:slab])
+        gathered = pkg.sharding.all_gather_rows(shard, total, chunk_rows=chunk)
         fence()
         dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        per = -(-total // world)
         if rank == 0:
-            out["allgather"] = {"bytes_received_per_rank": (world - 1) * slab * 8, "seconds": dt,
-                                "GBps_per_rank": (world - 1) * slab * 8 / dt / 1e9}
+            out["allgather"] = {"backend": "rccl" if args.backend == "nccl" else "gloo (host copies)",
+                                "rows_per_rank": per, "rows_gathered": total, "collectives": 1 if not chunk else -(-per // chunk),
+                                "bytes_sent_per_rank": per * n * 8, "bytes_received_per_rank": (world - 1) * per * n * 8,
+                                "seconds": dt, "GBps_received_per_rank": (world - 1) * per * n * 8 / dt / 1e9,
+                                "own_rows_in_place": ok,
+                                "note": "timed on its own after the transform; not part of `value` (SURVEY.md §8e)"}
+        del gathered
 
     if rank == 0 and not args.no_cpu_baseline:
         import numpy as np
@@ -510,6 +563,9 @@ def main():
         out["cpu_baseline"] = W["cpu"](load_oracle(), np, args.cpu_seconds)
 
     if rank == 0:
+        if dist is not None:
+            out["distributed"] = {"backend": "rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo",
+                                  "world_size": world, "forced_at_world_1": bool(args.force_dist and world == 1)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

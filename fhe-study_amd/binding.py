@@ -46,7 +46,7 @@ EXPORTS = [
     "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
-    "fhe_ntt_plan_prepare", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace",
+    "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace",
     "fhe_tggsw_prepared_words", "fhe_tggsw_prepare_dev", "fhe_tggsw_external_product_prepared_dev",
     "fhe_glwe_ksk_prepared_words", "fhe_glwe_ksk_prepare_dev", "fhe_glwe_key_switch_prepared_dev",
     "fhe_bfv_rlk_prepared_words", "fhe_bfv_rlk_prepare_dev", "fhe_bfv_relinearize_prepared_dev", "fhe_bfv_mul_prepared_dev",
@@ -223,6 +223,7 @@ def load_library():
     L.fhe_rq_div_round_dev.argtypes = [_u64, _u64, _vp, _vp, _sz, _vp]
     L.fhe_ntt_device_count.argtypes = []
     L.fhe_ntt_plan_prepare.argtypes = [_vp]
+    L.fhe_ntt_plan_arithmetic.argtypes = [_vp]
     L.fhe_ntt_release_stream_workspace.argtypes = [_vp]
     L.fhe_ntt_set_check_canonical.argtypes = [_int]
     L.fhe_shard_range.argtypes = [_sz, _uint, _uint, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
@@ -255,6 +256,15 @@ class Plan:
         _check(L.fhe_ntt_plan_get(int(q), int(n), ctypes.byref(h)))
         self.handle = h
         self.q, self.n = int(q), int(n)
+
+    ARITH_NAMES = {0: "shoup62", 1: "shoup61", 2: "pseudo-mersenne", 3: "word32"}
+
+    def arithmetic(self):
+        """fhe_ntt_plan_arithmetic: which exact form of Zq::mul the transform kernels run for this modulus"""
+        rc = load_library().fhe_ntt_plan_arithmetic(self.handle)
+        if rc < 0:
+            _check(rc)
+        return rc
 
     def info(self):
         q, n, psi, ninv = _u64(), _u64(), _u64(), _u64()

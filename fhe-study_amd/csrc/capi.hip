@@ -332,6 +332,13 @@ bool fhe_pm_enabled() {
     return on;
 }
 
+extern "C" int fhe_ntt_plan_arithmetic(const fhe_ntt_plan *plan) {
+    if (!plan) return fail(FHE_E_NULL, "plan is NULL");
+    if (fhe::smallq_supported(plan->q, plan->log_n) && fhe_ext32_enabled()) return FHE_ARITH_WORD32;
+    if (plan->mod.pm_k != 0 && fhe_pm_enabled()) return FHE_ARITH_PMERSENNE;
+    return (plan->q >> 61) == 0 ? FHE_ARITH_SHOUP61 : FHE_ARITH_SHOUP62;
+}
+
 extern "C" int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan) {
     if (!plan) return fail(FHE_E_NULL, "plan is NULL");
     fhe::DevicePlan dp;

@@ -17,13 +17,15 @@ def shard_range(batch, world, rank):
     return b0, min(batch, b0 + per)
 
 
-def all_gather_rows(local_rows, batch, group=None):
+def all_gather_rows(local_rows, batch, group=None, chunk_rows=0):
     """local_rows: (b1-b0, n) int64 tensor of this rank's shard → (batch, n) on every rank.
-    ONE all_gather_into_tensor per call (xGMI links are per-peer: fewer, larger collectives).
-    A full shard (every rank when batch % world == 0 — config 5: 8192 rows, 4 GiB per rank) is
-    sent as it is, no copy; only a rank whose block is short (the ragged tail: 77 of 79 rows
-    at 630 over 8) stages its rows in a ceil(B/G)-row buffer, because the collective needs
-    equal counts."""
+    chunk_rows = 0: ONE all_gather_into_tensor per call (xGMI links are per-peer: fewer, larger
+    collectives).  A full shard (every rank when batch % world == 0 — config 5: 8192 rows, 4 GiB per
+    rank) is sent as it is, no copy; only a rank whose block is short (the ragged tail: 77 of 79 rows
+    at 630 over 8) stages its rows in a ceil(B/G)-row buffer, because the collective needs equal counts.
+    chunk_rows = R > 0: the shard travels in ceil(per / R) collectives of R rows per rank, each landing
+    in a (world, R, n) staging buffer that is then copied into place — for a consumer that starts on
+    the first rows while the rest is still on the links, and to bound the collective's size."""
     world = dist.get_world_size(group)
     per = -(-batch // world)
     n = local_rows.shape[1]
@@ -31,8 +33,18 @@ def all_gather_rows(local_rows, batch, group=None):
     if local_rows.shape[0] != per:
         send = torch.zeros((per, n), dtype=local_rows.dtype, device=local_rows.device)
         send[: local_rows.shape[0]] = local_rows
+    send = send.contiguous()
     out = torch.empty((world * per, n), dtype=local_rows.dtype, device=local_rows.device)
-    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    if not chunk_rows or chunk_rows >= per:
+        dist.all_gather_into_tensor(out, send, group=group)
+        return out[:batch]
+    placed = out.view(world, per, n)
+    stage = torch.empty((world * chunk_rows, n), dtype=local_rows.dtype, device=local_rows.device)
+    for c0 in range(0, per, chunk_rows):
+        rows = min(per, c0 + chunk_rows) - c0
+        st = stage[: world * rows]                      # (world * rows, n): the flat form every backend accepts
+        dist.all_gather_into_tensor(st, send[c0:c0 + rows], group=group)
+        placed[:, c0:c0 + rows] = st.view(world, rows, n)
     return out[:batch]
 
 

@@ -92,6 +92,19 @@ int fhe_ntt_plan_tables(const fhe_ntt_plan *plan, uint64_t *roots, uint64_t *roo
  * of at the first transform there — the device-side half of CACHE's one-off
  * table build (ntt.rs:20-38). */
 int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan);
+/* Which arithmetic the transform kernels run for this plan's modulus — Zq::mul (arith/src/zq.rs:315-328) is generic
+ * over q; the engine picks the cheapest exact form at plan time.  Host-only, never fails for a valid plan:
+ *   FHE_ARITH_SHOUP62   q < 2^62: Shoup product (10 32-bit multiplies), values in [0,4q) between stages
+ *   FHE_ARITH_SHOUP61   q < 2^61: the same with compile-time value bounds (a correction every other stage)
+ *   FHE_ARITH_PMERSENNE q = 2^k - delta, 56 <= k <= 61, delta <= 2^(k-39) (2^61 - 2^21 + 1 is one): split
+ *                       multiplicand, no quotient, 5 multiplies (FHE_PM=0 in the environment selects SHOUP61 instead)
+ *   FHE_ARITH_WORD32    q < 2^32/25 and 2^8 <= n <= 2^17: one 32-bit word per coefficient (FHE_EXT32=0: SHOUP61)
+ * Results are the same words in every case.  Returns a negative FHE_E_* for a NULL plan. */
+#define FHE_ARITH_SHOUP62 0
+#define FHE_ARITH_SHOUP61 1
+#define FHE_ARITH_PMERSENNE 2
+#define FHE_ARITH_WORD32 3
+int fhe_ntt_plan_arithmetic(const fhe_ntt_plan *plan);
 
 /* ---- transforms: host buffers ------------------------------------------- */
 /* NTT::ntt(&Rq)->Rq, arith/src/ntt.rs:44-73: natural order in, bit-reversed

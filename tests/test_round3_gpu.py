@@ -6,6 +6,7 @@ q = 2^k - delta with 56 <= k <= 61 and delta <= 2^(k-39) — SURVEY.md section 8
 bounds the kernels rely on; the GPU part is word-for-word parity with the oracle at every such modulus shape, and
 identity with the Shoup kernels (FHE_PM=0) on the same inputs.
 """
+import json
 import os
 import random
 import subprocess
@@ -217,3 +218,67 @@ def test_shoup_and_pseudo_mersenne_kernels_give_the_same_words(pkg, oracle, need
         outs[pm] = [l for l in r.stdout.splitlines() if l.startswith("digest")]
         assert len(outs[pm]) == 4
     assert outs["0"] == outs["1"]
+
+
+# ---- multi-GPU rehearsals on the one GPU of the box ------------------------------------------------
+
+
+def _run_bench(args, nproc, timeout=900):
+    from test_sharding_gloo import _free_port
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_through_rccl_at_world_size_one(pkg, need_gpu):
+    """bench.py as ONE rank under the launcher with --backend nccl --force-dist: init_process_group("nccl"), the
+    barriers, the MAX all-reduce of the elapsed time on a DEVICE tensor and all_gather_into_tensor of the rank's real
+    shard all execute in librccl — nothing of the N > 1 line is first run on the day an 8-GPU node appears."""
+    out = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--backend", "nccl", "--force-dist", "--allgather",
+                      "--batch-per-gpu", "256", "--no-cpu-baseline", "--parity-all-ranks"], 1)
+    assert out["n_gpus"] == 1 and out["distributed"]["backend"].startswith("rccl") and out["distributed"]["forced_at_world_1"]
+    assert out["parity"]["mismatching_rows"] == 0 and out["parity"]["ranks_checked"] == 1
+    ag = out["allgather"]
+    assert ag["backend"] == "rccl" and ag["rows_per_rank"] == 256 and ag["rows_gathered"] == 256
+    assert ag["bytes_sent_per_rank"] == 256 * 65536 * 8 and ag["own_rows_in_place"] is True and ag["seconds"] > 0
+    # chunked form of the same collective
+    out = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "1", "--backend", "nccl", "--force-dist", "--allgather",
+                      "--allgather-chunk-rows", "96", "--global-batch", "256", "--no-cpu-baseline", "--no-parity"], 1)
+    assert out["allgather"]["collectives"] == 3 and out["allgather"]["own_rows_in_place"] is True
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 256
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_two_ranks_on_one_gpu(pkg, need_gpu):
+    """BASELINE.json configs[4] fixes the GLOBAL batch: two ranks (sharing cuda:0, gloo rendezvous) split 512 + 1
+    polynomials by fhe_shard_range (257 + 256), both shards against the oracle, shards gathered == single-rank
+    transform, and the all-gather of the real shards reported on its own."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--share-gpu", "--backend", "gloo",
+                      "--global-batch", "513", "--no-cpu-baseline", "--parity-all-ranks", "--gather-check", "--allgather"], 2)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == 513 and out["config"]["batch_per_gpu"] == 257
+    assert "strong scaling" in out["config"]["workload"]
+    assert out["parity"]["mismatching_rows"] == 0 and out["parity"]["ranks_checked"] == 2
+    assert out["gather_check"]["rows"] == 513 and out["gather_check"]["equal_to_single_rank_transform"] is True
+    assert out["allgather"]["rows_per_rank"] == 257 and out["allgather"]["rows_gathered"] == 513
+    # value counts the GLOBAL batch once per step
+    assert abs(out["value"] - 513 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_default_line_is_the_headline_configuration(pkg, need_gpu):
+    """no flags beyond the driver's: global batch 65536 on one GPU, the modulus of SURVEY.md section 8, the
+    five-multiply arithmetic — checked on a short run (2 steps)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["global_batch"] == 65536 and out["config"]["batch_per_gpu"] == 65536
+    assert out["config"]["q"] == Q61 and out["config"]["n"] == 65536 and out["config"]["arithmetic"] == "pseudo-mersenne"
+    assert out["scaling"] == "strong" and out["parity"]["mismatching_rows"] == 0
+    assert out["roofline"]["step_frac"] > 0.2

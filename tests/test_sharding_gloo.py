@@ -1,7 +1,9 @@
 """CPU, world_size 2, gloo: the N>1 path — block partition of the batch and the optional
 all-gather of result shards.  No GPU here, so the per-rank engine is stood in for by the
 CPU oracle (test infrastructure); what is under test is the sharding/gather plumbing that
-bench.py and downstream callers use with the HIP engine on real ranks."""
+bench.py and downstream callers use with the HIP engine on real ranks.  (The HIP engine itself
+under a process group is driven by the -m gpu tests: tests/test_round2_gpu.py runs bench.py as two
+ranks on one GPU, tests/test_round3_gpu.py runs it through RCCL and in its strong-scaling form.)"""
 import os
 import socket
 import sys
@@ -48,6 +50,10 @@ def _worker(rank, world, port, batch, n, q, out_dir):
     assert local.shape == (b1 - b0, n)
     full = eng.forward_sharded(rows_fn, batch, gather=True)
     np.save(os.path.join(out_dir, f"full_{rank}.npy"), full.numpy())
+    # the same gather in chunks of rows (several collectives + copies into place): same batch
+    for chunk in (1, 2, 3, 64):
+        again = pkg.sharding.all_gather_rows(local, batch, chunk_rows=chunk)
+        assert torch.equal(again, full), (rank, chunk)
     dist.barrier()
     dist.destroy_process_group()
 

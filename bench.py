@@ -265,6 +265,7 @@ def workload_bfv(args, pkg, torch, dev, st, rank, world):
                           f"oracle/fhe_next_oracle.c) on {cores} threads, {dt:.1f} s; single thread {one:.2f}/s",
                 "value_1core": one}
 
+    ext32 = os.environ.get("FHE_EXT32", "1")[:1] != "0"      # FHE_EXT32=0: the general 61-bit path (zring.hip)
     log2n = (2 * n).bit_length() - 1
     # bfv32.hip (small q): tensor 2 primes x (4 forward + 3 inverse) size-2N transforms, relinearisation 3 primes x
     # (1 forward + 2 inverse), all 32-bit butterflies (the key's forward transforms are per call, not per ciphertext)
@@ -273,8 +274,8 @@ def workload_bfv(args, pkg, torch, dev, st, rank, world):
         "metric": "BFV ct x ct multiply + relinearise per second (N=8192, q=65537, t=2, p=q^2) per node",
         "unit": "ct-mul/s", "units_per_step": batch, "step": step, "parity": parity, "cpu": cpu,
         "alg_bytes_per_unit": (4 + 2) * 8 * n,      # two ciphertexts in, one out; the key is shared by the batch
-        "bfly_per_unit": transforms * n * log2n,    # (2N/2) * log2(2N) per size-2N transform
-        "bfly_bits": 32,
+        "bfly_per_unit": (transforms if ext32 else 13) * n * log2n,    # (2N/2) * log2(2N) per size-2N transform; 61-bit path: 13 of them
+        "bfly_bits": 32 if ext32 else 64,
         "pass_bytes_per_launch_per_unit": None,
         "config": {"workload": f"RLWE::mul (tensor + relinearize_204), N={n}, q={q}, t={t}, p=q^2, {batch} ciphertext pairs "
                                "per GPU (BASELINE.json configs[2]), device-resident",
@@ -319,15 +320,16 @@ def workload_extprod(args, pkg, torch, dev, st, rank, world):
                           f"{cores} threads, {dt:.1f} s; single thread {one:.2f}/s",
                 "value_1core": one}
 
+    ext32 = os.environ.get("FHE_EXT32", "1")[:1] != "0"      # FHE_EXT32=0: the 61-bit fused kernels (digit_mac.hip), one prime
     log2n = n.bit_length() - 1
     # digit32.hip: every transform modulo two 27-bit primes (32-bit butterflies)
-    transforms = 2 * ((k + 1) * l + 2 * (k + 1))     # digit transforms + the inverses of the two 32-bit key halves
+    transforms = (2 if ext32 else 1) * ((k + 1) * l + 2 * (k + 1))     # digit transforms + the inverses of the two 32-bit key halves
     return {
         "metric": "TGGSW x TGLWE external products per second (N=1024, k=1, l=64) per node",
         "unit": "products/s", "units_per_step": batch, "step": step, "parity": parity, "cpu": cpu,
         "alg_bytes_per_unit": 2 * (k + 1) * 8 * n,    # ciphertext in + out; the TGGSW key is shared by the batch
         "bfly_per_unit": transforms * (n // 2) * log2n,
-        "bfly_bits": 32,
+        "bfly_bits": 32 if ext32 else 64,
         "pass_bytes_per_launch_per_unit": None,
         "config": {"workload": f"TGGSW x TGLWE external product, N={n}, k={k}, l={l}, {total} products block-sharded over "
                                f"{world} GPU(s) by fhe_shard_range (BASELINE.json configs[3]), device-resident",

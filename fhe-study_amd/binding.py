@@ -46,7 +46,7 @@ EXPORTS = [
     "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
-    "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace",
+    "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace", "fhe_ntt_workspace_bytes",
     "fhe_tggsw_prepared_words", "fhe_tggsw_prepare_dev", "fhe_tggsw_external_product_prepared_dev",
     "fhe_glwe_ksk_prepared_words", "fhe_glwe_ksk_prepare_dev", "fhe_glwe_key_switch_prepared_dev",
     "fhe_bfv_rlk_prepared_words", "fhe_bfv_rlk_prepare_dev", "fhe_bfv_relinearize_prepared_dev", "fhe_bfv_mul_prepared_dev",
@@ -152,6 +152,12 @@ def load_library():
             "there is no fallback path")
     _preload_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
+    L.fhe_ntt_version.restype = ctypes.c_char_p
+    if b"ABLATED" in L.fhe_ntt_version() and os.environ.get("FHE_NTT_ALLOW_ABLATED") != "1":
+        # a timing-only build (tools/abl_build.sh: kernels that skip work and return wrong words by design), reached
+        # through a stray FHE_NTT_LIB or -D flag: never run tests or benches on it by accident
+        raise RuntimeError(f"{LIB_PATH} reports {L.fhe_ntt_version().decode()!r}: a timing-only build with wrong results "
+                           "by design; set FHE_NTT_ALLOW_ABLATED=1 to load it on purpose (tools/abl_*.py do)")
     L.fhe_ntt_plan_get.argtypes = [_u64, _u64, ctypes.POINTER(_vp)]
     L.fhe_ntt_plan_info.argtypes = [_vp, _p64, _p64, _p64, _p64]
     L.fhe_ntt_plan_tables.argtypes = [_vp, _p64, _p64]
@@ -224,6 +230,8 @@ def load_library():
     L.fhe_ntt_device_count.argtypes = []
     L.fhe_ntt_plan_prepare.argtypes = [_vp]
     L.fhe_ntt_plan_arithmetic.argtypes = [_vp]
+    L.fhe_ntt_workspace_bytes.argtypes = []
+    L.fhe_ntt_workspace_bytes.restype = _sz
     L.fhe_ntt_release_stream_workspace.argtypes = [_vp]
     L.fhe_ntt_set_check_canonical.argtypes = [_int]
     L.fhe_shard_range.argtypes = [_sz, _uint, _uint, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]

@@ -313,4 +313,13 @@ hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) { FHE
 hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_relin_inverse_kernel, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1) }
 #undef FHE_BIG_SWITCH
 
+// timing-only builds (tools/abl_build.sh) produce wrong words by design: fhe_ntt_version() says so (capi.hip)
+bool bfv32_ablated() {
+#if defined(FHE_B32_ABLATE_INV) || defined(FHE_B32_ABLATE_EPI)
+    return true;
+#else
+    return false;
+#endif
+}
+
 }  // namespace fhe

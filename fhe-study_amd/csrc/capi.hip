@@ -558,13 +558,24 @@ extern "C" int fhe_ntt_release_stream_workspace(void *hip_stream) {
     HIP_TRY(hipStreamSynchronize(st));
     const size_t tid = st == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0;
     std::lock_guard<std::mutex> lk(g_ws_lock);
-    for (int slot = 0; slot < 2; slot++) {
-        auto it = g_ws.find(WsKey{slot, dev, st, tid});
-        if (it == g_ws.end()) continue;
-        if (it->second.ptr) (void)hipFree(it->second.ptr);
-        g_ws.erase(it);
+    for (auto it = g_ws.begin(); it != g_ws.end();) {        // every slot of this (device, stream, thread)
+        if (it->first.dev == dev && it->first.st == st && it->first.tid == tid) {
+            if (it->second.ptr) (void)hipFree(it->second.ptr);
+            it = g_ws.erase(it);
+        } else {
+            ++it;
+        }
     }
     return FHE_OK;
+}
+
+// bytes of library workspace currently held on every device (live buffers; buffers retired by a growth are released at
+// fhe_ntt_shutdown() and not counted)
+extern "C" size_t fhe_ntt_workspace_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_ws_lock);
+    size_t total = 0;
+    for (auto &kv : g_ws) total += kv.second.bytes;
+    return total;
 }
 
 void fhe_workspace_free_all() {
@@ -1021,7 +1032,11 @@ extern "C" int fhe_ntt_device_count(void) {
 }
 
 extern "C" const char *fhe_last_error(void) { return g_err; }
-extern "C" const char *fhe_ntt_version(void) { return "fhe_ntt 0.2 (gfx950)"; }
+extern "C" const char *fhe_ntt_version(void) {
+    // a library linked from a timing-only object (tools/abl_build.sh) computes wrong words by design: say so
+    const bool ablated = fhe::ntt_kernels_ablated() || fhe::digit_mac_ablated() || fhe::digit32_ablated() || fhe::bfv32_ablated();
+    return ablated ? "fhe_ntt 0.3 (gfx950) ABLATED" : "fhe_ntt 0.3 (gfx950)";
+}
 
 extern "C" int fhe_ntt_shutdown(void) {
     {

@@ -518,4 +518,13 @@ hipError_t launch_ext32_tail_ks(const Ext32Args &a, int log_n, hipStream_t st) {
 #undef FHE_LP_SWITCH
 #undef FHE_COMMA
 
+// timing-only builds (tools/abl_build.sh) produce wrong words by design: fhe_ntt_version() says so (capi.hip)
+bool digit32_ablated() {
+#if defined(FHE_D32_ABLATE_NTT) || defined(FHE_D32_ABLATE_MAC)
+    return true;
+#else
+    return false;
+#endif
+}
+
 }  // namespace fhe

@@ -381,4 +381,13 @@ hipError_t launch_sum_parts(const u64 *partial, u64 *out, u64 batch, uint32_t pa
     return hipGetLastError();
 }
 
+// timing-only builds (tools/abl_digit_mac.py) produce wrong words by design: fhe_ntt_version() says so (capi.hip)
+bool digit_mac_ablated() {
+#if defined(FHE_DM_ABLATE_NTT) || defined(FHE_DM_ABLATE_MAC) || defined(FHE_ABLATE_NO_BUTTERFLIES)
+    return true;
+#else
+    return false;
+#endif
+}
+
 }  // namespace fhe

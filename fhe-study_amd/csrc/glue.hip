@@ -534,6 +534,14 @@ static int ksk_args_ok(const char *fn, const fhe_ntt_plan *plan, unsigned k, uns
 }
 extern "C" size_t fhe_glwe_ksk_prepared_words(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l) {
     if (!plan || k == 0 || l == 0 || beta < 2) return 0;
+    {   // the arguments fhe_glwe_ksk_prepare_dev would reject (check_decompose_args) have no prepared form: 0, and the
+        // caller's fhe_last_error() is left as it was
+        unsigned bad = beta == 2 ? l > 64 : 0;
+        u64 bl = 1;
+        for (unsigned i = 0; beta != 2 && i < l && !bad; i++) { bl *= beta; bad = (bl >> 32) != 0; }
+        if (!bad && beta != 2 && plan->q / bl == 0) bad = 1;
+        if (bad) return 0;
+    }
     const size_t rows = (size_t)k * l * (k + 1);
     return (ks32_usable(plan, k, beta, l) ? 2 : 1) * rows * plan->n;
 }

@@ -177,8 +177,14 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
             for (int j = 0; j < 8; j++) {
                 const ulonglong2 y = ld_c<ulonglong2>(pin2, g0 + j * 16u);
                 ulonglong2 p;
-                p.x = mul_mod_var(v[2 * j], y.x, a.mod);
-                p.y = mul_mod_var(v[2 * j + 1], y.y, a.mod);
+                if constexpr (AR == 2) {   // both canonical: five multiplies; canonical only if the product is an output
+                    p.x = mul_var_pm(v[2 * j], y.x, a.mod);
+                    p.y = mul_var_pm(v[2 * j + 1], y.y, a.mod);
+                    if (a.out2) { p.x = pm_canon(p.x, a.mod); p.y = pm_canon(p.y, a.mod); }
+                } else {
+                    p.x = mul_mod_var(v[2 * j], y.x, a.mod);
+                    p.y = mul_mod_var(v[2 * j + 1], y.y, a.mod);
+                }
                 v[2 * j] = p.x;
                 v[2 * j + 1] = p.y;
                 if (a.out2 && active) st_c<ulonglong2>(pout2, g0 + j * 16u, p);
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
 
     __syncthreads();
     // inputs are canonical (evals, or their product); a non-FINAL pass hands values below 4q (WIDE) / 2q on
-    if constexpr (AR == 2) inv_rounds_contig_pm<LP, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) inv_rounds_contig_pm<LP, FINAL, true, (MUL_IN ? kPmMul : kPmOne)>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_contig<LP, WIDE, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
 
     if (active) {
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
 
     // an operand: coefficients -> forward transform (natural-order load, window A0), or evals ->
     // the 16 consecutive values of this thread; canonical in the [0,4) register window either way
-    auto operand = [&](const u64 *__restrict__ src, bool is_evals, u64 (&v)[16], auto fresh) {
+    auto operand = [&](const u64 *__restrict__ src, bool is_evals, bool keep, u64 (&v)[16], auto fresh) {
         const u64 *__restrict__ p = src + ubase;
         if (is_evals) {
 #pragma unroll
@@ -289,10 +295,12 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = ld_c<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
-            if constexpr (AR == 2) {
+            if constexpr (AR == 2) {   // canonical only where the evals are an output (see the product below)
                 fwd_rounds_contig_pm<LP, kPmOne, decltype(fresh)::value>(v, lds, ltw_f, a.tw, 0u, 0u, w, tf, m);
+                if (keep) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = pm_canon(v[k], m);
+                    for (int k = 0; k < 16; k++) v[k] = pm_canon(v[k], m);
+                }
             } else {
                 fwd_rounds_single<LP, WIDE, decltype(fresh)::value>(v, lds, ltw_f, a.tw, w, tf, m);
             }
@@ -306,15 +314,25 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
     };
 
     u64 va[16], vb[16];
-    operand(a.in, a.flags & 1u, va, std::true_type{});
+    operand(a.in, a.flags & 1u, a.out3 != nullptr, va, std::true_type{});
     store_evals(a.out3, va);
-    operand(a.in2, a.flags & 2u, vb, std::false_type{});   // the tile may have been used by the first operand
+    operand(a.in2, a.flags & 2u, a.out4 != nullptr, vb, std::false_type{});   // the tile may have been used by the first operand
     store_evals(a.out4, vb);
+    // zip_eq(l,r).map(l*r), ring_nq.rs:601-604
+    if constexpr (AR == 2) {   // lazy operands are fine: a < 7.1 q as it is, b brought below 2^k; the product is canonical only as an output
 #pragma unroll
-    for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);   // zip_eq(l,r).map(l*r), ring_nq.rs:601-604
+        for (int k = 0; k < 16; k++) va[k] = mul_var_pm(va[k], pm_below_2k(vb[k], m), m);
+        if (a.out2) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) va[k] = pm_canon(va[k], m);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
+    }
     store_evals(a.out2, va);
     if constexpr (C::NR == 1) { /* twiddles published above */ } else if (a.flags == 3u) __syncthreads();   // no forward exchange ran
-    if constexpr (AR == 2) inv_rounds_contig_pm<LP, true, false>(va, lds, ltw_i, a.tw_inv, 0u, 0u, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) inv_rounds_contig_pm<LP, true, false, kPmMul>(va, lds, ltw_i, a.tw_inv, 0u, 0u, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_single<LP, WIDE>(va, lds, ltw_i, a.tw_inv, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
@@ -393,13 +411,22 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     store_evals(a.out3, va);
     operand(a.in2, a.flags & 2u, a.out4 != nullptr, vb, std::false_type{});   // the tile may have been used by the first operand
     store_evals(a.out4, vb);
+    if constexpr (AR == 2) {   // as in rq_mul_fused_kernel
 #pragma unroll
-    for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
+        for (int k = 0; k < 16; k++) va[k] = mul_var_pm(va[k], pm_below_2k(vb[k], m), m);
+        if (a.out2) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) va[k] = pm_canon(va[k], m);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
+    }
     store_evals(a.out2, va);
     // the inverse rounds' first exchange follows a forward exchange's gather unless both operands were
     // evals; its leading barrier (FRESH = false) also publishes the inverse twiddle tile in that case
     if (a.flags == 3u) __syncthreads();   // no forward exchange ran: publish the twiddle tiles here
-    if constexpr (AR == 2) inv_rounds_contig_pm<LP, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) inv_rounds_contig_pm<LP, false, false, kPmMul>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_contig<LP, WIDE, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
@@ -1003,6 +1030,15 @@ hipError_t launch_check_canonical(const u64 *x, u64 count, u64 q, int *d_flag, h
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(check_canonical_kernel, dim3(ew_grid(count)), dim3(256), 0, st, x, count, q, d_flag);
     return post_launch();
+}
+
+// timing-only build (memory pattern without the arithmetic): wrong words by design, fhe_ntt_version() says so (capi.hip)
+bool ntt_kernels_ablated() {
+#if defined(FHE_ABLATE_NO_BUTTERFLIES)
+    return true;
+#else
+    return false;
+#endif
 }
 
 }  // namespace fhe

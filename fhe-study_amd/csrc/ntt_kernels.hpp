@@ -106,5 +106,11 @@ hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y,
                                 hipStream_t st);
 hipError_t launch_fill_synthetic(u64 *out, u64 count, u64 q, u64 seed, u64 first, hipStream_t st);
 hipError_t launch_check_canonical(const u64 *x, u64 count, u64 q, int *d_flag, hipStream_t st);
+// true when the translation unit was compiled with one of its timing-only switches (FHE_*_ABLATE_*): its kernels then
+// skip work and return wrong words by design; fhe_ntt_version() reports it and the Python binding refuses such a library
+bool ntt_kernels_ablated();
+bool digit_mac_ablated();
+bool digit32_ablated();
+bool bfv32_ablated();
 
 }  // namespace fhe

@@ -573,7 +573,9 @@ __device__ __forceinline__ void fwd_rounds_contig_pm(u64 (&v)[16], u64 *lds, con
     }
 }
 
-template <int LP, bool FOLD, bool FRESH>
+// BFIRST: bound (sixteenths of q) of what the first round that runs receives: canonical evals from memory (kPmOne), or
+// the lazy pointwise product formed in registers (kPmMul)
+template <int LP, bool FOLD, bool FRESH, int BFIRST = kPmOne>
 __device__ __forceinline__ void inv_rounds_contig_pm(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
                                                      u32 w, u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
     using C = ContigCfg<LP>;
@@ -581,7 +583,7 @@ __device__ __forceinline__ void inv_rounds_contig_pm(u64 (&v)[16], u64 *lds, con
     auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
         return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
     };
-    constexpr int BF = kPmOne, BN = kPmInvBound;   // canonical inputs for the first round that runs
+    constexpr int BF = BFIRST, BN = kPmInvBound;
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
         constexpr bool L = C::in_lds(3);

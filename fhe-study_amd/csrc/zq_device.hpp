@@ -220,6 +220,22 @@ __device__ __forceinline__ u64 mul_pm(u64 y, u64 w, u64 w2, const Mod &m) {
     return r;
 }
 
+
+// VARIABLE x VARIABLE (zip_eq(l,r).map(l*r), arith/src/ring_nq.rs:601-604) on the same five multiplies: the second
+// table word of the multiplier b is formed on the fly, b 2^32 = (b >> (k-32)) 2^k + (b mod 2^(k-32)) 2^32
+// = (b >> (k-32)) delta + ((b mod 2^(k-32)) << 32)  (mod q), three instructions and a multiply for b < 2^k.
+// It is below 2^k (1 + 2^-7), so the product's T stays below 2^(k+33) for every multiplicand a < 7.9 q — anything the
+// rounds hand over.  13 instructions against ~50 for the Shoup form (mul_mod_var: two 64-bit quotients).
+__device__ __forceinline__ u64 pm_shift32(u64 w, const Mod &m) {
+    const u32 w0 = (u32)w, w1 = (u32)(w >> 32);
+    const u32 wh = __builtin_amdgcn_alignbit(w1, w0, m.pm_rsh);          // w >> (k-32) < 2^32 for w < 2^k
+    return (u64)wh * (u64)m.pm_delta + ((u64)(w0 & m.pm_rmask) << 32);
+}
+// x -> x (mod q), strictly below 2^k (not canonical): the form a variable multiplier needs
+__device__ __forceinline__ u64 pm_below_2k(u64 x, const Mod &m) { return pm_reduce(pm_reduce(x, m), m); }
+// a * b mod q, lazily (< 2q + q/16), for a < 7.9 q and b < 2^k
+__device__ __forceinline__ u64 mul_var_pm(u64 a, u64 b, const Mod &m) { return mul_pm<false>(a, b, pm_shift32(b, m), m); }
+
 // Forward butterfly (ntt.rs:57-62): x' = u + r, y' = u - r + 3q  (r = y w < 2q + q/16), u = x < B q  ->  both below
 // (B + 3) q; the caller reduces x first when B + 3 would pass 8.
 template <bool SGPR_TW>

@@ -22,12 +22,17 @@
  *     reference panics in the same situations; the Rust shim turns a non-zero
  *     return into `panic!`.
  *   - All functions are thread-safe and may be called concurrently, on the same
- *     or different plans.  Plans are immutable and owned by the library until
- *     fhe_ntt_shutdown().  Entry points that need intermediates use a
- *     library-owned workspace keyed by (device, stream): calls on one stream
- *     are ordered by the stream, calls on different streams (or, for
- *     hipStreamPerThread / the host-buffer entry points, different threads)
- *     never share a buffer.
+ *     or different plans, with ONE restriction: entry points that need
+ *     intermediates use a library-owned workspace keyed by (device, stream),
+ *     so the calls that use one (fhe_rq_mul_dev with d_work = NULL, the
+ *     small-modulus two-pass sizes, rows N1 - N3) must not be issued on the
+ *     SAME explicit stream — the NULL default stream included — from several
+ *     host threads at once: their kernel sequences would interleave on a
+ *     shared buffer.  Calls on one stream from one thread are ordered by the
+ *     stream; calls on different streams, and calls on hipStreamPerThread /
+ *     the host-buffer entry points from different threads (keyed by thread as
+ *     well), never share a buffer.  Plans are immutable and owned by the
+ *     library until fhe_ntt_shutdown().
  *   - `*_dev` variants take DEVICE pointers of the current HIP device and a
  *     `hipStream_t` passed as `void*` (NULL = the default stream); they only
  *     enqueue work and never synchronise — except the first use of a plan on a
@@ -343,7 +348,11 @@ int fhe_rq_remodule_dev(uint64_t p, const void *d_a, void *d_c, size_t count, vo
 int fhe_rq_mul_by_f64_dev(uint64_t q, double s, const void *d_a, void *d_c, size_t count, void *hip_stream);
 int fhe_rq_div_round_dev(uint64_t q, uint64_t s, const void *d_a, void *d_c, size_t count, void *hip_stream);
 /* Rq::decompose(beta, l), ring_nq.rs:67-78 with Zq::decompose zq.rs:141-207 (base 2 and
- * base beta, including their saturation branch).  a: [rows][n] -> out: [rows][l][n]. */
+ * base beta, including their saturation branch).  a: [rows][n] -> out: [rows][l][n].
+ * Argument ranges: beta = 2 takes 1 <= l <= 64; at l = 64 the reference's `1 << l` (zq.rs:176-180) overflows — a
+ * panic in a debug build, a shift taken modulo 64 in a --release build — and the kernels follow the RELEASE build
+ * (the saturation threshold is then 1).  beta > 2 needs beta^l < 2^32 and q / beta^l > 0; anything else is
+ * FHE_E_INVALID (the reference panics there in every build).  The same ranges hold for key switching. */
 int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, const void *d_a, void *d_out, size_t rows, void *hip_stream);
 
 /* ---- misc ---------------------------------------------------------------- */
@@ -359,8 +368,13 @@ int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, cons
 int fhe_shard_range(size_t total, unsigned world, unsigned rank, size_t *begin, size_t *end);
 
 /* Library workspaces are kept per (device, stream) until fhe_ntt_shutdown(); a caller about to destroy a stream
- * returns that stream's workspaces with this call (it synchronises the stream first). */
+ * returns that stream's workspaces — every one of them, whatever entry point took it — with this call (it
+ * synchronises the stream first).  Workspaces of hipStreamPerThread, which the host-buffer entry points use, are
+ * keyed by the calling THREAD as well: a thread that used those entry points (or passed hipStreamPerThread) should
+ * call fhe_ntt_release_stream_workspace(hipStreamPerThread) before it exits, or its buffers stay until shutdown. */
 int fhe_ntt_release_stream_workspace(void *hip_stream);
+/* bytes of library workspace currently held, over all devices, streams and threads (diagnostic) */
+size_t fhe_ntt_workspace_bytes(void);
 
 int fhe_ntt_device_count(void);            /* HIP devices visible (0 if none) */
 const char *fhe_last_error(void);          /* thread-local, never NULL */

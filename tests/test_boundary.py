@@ -161,7 +161,16 @@ def test_next_row_entry_points_validate_before_touching_the_gpu(pkg):
     assert L.fhe_glwe_ksk_prepared_words(None, 1, 2, 4) == 0
     assert L.fhe_glwe_ksk_prepared_words(plan.handle, 0, 2, 4) == 0
     big = pkg.Plan(Q61, 4096)
-    assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 2, 61) == 2 * 61 * 2 * 4096       # two-small-prime form: twice the key
+    # arguments fhe_glwe_ksk_prepare_dev rejects have no prepared form: 0 words, and no error string is set
+    L.fhe_ntt_plan_prepare(None)                                                          # leaves "plan is NULL" behind
+    before = L.fhe_last_error()
+    assert L.fhe_glwe_ksk_prepared_words(pkg.Plan(Q16, 8).handle, 1, 4, 9) == 0            # 4^9 > q: divisor 0 (zq.rs:164-165)
+    assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 2, 65) == 0                        # beta = 2: l <= 64
+    assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 70000, 2) == 0                     # beta^l overflows u32
+    assert L.fhe_last_error() == before
+    # the two-small-prime form exists unless FHE_EXT32=0 (read once per process): twice the key, or the key's size
+    ext32 = os.environ.get("FHE_EXT32", "1")[:1] != "0"
+    assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 2, 61) == (2 if ext32 else 1) * 61 * 2 * 4096
     assert L.fhe_glwe_ksk_prepared_words(big.handle, 2, 2, 61) == 2 * 61 * 3 * 4096       # k = 2: transforms modulo q
     assert L.fhe_glwe_ksk_prepared_words(big.handle, 1, 4, 8) == 8 * 2 * 4096
     assert L.fhe_glwe_ksk_prepare_dev(None, 1, 2, 4, d, d, None) == B.FHE_E_NULL

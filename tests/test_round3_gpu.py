@@ -91,6 +91,37 @@ def test_five_multiply_product_identity_and_bounds():
         assert 8 * q <= 1 << 64
 
 
+def test_variable_times_variable_on_the_same_product():
+    """zip_eq(l,r).map(l*r) (ring_nq.rs:601-604) with the multiplier's second table word formed on the fly
+    (zq_device.hpp: pm_shift32): exact for every multiplicand below 7.9 q and every multiplier below 2^k, and the
+    double reduction lands strictly below 2^k"""
+    from fhe_study_amd.arith import pm_params
+
+    rnd = random.Random(0xF4E5_0301)
+    for q, k in PM_PRIMES:
+        p = pm_params(q)
+
+        def red(x):
+            x1 = x >> 32
+            return (x1 >> p["rsh"]) * p["delta"] + (((x1 & p["rmask"]) << 32) | (x & 0xFFFFFFFF))
+
+        amax = min((1 << 64) - 1, (127 * q) // 16)
+        As = [0, 1, q - 1, q, amax, (113 * q) // 16] + [rnd.randrange(amax + 1) for _ in range(200)]
+        Bs = [0, 1, q - 1, q, (1 << k) - 1, (1 << (k - 32)) - 1, 1 << (k - 32)] + [rnd.randrange(1 << k) for _ in range(200)]
+        for a in As:
+            for b in Bs[:7] + rnd.sample(Bs[7:], 10):
+                wh = ((b >> 32 << 32 | (b & 0xFFFFFFFF)) >> p["rsh"]) & 0xFFFFFFFF
+                assert wh == b >> p["rsh"]                                   # fits 32 bits for b < 2^k
+                w2 = wh * p["delta"] + (((b & 0xFFFFFFFF) & p["rmask"]) << 32)
+                assert w2 % q == (b << 32) % q and w2 < (1 << k) + (1 << (k - 7))
+                r = _mul_pm(a, b, w2, p)                                      # asserts T >> (k+1) < 2^32 inside
+                assert r % q == (a * b) % q and 16 * r < 33 * q
+        for x in [0, (1 << 64) - 1, 8 * q - 1 if 8 * q <= 1 << 64 else (1 << 64) - 1, (1 << k) - 1, 1 << k, (1 << k) + 7 * p["delta"]] + \
+                 [rnd.getrandbits(64) for _ in range(500)]:
+            y = red(red(x))
+            assert y % q == x % q and y < 1 << k
+
+
 def test_round_schedules_never_pass_the_cap():
     """the compile-time schedules of ntt_rounds.hpp restated: forward bounds per stage, inverse per register"""
     CAP, MUL, RED, ONE = 128, 33, 17, 16
@@ -282,3 +313,74 @@ def test_default_line_is_the_headline_configuration(pkg, need_gpu):
     assert out["config"]["q"] == Q61 and out["config"]["n"] == 65536 and out["config"]["arithmetic"] == "pseudo-mersenne"
     assert out["scaling"] == "strong" and out["parity"]["mismatching_rows"] == 0
     assert out["roofline"]["step_frac"] > 0.2
+
+
+# ---- advisor findings of round 2 ------------------------------------------------------------------------------------------
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q,sizes", [(0x0a3c8001, (4096, 8192, 16384)), (0x0a320001, (1024, 65536))])
+def test_small_modulus_kernels_at_the_top_of_their_range(pkg, oracle, need_gpu, q, sizes):
+    """smallq.hip admits q with 25 q < 2^32; its value bounds (25 q after twelve loose stages, the reduction points
+    of the big transforms, 4 q^2 < q 2^32 in the Montgomery product) are tight only at the top of that range:
+    25 * 0x0a3c8001 = 2^32 - 1.5 M.  Forward, inverse and the product with every evals combination, on inputs that
+    maximise the redundant representation."""
+    assert 25 * q < 1 << 32
+    for n in sizes:
+        assert (q - 1) % (2 * n) == 0
+        a = _extreme_rows(oracle, q, n, 4000 + n)
+        b = a[::-1].copy()
+        plan = pkg.Plan(q, n)
+        assert plan.arithmetic() == (3 if os.environ.get("FHE_EXT32", "1")[:1] != "0" else 1)
+        A = plan.forward(a)
+        assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (q, n)
+        want = oracle.rq_mul(q, n, a, b)
+        ae, be = want[2], want[3]
+        for got in (plan.rq_mul(a, b), plan.rq_mul(ae, b, a_is_evals=True), plan.rq_mul(a, be, b_is_evals=True),
+                    plan.rq_mul(ae, be, a_is_evals=True, b_is_evals=True)):
+            assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, want)), (q, n)
+
+
+@pytest.mark.gpu
+def test_release_stream_workspace_frees_every_slot(pkg, oracle, need_gpu):
+    """the small-modulus two-pass sizes keep their u32 intermediates in a library workspace of their own slot;
+    fhe_ntt_release_stream_workspace must hand that one back too (it used to free slots 0 and 1 only)"""
+    import torch
+
+    B, L = pkg.binding, pkg.load_library()
+    q, n, batch = 786433, 65536, 6
+    plan = pkg.Plan(q, n)
+    a = oracle.fill_synthetic(q, 11, 0, batch * n)
+    want = oracle.ntt(q, n, a)
+    s1 = torch.cuda.Stream()
+    held0 = L.fhe_ntt_workspace_bytes()
+    x = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    y = torch.empty_like(x)
+    c = torch.empty_like(x)
+    torch.cuda.synchronize()
+    plan.forward_dev(x.data_ptr(), y.data_ptr(), batch, s1.cuda_stream)
+    B._check(L.fhe_rq_mul_dev(plan.handle, x.data_ptr(), 0, x.data_ptr(), 0, c.data_ptr(), None, None, None, batch, None, s1.cuda_stream))
+    s1.synchronize()
+    assert np.array_equal(y.cpu().numpy().view(np.uint64), want)
+    held1 = L.fhe_ntt_workspace_bytes()
+    if plan.arithmetic() == 3:
+        assert held1 >= held0 + batch * n * 4            # at least the u32 intermediate of the transform
+    assert held1 > held0
+    B._check(L.fhe_ntt_release_stream_workspace(s1.cuda_stream))
+    assert L.fhe_ntt_workspace_bytes() == held0          # everything this stream took, whatever the slot
+    plan.forward_dev(x.data_ptr(), y.data_ptr(), batch, s1.cuda_stream)      # and the stream is still usable
+    s1.synchronize()
+    assert np.array_equal(y.cpu().numpy().view(np.uint64), want)
+    B._check(L.fhe_ntt_release_stream_workspace(s1.cuda_stream))
+
+
+def test_version_string_and_ablation_guard(pkg):
+    """a production build never reports ABLATED; the binding refuses a library that does (tools/abl_build.sh) unless
+    FHE_NTT_ALLOW_ABLATED=1 — checked on the loader's own logic, no second library needed"""
+    v = pkg.load_library().fhe_ntt_version()
+    assert v.startswith(b"fhe_ntt") and b"ABLATED" not in v
+    import inspect
+
+    src = inspect.getsource(pkg.binding.load_library)
+    assert "ABLATED" in src and "FHE_NTT_ALLOW_ABLATED" in src

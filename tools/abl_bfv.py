@@ -2,6 +2,8 @@
 """tools/abl_bfv.py — per-kernel times of 2048 BFV ciphertext products (N=8192, q=65537, p=q^2) through whatever build of the
 library FHE_NTT_LIB points to (timing-only builds of tools/abl_build.sh give wrong words by design); FHE_EXT32=0: 61-bit kernels."""
 import os, sys
+
+os.environ.setdefault("FHE_NTT_ALLOW_ABLATED", "1")   # these tools load timing-only builds on purpose (binding.load_library)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fhe_study_amd as pkg

@@ -3,6 +3,8 @@
 FHE_NTT_LIB points to.  Used with the timing-only builds of digit_mac.hip (-DFHE_DM_ABLATE_MAC / -DFHE_DM_ABLATE_NTT:
 the fused kernel without its multiply phase / without its transform) to split the kernel's time; numbers in digit_mac.hip."""
 import os, sys
+
+os.environ.setdefault("FHE_NTT_ALLOW_ABLATED", "1")   # these tools load timing-only builds on purpose (binding.load_library)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fhe_study_amd as pkg

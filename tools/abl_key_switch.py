@@ -2,6 +2,8 @@
 """tools/abl_key_switch.py — per-kernel times of 256 key switches (N=4096, k=1, l=61, base 2) through whatever build of
 the library FHE_NTT_LIB points to; FHE_EXT32=0 selects the 61-bit kernels."""
 import os, sys
+
+os.environ.setdefault("FHE_NTT_ALLOW_ABLATED", "1")   # these tools load timing-only builds on purpose (binding.load_library)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fhe_study_amd as pkg

@@ -7,6 +7,8 @@
 --loop   restrict to the innermost backward-branch loop (micro-benchmarks); default = whole kernel
 --per N  also print every count divided by N (e.g. butterflies per thread: 8 stages x 8 = 64)
 --dump   print the instructions themselves after the histogram
+--split-asm  two histograms: the instructions inside inline-asm statements (the hand-written butterfly cores, bracketed
+         by ;;#ASMSTART / ;;#ASMEND in a -S listing) and everything the compiler wrote around them
 """
 import re
 import sys
@@ -52,6 +54,9 @@ def kernel_body(lines, needle):
         if t.startswith("s_endpgm"):
             body.append(t)
             break
+        if t.startswith(";;#ASMSTART") or t.startswith(";;#ASMEND"):
+            body.append(t[2:].split()[0])           # "#ASMSTART" / "#ASMEND" markers (kept for --split-asm)
+            continue
         if not t or t.startswith(";") or t.startswith("//"):
             continue
         if t.startswith(".") and not re.match(r"^\.LBB\d+_\d+:", t):
@@ -82,6 +87,32 @@ def innermost_loop(body):
     return body[best[0]:best[1] + 1]
 
 
+def histogram(title, ins, per, dump_ops=True):
+    hist = Counter()
+    for l in ins:
+        op = l.split()[0]
+        for cname, pat in CLASSES:
+            if re.match(pat, op):
+                hist[cname] += 1
+                break
+        else:
+            hist["(unclassified) " + op] += 1
+    valu = sum(v for k, v in hist.items() if k in {c for c, p in CLASSES if p.startswith("^v_") or "v_" in p})
+    print(f"{title}: {len(ins)} instructions, VALU {valu}")
+    for cname, _ in CLASSES:
+        if hist[cname]:
+            extra = f"   {hist[cname] / per:7.2f} per unit" if per else ""
+            print(f"  {cname:32s} {hist[cname]:6d}{extra}")
+    for k, v in hist.items():
+        if k.startswith("(unclassified)"):
+            print(f"  {k:32s} {v:6d}")
+    if per:
+        print(f"  {'VALU total':32s} {valu:6d}   {valu / per:7.2f} per unit")
+    if dump_ops:
+        ops = Counter(l.split()[0] for l in ins)
+        print("  opcodes " + ", ".join(f"{k} {v}" for k, v in ops.most_common()))
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     flags = [a for a in sys.argv[1:] if a.startswith("--")]
@@ -94,30 +125,24 @@ def main():
     name, body = kernel_body(lines, needle)
     if "--loop" in flags:
         body = innermost_loop(body)
-    ins = [l for l in body if not re.match(r"^\.LBB", l)]
-    hist = Counter()
-    for l in ins:
-        op = l.split()[0]
-        for cname, pat in CLASSES:
-            if re.match(pat, op):
-                hist[cname] += 1
-                break
-        else:
-            hist["(unclassified) " + op] += 1
-    valu = sum(v for k, v in hist.items() if k in {c for c, p in CLASSES if p.startswith("^v_") or "v_" in p})
+    ins, inside, outside, in_asm = [], [], [], False
+    for l in body:
+        if l == "#ASMSTART":
+            in_asm = True
+            continue
+        if l == "#ASMEND":
+            in_asm = False
+            continue
+        if re.match(r"^\.LBB", l):
+            continue
+        ins.append(l)
+        (inside if in_asm else outside).append(l)
     print(f"kernel  {name}")
-    print(f"scope   {'innermost loop' if '--loop' in flags else 'whole kernel'}: {len(ins)} instructions, VALU {valu}")
-    for cname, _ in CLASSES:
-        if hist[cname]:
-            extra = f"   {hist[cname] / per:7.2f} per unit" if per else ""
-            print(f"  {cname:32s} {hist[cname]:6d}{extra}")
-    for k, v in hist.items():
-        if k.startswith("(unclassified)"):
-            print(f"  {k:32s} {v:6d}")
-    if per:
-        print(f"  {'VALU total':32s} {valu:6d}   {valu / per:7.2f} per unit")
-    ops = Counter(l.split()[0] for l in ins)
-    print("opcodes " + ", ".join(f"{k} {v}" for k, v in ops.most_common()))
+    histogram(f"scope   {'innermost loop' if '--loop' in flags else 'whole kernel'}", ins, per)
+    if "--split-asm" in flags:
+        histogram("  -- inside inline asm (butterfly cores)", inside, per, False)
+        histogram("  -- compiler-generated (addressing, exchanges, reductions, canonicalisation, control)", outside, per, False)
+    body = [l for l in body if l not in ("#ASMSTART", "#ASMEND")]
     if "--dump" in flags:
         print("\n".join(body))
 

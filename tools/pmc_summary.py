@@ -8,10 +8,11 @@ Counter units are KiB; on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes 
 import csv, glob, json, os, re, sys
 
 NAMES = [  # (regex on the rocprofv3 kernel name, name used by the library's kernel timer)
-    (r"ntt_fwd_strided_kernel<8, 32, true(, false)?>", "ntt_fwd_strided_8"),
-    (r"ntt_fwd_contig_kernel<8, true, true(, 0)?>", "ntt_fwd_contig_final_8"),
-    (r"ntt_inv_contig_kernel<8, false, false>", "ntt_inv_contig_8"),
-    (r"ntt_inv_strided_kernel<8, 32>", "ntt_inv_strided_8"),
+    # the third template argument is the arithmetic (round 3: 0 / 1 / 2 = Shoup62 / Shoup61 / pseudo-Mersenne; `true` before)
+    (r"ntt_fwd_strided_kernel<8, 32, (true|[012])(, false)?>", "ntt_fwd_strided_8"),
+    (r"ntt_fwd_contig_kernel<8, true, (true|[012])(, 0)?>", "ntt_fwd_contig_final_8"),
+    (r"ntt_inv_contig_kernel<8, false, false(, [012])?>", "ntt_inv_contig_8"),
+    (r"ntt_inv_strided_kernel<8, 32(, [012])?>", "ntt_inv_strided_8"),
 ]
 
 

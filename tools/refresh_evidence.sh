@@ -1,11 +1,11 @@
 #!/bin/bash
 # tools/refresh_evidence.sh <tag> — regenerate the measured evidence in one GPU-box call:
-#   /usr/local/graft/bin/gpurun --timeout 1190 -- 'bash tools/refresh_evidence.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 1190 -- 'bash tools/refresh_evidence.sh r03'
 # Writes everything under gpurun_out/evid_<tag>/; the summaries the judge reads are copied into profiles/ by
 # `bash tools/refresh_evidence.sh <tag> collect` run afterwards in the repo (no GPU needed).
 # Steps are joined so that a failed or killed GPU step stops the script.
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/evid_$TAG
 if [ "$2" = "collect" ]; then
   cp $OUT/bench.json profiles/${TAG}_bench.json
@@ -22,6 +22,10 @@ if [ "$2" = "collect" ]; then
   cp $OUT/bfv_kernels.txt profiles/${TAG}_bfv_kernels.txt
   grep FHE_EXT32 $OUT/smallq.txt > profiles/${TAG}_small_modulus.txt
   cp $OUT/bench_2ranks.json profiles/${TAG}_bench_2ranks_one_gpu.json 2>/dev/null || true
+  cp $OUT/bench_rccl_world1.json profiles/${TAG}_bench_rccl_world1.json 2>/dev/null || true
+  cp $OUT/bench_pm0.json profiles/${TAG}_bench_shoup_kernels.json 2>/dev/null || true
+  cp $OUT/isa_counters_a.json profiles/${TAG}_isa_counters_a.json 2>/dev/null || true
+  cp $OUT/isa_counters_b.json profiles/${TAG}_isa_counters_b.json 2>/dev/null || true
   sed -i '/amdgpu.ids/d' profiles/${TAG}_*.txt
   exit 0
 fi
@@ -39,9 +43,21 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write 65536 $OUT/${TAG}_pmc_traffic.json > $OUT/pmc_summary.txt
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json     # bench.py reads it from profiles/
 
+echo "[2b] dynamic instruction counters of the pass kernels (beside profiles/<tag>_isa_*.txt)"; date
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_isa_a -o runc --output-format csv -- python3 $B > $OUT/pmc_isa_a.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $OUT/pmc_isa_b -o runc --output-format csv -- python3 $B > $OUT/pmc_isa_b.log 2>&1
+python3 tools/pmc_isa.py $OUT/pmc_isa_a $OUT/isa_counters_a.json | grep -E "ntt_(fwd|inv)" || true
+python3 tools/pmc_isa.py $OUT/pmc_isa_b $OUT/isa_counters_b.json | grep -E "ntt_(fwd|inv)" || true
+
 echo "[3/7] bench.py (contract run)"; date
 timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
+
+FHE_PM=0 timeout -k 10 600 python bench.py --no-cpu-baseline > $OUT/bench_pm0.json 2> $OUT/bench_pm0.err    # the Shoup kernels on the same box
+python3 -c "
+import json
+a=json.loads([l for l in open('$OUT/bench.json') if l.startswith('{')][-1]); b=json.loads([l for l in open('$OUT/bench_pm0.json') if l.startswith('{')][-1])
+print('pseudo-Mersenne', round(a['value']), 'NTT/s step_frac', round(a['roofline']['step_frac'],4), '| Shoup kernels (FHE_PM=0)', round(b['value']), round(b['roofline']['step_frac'],4))"
 
 echo "[4/7] rocprofv3 --kernel-trace --stats of the same command"; date
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o runc --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
@@ -70,8 +86,12 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc4_write -
 cat $OUT/config4_pmc_traffic.txt
 
 echo "[6/7] two ranks on one GPU (gloo rendezvous): the multi-rank driver"; date
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --share-gpu --backend gloo --batch-per-gpu 2048 --no-cpu-baseline --parity-all-ranks --gather-check > $OUT/bench_2ranks.json 2> $OUT/bench_2ranks.err || tail -5 $OUT/bench_2ranks.err
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --share-gpu --backend gloo --global-batch 4096 --no-cpu-baseline --parity-all-ranks --gather-check --allgather > $OUT/bench_2ranks.json 2> $OUT/bench_2ranks.err || tail -5 $OUT/bench_2ranks.err
 tail -1 $OUT/bench_2ranks.json | cut -c1-300
+
+echo "[6b] ONE rank through RCCL (world size 1): process group, barrier, MAX all-reduce, all-gather of the real shard"; date
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --steps 3 --warmup 1 --backend nccl --force-dist --allgather --batch-per-gpu 2048 --no-cpu-baseline > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err || tail -5 $OUT/bench_rccl_world1.err
+tail -1 $OUT/bench_rccl_world1.json | python3 -c "import json,sys; o=json.loads(sys.stdin.read()); print(o.get('distributed'), o.get('allgather'))" || true
 
 echo "[7/7] inverse / other sizes / product / next rows (diagnostic)"; date
 timeout -k 10 300 python tools/kbench.py 16 16384 0 > $OUT/kbench_16.txt 2>&1
@@ -85,6 +105,6 @@ FHE_EXT32=0 timeout -k 10 200 python tools/smallq_bench.py >> $OUT/smallq.txt 2>
 timeout -k 10 100 python tools/abl_bfv.py > $OUT/bfv_kernels.txt 2>&1 || true
 FHE_EXT32=0 timeout -k 10 100 python tools/abl_bfv.py >> $OUT/bfv_kernels.txt 2>&1 || true
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt
-rm -rf $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc4_*/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true
+rm -rf $OUT/pmc_isa_*/*/*.db $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc4_*/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true
 find $OUT -name "*.db" -delete 2>/dev/null || true
 date

@@ -38,88 +38,152 @@ __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
     return (u64)rA + (u64)pA * h;
 }
 
-template <int LP>
-__device__ __forceinline__ void stage_all(Tw32 *(&ltw)[3], unsigned char *base, const Tw32 *const (&tw)[3], u32 tid) {
-    using C = Big32<LP>;
-#pragma unroll
-    for (int pr = 0; pr < 3; pr++) {
-        ltw[pr] = reinterpret_cast<Tw32 *>(base + pr * C::TW_BYTES);
-        stage_tw32<C::TH>(ltw[pr], tw[pr], C::LTW_N, tid);
-    }
+// ---- the 2n-point transform of a zero-padded row as TWO n-point blocks (round 3) ------------------------------------------
+// Stage 0 of the 2n-point forward transform pairs x[j] with the padding — x + w 0 and x - w 0: both halves start as x —
+// and stages 1 .. L-1 never mix the halves: the transform IS block 0 and block 1 (s0 = 1: ntt32_big.hpp) of the same n
+// words.  Likewise the inverse: stages L-1 .. 1 act inside the halves and only the last one (roots_inv[1]) pairs point j of
+// half 0 with point j of half 1 — coefficients j and j + n of the 2n-word product, exactly the pair the epilogues need
+// together (scale, round, X^n+1 fold).  So a workgroup is n / 16 threads (512 at n = 8192) around a 34 KiB tile instead
+// of 1024 around 68 KiB, and a CU holds two of them (128 registers): one computes while the other waits at a barrier or
+// for its loads.  Until round 2 one 1024-thread workgroup per CU left every load phase and barrier exposed (2048
+// products: 2.75 ms).
+// how the block kernels run their inverse rounds (shape experiments: -DFHE_B32_INV_T=.. / -DFHE_B32_INV_R=..):
+// 0 = twiddles preloaded ahead of the exchanges (inv_big), 1 = read as they go (inv_big_direct), 2 = the same, one stage at a time
+#ifndef FHE_B32_INV_T
+#define FHE_B32_INV_T 2          // tensor
+#endif
+#ifndef FHE_B32_INV_R
+#define FHE_B32_INV_R 1          // relinearisation (measured, 2048 pairs at n = 8192: 937 / 897 / 1019 us for 0 / 1 / 2; tensor 863 / 898 / 853)
+#endif
+template <int MODE, int LB>
+__device__ __forceinline__ void inv_block(u32 (&v)[1][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 blk) {
+    if constexpr (MODE == 0) inv_big<LB>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
+    else if constexpr (MODE == 1) inv_big_direct<LB, false>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
+    else inv_big_direct<LB, true>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
 }
+template <int LB>
+struct Blk {
+    using C = Big32<LB>;                                        // the n-point block: VT = 1, TH = n / 16 threads
+    static constexpr u32 M = C::M, TH = C::TH;
+    static constexpr size_t LDS(int tables) { return C::TILE_BYTES + (size_t)tables * C::TW_BYTES; }
+    static __device__ __forceinline__ Tw32 *table(unsigned char *smem, int i) { return reinterpret_cast<Tw32 *>(smem + C::TILE_BYTES + i * C::TW_BYTES); }
+};
 
-// ---- forward: row r of n words, zero-padded to 2n, modulo the first NPR primes ----------------------------------------
-// WORD32: the source words are below 2^32 (ciphertext words modulo a q that small): reduced in one word
-template <int LP, int NPR, bool WORD32>
-__global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_forward_kernel(Bfv32Args a) {
-    using C = Big32<LP>;
+// ---- forward: row r of n words -> both blocks of its 2n-point transform, modulo the first NPR primes --------------------
+// WORD32: the source words are below 2^32 (ciphertext words modulo a q that small): reduced in one word.
+// Workgroup ids 16 g + 8 blk + (row % 8): the two blocks of a row read the same words through ONE XCD's L2.
+template <int LB, int NPR, bool WORD32>
+__global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_forward_kernel(Bfv32Args a) {
+    using C = Big32<LB>;
+    using K = Blk<LB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32 *lds = reinterpret_cast<u32 *>(smem_raw);
-    Tw32 *ltw[3];
     const u32 tf = threadIdx.x;
-    stage_all<LP>(ltw, smem_raw + C::TILE_BYTES, a.t.tw_fwd, tf);
-    const u64 row = blockIdx.x;
-    const u32 n = C::M / 2;
-    const u64 *__restrict__ src = a.src + row * n;
-    // window [LP-4, LP): register k of logical thread t = point k * (M / 16) + t; k >= 8 is the zero padding
-    u64 x[C::VT][8];
+    const u64 g8 = blockIdx.x / 16;
+    const u32 r16 = blockIdx.x % 16;
+    const u64 row = g8 * 8 + (r16 & 7u);
+    const u32 blk = r16 >> 3;
+    if (row >= a.rows) return;                                  // padding of the last group (before any barrier)
+    // NPR == 1: prime blockIdx.y of this row (the relinearisation key: two rows, so three workgroups per block instead of
+    // three transforms in turn)
 #pragma unroll
-    for (int s = 0; s < C::VT; s++)
+    for (int i = 0; i < NPR; i++) stage_tw32_block<C::TH>(K::table(smem_raw, i), a.t.tw_fwd[NPR == 1 ? blockIdx.y : i], C::LTW_N, tf, 1u, blk);
+    const u64 *__restrict__ src = a.src + row * K::M;
+    u64 x[16];                                                  // window [LB-4, LB): register k = word k * TH + tf
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[s][k] = src[(u32)k * (C::VT * C::TH) + tf + s * C::TH];
+    for (int k = 0; k < 16; k++) x[k] = src[(u32)k * C::TH + tf];
     __syncthreads();                                            // the twiddle tiles
-    // NPR == 1: prime blockIdx.y of this row (the relinearisation key: two rows, so three workgroups each instead of three
-    // transforms in turn)
 #pragma unroll
     for (int i = 0; i < NPR; i++) {
         const u32 pr = NPR == 1 ? blockIdx.y : (u32)i;
         const u32 p = a.t.p[pr], p2 = 2u * p;
-        const Tw32 *lt = reinterpret_cast<const Tw32 *>(smem_raw + C::TILE_BYTES + pr * C::TW_BYTES);
-        u32 v[C::VT][16];
+        u32 v[1][16];
 #pragma unroll
-        for (int s = 0; s < C::VT; s++)
+        for (int k = 0; k < 16; k++)
+            v[0][k] = WORD32 ? csub_u32(barrett2p_32((u32)x[k], p, a.t.bq[pr]), p) : reduce64_32(x[k], p, a.t.mu[pr]);
+        fwd_big<LB, 0, 1>(v, lds, K::table(smem_raw, i), a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr], 1u, blk);
+        // stored order (internal to this file): quad j of logical thread t at j * (M / 4) + 4 t of its block — a wave's
+        // 16-byte accesses are contiguous (with the natural 16 t + 4 j every access would touch a quarter of each line)
+        u32 *__restrict__ dst = a.fw + (((u64)pr * a.rows + row) << (LB + 1)) + blk * K::M + tf * 4u;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                v[s][k] = WORD32 ? csub_u32(barrett2p_32((u32)x[s][k], p, a.t.bq[pr]), p) : reduce64_32(x[s][k], p, a.t.mu[pr]);
-                v[s][k + 8] = v[s][k];                          // stage 0 against zeros: x + w * 0 and x - w * 0
-            }
-        fwd_big<LP, 1>(v, lds, lt, a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr]);
-#pragma unroll
-        for (int s = 0; s < C::VT; s++) {
-            // stored order (internal to this file): quad j of logical thread t at j * (M / 4) + 4 t — a wave's 16-byte
-            // accesses are contiguous (with the natural 16 t + 4 j every access would touch a quarter of each 64-byte line)
-            u32 *__restrict__ dst = a.fw + (((u64)pr * a.rows + row) << LP) + (tf + s * C::TH) * 4u;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint4 o;
-                o.x = barrett2p_32(v[s][4 * j], p, a.t.bq[pr]); o.y = barrett2p_32(v[s][4 * j + 1], p, a.t.bq[pr]);
-                o.z = barrett2p_32(v[s][4 * j + 2], p, a.t.bq[pr]); o.w = barrett2p_32(v[s][4 * j + 3], p, a.t.bq[pr]);
-                *reinterpret_cast<uint4 *>(dst + j * (C::M / 4)) = o;    // below 2p: a product of two such is below p * 2^32
-            }
+        for (int j = 0; j < 4; j++) {
+            uint4 o;
+            o.x = barrett2p_32(v[0][4 * j], p, a.t.bq[pr]); o.y = barrett2p_32(v[0][4 * j + 1], p, a.t.bq[pr]);
+            o.z = barrett2p_32(v[0][4 * j + 2], p, a.t.bq[pr]); o.w = barrett2p_32(v[0][4 * j + 3], p, a.t.bq[pr]);
+            *reinterpret_cast<uint4 *>(dst + j * (K::M / 4)) = o;    // below 2p: a product of two such is below p * 2^32
         }
     }
 }
 
-// the 16 transform values of a logical thread: src = row + 4 t, quads M / 4 apart (the forward kernel's stored order)
-template <int LP>
+// the 16 transform values of a logical thread: src = block + 4 t, quads M / 4 apart (the forward kernel's stored order)
+template <int LB>
 __device__ __forceinline__ void load16(u32 (&v)[16], const u32 *__restrict__ src) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(src + j * (Big32<LP>::M / 4));
+        const uint4 x = *reinterpret_cast<const uint4 *>(src + j * (Big32<LB>::M / 4));
         v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
     }
 }
+// the inverse's LAST stage (roots_inv[1]) on the two blocks' results, with the scaling by (2n)^-1 (and the Montgomery
+// factor of the products): register k of logical thread t -> coefficients j = k * TH + t (lo) and j + n (hi), canonical
+__device__ __forceinline__ void last_stage(u32 &lo, u32 &hi, Tw32 w1, Tw32 ni, u32 p, u32 p2) {
+    gs32(lo, hi, w1, p, p2);
+    lo = csub_u32(mul_shoup32(lo, ni, p), p);
+    hi = csub_u32(mul_shoup32(hi, ni, p), p);
+}
+
+// Zq::from_f64(round(num * v / q)) — ring_n.rs:130-138 (mul_div_round), ring_nq.rs:160-163, zq.rs:32-39 — for an integer
+// v >= 0 with N = num * v < 2^52, WITHOUT f64.  Why it is the same number: in f64 the product num * v is exact (< 2^53);
+// the quotient fl(N / q) has absolute error below (N / q) 2^-53 < 1 / (2q); the exact quotient k + f / q (f = N mod q) is
+// either ON a half-integer (2f = q: fl is exact there and `round` goes away from zero) or at least 1 / (2q) away from
+// every half-integer, and fl cannot land on one it is not on (half an ulp below 2^52 is smaller than that distance).  So
+// round(fl(N / q)) = a + [2f >= q] with a = N div q, which `as i64` keeps and Zq::from_f64 reduces modulo q.
+// mu = floor((2^64 - 1) / q): the quotient estimates are short by at most two.  The f64 form costs ~150 instructions
+// per coefficient (IEEE division), this one ~35.  (The relinearisation's R / p is NOT in this regime — |R| reaches 2^63,
+// the f64 quotient's error reaches past the nearest half-integer — and keeps the f64 form.)
+__device__ __forceinline__ u64 zq_scale_round_int(u64 N, u64 q, u64 mu) {
+    u64 a = __umul64hi(N, mu);
+    u64 f = N - a * q;
+    if (f >= q) { f -= q; a += 1; }
+    if (f >= q) { f -= q; a += 1; }
+    a += (2 * f >= q);
+    u64 r = a - __umul64hi(a, mu) * q;
+    r = r >= q ? r - q : r;
+    return r >= q ? r - q : r;
+}
+
+// Zq::from_f64 (zq.rs:32-39: round, `as i64`, ((e % q) + q) % q) for |ef| < 2^50 and q < 2^31, entirely in f64 — full
+// rate on this chip.  The general form (zq_from_f64_mu) goes through a saturating f64 -> i64 conversion and a 64-bit
+// remainder: ~90 instructions of the ~150 an epilogue spends per coefficient.  Here e = round(ef) is an exact integer,
+// k = rint(e * fl(1/q)) is within one of the true quotient, r = e - k q is exact (one fma: |k q| < 2^52) and within
+// (-3q/2, 3q/2): two conditional additions and a subtraction bring it to [0, q).  The same integer modulo q: bit-exact.
+__device__ __forceinline__ u64 zq_from_f64_small(double ef, double qf, double qinv) {
+    const double e = round(ef);
+    const double k = rint(e * qinv);
+    double r = fma(-k, qf, e);
+    r = r < 0.0 ? r + qf : r;
+    r = r < 0.0 ? r + qf : r;
+    r = r >= qf ? r - qf : r;
+    return (u64)(u32)r;
+}
+// the epilogue's Zq::from_f64(round(num * v / den)): SMALL = the f64-only form above (decided on the host)
+template <bool SMALL>
+__device__ __forceinline__ u64 scale_round(const Bfv32Args &a, long long v) {
+    const double x = (a.numf * (double)v) / a.denf;
+    if constexpr (SMALL) return zq_from_f64_small(x, (double)a.q, a.qinvf);
+    else return zq_from_f64_mu(a.q, a.qmu, round(x));
+}
 
 // ---- tensor: products in the load -> inverse (both primes) -> CRT -> scale, round, Z_q, fold ---------------------------
+// INT: the integer form of the epilogue's scale-and-round (a.int_num * v < 2^52 for every coefficient: decided on the host)
 // workgroup = (ciphertext pair b, output polynomial which): c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1 (lib.rs:71-77)
-template <int LP>
-__global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_tensor_inverse_kernel(Bfv32Args a) {
-    using C = Big32<LP>;
+template <int LB, bool INT, bool SMALL>
+__global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kernel(Bfv32Args a) {
+    using C = Big32<LB>;
+    using K = Blk<LB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32 *lds = reinterpret_cast<u32 *>(smem_raw);
-    Tw32 *ltw[3];
     const u32 tf = threadIdx.x;
-    stage_all<LP>(ltw, smem_raw + C::TILE_BYTES, a.t.tw_inv, tf);
     // the three workgroups of a pair read the same four transforms: workgroup ids are dealt round-robin over the 8 XCDs,
     // so ids 24 g + 8 which + (b % 8) put them on ONE XCD (one L2), a few dispatches apart
     const u64 g8 = blockIdx.x / 24;
@@ -127,147 +191,162 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_tensor_inverse_kernel(B
     const u64 b = g8 * 8 + (r24 & 7u);
     const u32 which = r24 >> 3;
     if (b >= a.batch) return;                                   // padding of the last group (before any barrier)
-    const u32 n = C::M / 2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) stage_tw32_block<C::TH>(K::table(smem_raw, i), a.t.tw_inv[i >> 1], C::LTW_N, tf, 1u, (u32)(i & 1));
     __syncthreads();
-    u32 resA[C::VT][16];
-    u64 *__restrict__ po = a.out + ((u64)which * a.batch + b) * n + tf;
-#pragma unroll
-    for (int pr = 0; pr < 2; pr++) {
+    u32 loA[16], hiA[16];
+    u64 *__restrict__ po = a.out + ((u64)which * a.batch + b) * K::M + tf;
+    auto prime = [&](auto prc) __attribute__((always_inline)) {     // a lambda per prime: the loop form is not unrolled by the compiler
+        constexpr int pr = decltype(prc)::value;
         const u32 p = a.t.p[pr], p2 = 2u * p, pn = a.pinv_neg[pr];
-        const u32 *__restrict__ fw = a.fw + (((u64)pr * a.rows) << LP);      // rows: [a0 | a1 | b0 | b1] x batch
-        u32 v[C::VT][16];
+        const u32 *__restrict__ fw = a.fw + (((u64)pr * a.rows) << (LB + 1));      // rows: [a0 | a1 | b0 | b1] x batch
+        auto block = [&](u32 blk, u32 (&v)[1][16]) __attribute__((always_inline)) {
+            const u32 off = blk * K::M + tf * 4u;
+            auto rowp = [&](u32 w) { return fw + (((u64)w * a.batch + b) << (LB + 1)) + off; };
+            // a quad at a time (four 16-byte loads in flight per term), so that the operands of the products are never
+            // all live together: the kernel keeps the first prime's 32 residues across this
+            const u32 *__restrict__ ra = rowp(which == 2 ? 1 : 0), *__restrict__ rb = rowp(which == 0 ? 2 : 3);
+            const u32 *__restrict__ rc = rowp(1), *__restrict__ rd = rowp(2);            // which == 1: + a1 b0
 #pragma unroll
-        for (int s = 0; s < C::VT; s++) {
-            const u32 off = (tf + s * C::TH) * 4u;
-            auto rowp = [&](u32 w) { return fw + (((u64)w * a.batch + b) << LP) + off; };
-            u32 y[16];
-            if (which == 1) {
-                u32 t0[16];
-                load16<LP>(v[s], rowp(0)); load16<LP>(y, rowp(3));
+            for (int j = 0; j < 4; j++) {
+                const uint4 xa = *reinterpret_cast<const uint4 *>(ra + j * (K::M / 4)), xb = *reinterpret_cast<const uint4 *>(rb + j * (K::M / 4));
+                u32 t[4] = {mont32(xa.x, xb.x, p, pn), mont32(xa.y, xb.y, p, pn), mont32(xa.z, xb.z, p, pn), mont32(xa.w, xb.w, p, pn)};
+                if (which == 1) {
+                    const uint4 xc = *reinterpret_cast<const uint4 *>(rc + j * (K::M / 4)), xd = *reinterpret_cast<const uint4 *>(rd + j * (K::M / 4));
+                    t[0] = csub_u32(t[0] + mont32(xc.x, xd.x, p, pn), p2); t[1] = csub_u32(t[1] + mont32(xc.y, xd.y, p, pn), p2);
+                    t[2] = csub_u32(t[2] + mont32(xc.z, xd.z, p, pn), p2); t[3] = csub_u32(t[3] + mont32(xc.w, xd.w, p, pn), p2);
+                }
+                v[0][4 * j] = t[0]; v[0][4 * j + 1] = t[1]; v[0][4 * j + 2] = t[2]; v[0][4 * j + 3] = t[3];
+            }
+#ifndef FHE_B32_ABLATE_INV      // timing-only builds (tools/abl_build.sh): the kernels without their transforms / their f64 epilogues
+            inv_block<FHE_B32_INV_T, LB>(v, lds, K::table(smem_raw, 2 * pr + (int)blk), a.t.tw_inv[pr], tf, p, p2, blk);
+#endif
+        };
+        u32 v0[1][16], v1[1][16];
+        block(0u, v0);
+        block(1u, v1);
+        const Tw32 ni = a.ninv_mont[pr], w1 = a.t.tw_inv[pr][1];
 #pragma unroll
-                for (int k = 0; k < 16; k++) t0[k] = mont32(v[s][k], y[k], p, pn);
-                load16<LP>(v[s], rowp(1)); load16<LP>(y, rowp(2));
-#pragma unroll
-                for (int k = 0; k < 16; k++) v[s][k] = csub_u32(t0[k] + mont32(v[s][k], y[k], p, pn), p2);
+        for (int k = 0; k < 16; k++) {
+            u32 rl = v0[0][k], rh = v1[0][k];
+            last_stage(rl, rh, w1, ni, p, p2);
+            if constexpr (pr == 0) {
+                loA[k] = rl; hiA[k] = rh;
             } else {
-                load16<LP>(v[s], rowp(which == 0 ? 0 : 1)); load16<LP>(y, rowp(which == 0 ? 2 : 3));
-#pragma unroll
-                for (int k = 0; k < 16; k++) v[s][k] = mont32(v[s][k], y[k], p, pn);
+                // coefficients j and j + n of the 2n-word convolution — the pair the X^n+1 fold subtracts (ring_nq.rs:132-141);
+                // mul_div_round (ring_n.rs:130-138) + Rq::from_vec_f64 (ring_nq.rs:160-163)
+                const long long lo = (long long)crt2(loA[k], rl, a.t.p[0], a.t.p[1], a.t.crt);
+                const long long hi = (long long)crt2(hiA[k], rh, a.t.p[0], a.t.p[1], a.t.crt);
+#ifndef FHE_B32_ABLATE_EPI
+                u64 zl, zh;
+                if constexpr (INT) {
+                    zl = zq_scale_round_int(a.int_num * (u64)lo, a.q, a.qmu);
+                    zh = zq_scale_round_int(a.int_num * (u64)hi, a.q, a.qmu);
+                } else {
+                    zl = scale_round<SMALL>(a, lo);
+                    zh = scale_round<SMALL>(a, hi);    // slot 2n-1 of a (2n-1)-term convolution is 0
+                }
+#else
+                const u64 zl = (u64)lo, zh = (u64)hi;
+#endif
+                po[(u32)k * C::TH] = zl >= zh ? zl - zh : (a.q + zl) - zh;   // Zq::sub, zq.rs:259-276
+                __builtin_amdgcn_sched_barrier(0);              // one coefficient pair at a time: the f64 temporaries of 16 interleaved epilogues do not fit
             }
         }
-#ifndef FHE_B32_ABLATE_INV      // timing-only builds (tools/abl_build.sh): the kernels without their transforms / their f64 epilogues
-        inv_big<LP>(v, lds, ltw[pr], a.t.tw_inv[pr], tf, p, p2);
-#endif
-        const Tw32 ni = a.ninv_mont[pr];
-        if (pr == 0) {
-#pragma unroll
-            for (int s = 0; s < C::VT; s++)
-#pragma unroll
-                for (int k = 0; k < 16; k++) resA[s][k] = csub_u32(mul_shoup32(v[s][k], ni, p), p);
-        } else {
-            // register k of logical thread t = point k * (M / 16) + t: k and k + 8 are coefficients j and j + n of the 2n-word
-            // convolution — the pair the X^n+1 fold subtracts (ring_nq.rs:132-141); mul_div_round (ring_n.rs:130-138) +
-            // Rq::from_vec_f64 (ring_nq.rs:160-163)
-#pragma unroll
-            for (int s = 0; s < C::VT; s++)
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const u32 rl = csub_u32(mul_shoup32(v[s][k], ni, p), p), rh = csub_u32(mul_shoup32(v[s][k + 8], ni, p), p);
-                    const long long lo = (long long)crt2(resA[s][k], rl, a.t.p[0], a.t.p[1], a.t.crt);
-                    const long long hi = (long long)crt2(resA[s][k + 8], rh, a.t.p[0], a.t.p[1], a.t.crt);
-#ifndef FHE_B32_ABLATE_EPI
-                    const u64 zl = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)lo) / a.denf));
-                    const u64 zh = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)hi) / a.denf));    // slot 2n-1 of a (2n-1)-term convolution is 0
-#else
-                    const u64 zl = (u64)lo, zh = (u64)hi;
-#endif
-                    po[(u32)k * (C::VT * C::TH) + s * C::TH] = zl >= zh ? zl - zh : (a.q + zl) - zh;   // Zq::sub, zq.rs:259-276
-                }
-        }
-    }
+    };
+    prime(std::integral_constant<int, 0>{});
+    prime(std::integral_constant<int, 1>{});
 }
 
-// ---- relinearisation: key-limb products in the load -> inverse (both primes) -> CRT -> limbs recombined mod 2^64
-//      -> 1/p scale, round, Z_q, fold, + c0 / c1 (lib.rs:204-277) ---------------------------------------------------------
+// ---- relinearisation: key products in the load -> inverse (three primes) -> Garner modulo 2^64 -> 1/p scale, round,
+//      Z_q, fold, + c0 / c1 (lib.rs:204-277) --------------------------------------------------------------------------------
 // workgroup = (ciphertext b, output polynomial o)
-template <int LP>
-__global__ __launch_bounds__((Big32<LP>::TH)) void bfv32_relin_inverse_kernel(Bfv32Args a) {
-    using C = Big32<LP>;
+template <int LB, bool SMALL>
+__global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel(Bfv32Args a) {
+    using C = Big32<LB>;
+    using K = Blk<LB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32 *lds = reinterpret_cast<u32 *>(smem_raw);
-    Tw32 *ltw[3];
     const u32 tf = threadIdx.x;
-    stage_all<LP>(ltw, smem_raw + C::TILE_BYTES, a.t.tw_inv, tf);
     // both output polynomials of a ciphertext read the same transform of c2: ids 16 g + 8 o + (b % 8) share an XCD
     const u64 g8 = blockIdx.x / 16;
     const u32 r16 = blockIdx.x % 16;
     const u64 b = g8 * 8 + (r16 & 7u);
     const u32 o = r16 >> 3;
     if (b >= a.batch) return;
-    const u32 n = C::M / 2;
+#pragma unroll
+    for (int i = 0; i < 6; i++) stage_tw32_block<C::TH>(K::table(smem_raw, i), a.t.tw_inv[i >> 1], C::LTW_N, tf, 1u, (u32)(i & 1));
     __syncthreads();
     // Garner's digits: x = v0 + pA v1 + pA pB v2 with v0 = rA, v1 = (rB - v0) pA^-1 mod pB,
-    // v2 = ((rC - v0) pA^-1 - v1) pB^-1 mod pC; only x mod 2^64 is kept
-    u32 v0[C::VT][16], v1[C::VT][16];
-    u64 R[C::VT][16];
-    auto prime = [&](auto prc) __attribute__((always_inline)) {     // a lambda per prime: the loop form is not unrolled by the compiler
+    // v2 = ((rC - v0) pA^-1 - v1) pB^-1 mod pC; only x mod 2^64 is kept.  [0] = coefficient j, [1] = coefficient j + n
+    u32 g0[2][16], g1[2][16];
+    const u64 off = ((u64)o * a.batch + b) * K::M + tf;
+    auto prime = [&](auto prc) __attribute__((always_inline)) {
         constexpr int pr = decltype(prc)::value;
         const u32 p = a.t.p[pr], p2 = 2u * p, pn = a.pinv_neg[pr];
-        u32 v[C::VT][16];
+        auto block = [&](u32 blk, u32 (&v)[1][16]) __attribute__((always_inline)) {
+            const u32 bo = blk * K::M + tf * 4u;
+            const u32 *__restrict__ rx = a.x + (((u64)pr * a.batch + b) << (LB + 1)) + bo;
+            const u32 *__restrict__ rk = a.key + (((u64)pr * 2 + o) << (LB + 1)) + bo;
 #pragma unroll
-        for (int s = 0; s < C::VT; s++) {
-            const u32 off = (tf + s * C::TH) * 4u;
-            u32 y[16];
-            load16<LP>(v[s], a.x + (((u64)pr * a.batch + b) << LP) + off);
-            load16<LP>(y, a.key + (((u64)pr * 2 + o) << LP) + off);
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[s][k] = mont32(v[s][k], y[k], p, pn);
-        }
-#ifndef FHE_B32_ABLATE_INV      // timing-only builds (tools/abl_build.sh): the kernels without their transforms / their f64 epilogues
-        inv_big<LP>(v, lds, ltw[pr], a.t.tw_inv[pr], tf, p, p2);
+            for (int j = 0; j < 4; j++) {
+                const uint4 xa = *reinterpret_cast<const uint4 *>(rx + j * (K::M / 4)), xb = *reinterpret_cast<const uint4 *>(rk + j * (K::M / 4));
+                v[0][4 * j] = mont32(xa.x, xb.x, p, pn); v[0][4 * j + 1] = mont32(xa.y, xb.y, p, pn);
+                v[0][4 * j + 2] = mont32(xa.z, xb.z, p, pn); v[0][4 * j + 3] = mont32(xa.w, xb.w, p, pn);
+            }
+#ifndef FHE_B32_ABLATE_INV
+            inv_block<FHE_B32_INV_R, LB>(v, lds, K::table(smem_raw, 2 * pr + (int)blk), a.t.tw_inv[pr], tf, p, p2, blk);
 #endif
-        const Tw32 ni = a.ninv_mont[pr];
+        };
+        u32 v0[1][16], v1[1][16];
+        block(0u, v0);
+        block(1u, v1);
+        const Tw32 ni = a.ninv_mont[pr], w1 = a.t.tw_inv[pr][1];
 #pragma unroll
-        for (int s = 0; s < C::VT; s++)
+        for (int k = 0; k < 16; k++) {
+            u32 r2[2] = {v0[0][k], v1[0][k]};
+            last_stage(r2[0], r2[1], w1, ni, p, p2);
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const u32 r = csub_u32(mul_shoup32(v[s][k], ni, p), p);
+            for (int h = 0; h < 2; h++) {
+                const u32 r = r2[h];
                 if constexpr (pr == 0) {
-                    v0[s][k] = r;
+                    g0[h][k] = r;
                 } else if constexpr (pr == 1) {
-                    const u32 d = csub_u32(r - csub_u32(v0[s][k], p) + p, p);              // pA - pB < pB: one subtraction reduces v0
-                    v1[s][k] = csub_u32(mul_shoup32(d, a.t.crt, p), p);
+                    const u32 d = csub_u32(r - csub_u32(g0[h][k], p) + p, p);              // pA - pB < pB: one subtraction reduces v0
+                    g1[h][k] = csub_u32(mul_shoup32(d, a.t.crt, p), p);
                 } else {
-                    const u32 a0 = csub_u32(csub_u32(v0[s][k], p), p);                       // pA - pC < 2 pC
+                    const u32 a0 = csub_u32(csub_u32(g0[h][k], p), p);                       // pA - pC < 2 pC
                     const u32 d = csub_u32(r - a0 + p, p);
                     const u32 e = csub_u32(mul_shoup32(d, a.t.crt_ac, p), p);
-                    const u32 b1 = csub_u32(v1[s][k], p);                                    // pB - pC < pC
+                    const u32 b1 = csub_u32(g1[h][k], p);                                    // pB - pC < pC
                     const u32 v2 = csub_u32(mul_shoup32(csub_u32(e - b1 + p, p), a.t.crt_bc, p), p);
-                    R[s][k] = (u64)v0[s][k] + (u64)a.t.p[0] * v1[s][k] + a.t.P * v2;        // mod 2^64; P = pA pB < 2^55
+                    r2[h] = 0;
+                    const u64 R = (u64)g0[h][k] + (u64)a.t.p[0] * g1[h][k] + a.t.P * v2;    // mod 2^64; P = pA pB < 2^55
+                    // the two coefficients' words meet below: keep them in g0 / g1 (both halves of a 64-bit word)
+                    g0[h][k] = (u32)R;
+                    g1[h][k] = (u32)(R >> 32);
                 }
             }
+            if constexpr (pr == 2) {
+                const long long lo = (long long)(((u64)g1[0][k] << 32) | g0[0][k]), hi = (long long)(((u64)g1[1][k] << 32) | g0[1][k]);
+#ifndef FHE_B32_ABLATE_EPI
+                const u64 zl = scale_round<SMALL>(a, lo);
+                const u64 zh = scale_round<SMALL>(a, hi);
+#else
+                const u64 zl = (u64)lo, zh = (u64)hi;
+#endif
+                u64 v = zl >= zh ? zl - zh : (a.q + zl) - zh;      // Zq::sub, zq.rs:259-276
+                const u64 at = off + (u32)k * C::TH;
+                v += a.addend[at];
+                if (v >= a.q) v -= a.q;                            // Zq::add, zq.rs:219-231
+                a.out[at] = v;
+                __builtin_amdgcn_sched_barrier(0);              // as in the tensor kernel
+            }
+        }
     };
     prime(std::integral_constant<int, 0>{});
     prime(std::integral_constant<int, 1>{});
     prime(std::integral_constant<int, 2>{});
-    const u64 off = ((u64)o * a.batch + b) * n + tf;
-#pragma unroll
-    for (int s = 0; s < C::VT; s++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const long long lo = (long long)R[s][k], hi = (long long)R[s][k + 8];
-#ifndef FHE_B32_ABLATE_EPI
-            const u64 zl = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)lo) / a.denf));
-            const u64 zh = zq_from_f64_mu(a.q, a.qmu, round((a.numf * (double)hi) / a.denf));
-#else
-            const u64 zl = (u64)lo, zh = (u64)hi;
-#endif
-            u64 v = zl >= zh ? zl - zh : (a.q + zl) - zh;      // Zq::sub, zq.rs:259-276
-            const u64 at = off + (u32)k * (C::VT * C::TH) + s * C::TH;
-            v += a.addend[at];
-            if (v >= a.q) v -= a.q;                            // Zq::add, zq.rs:219-231
-            a.out[at] = v;
-        }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -291,26 +370,40 @@ static hipError_t launch_big(K kernel, const char *name, int lp, size_t lds, uns
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid, gridy), dim3(th), lds, st, a);
     return hipGetLastError();
 }
-#define FHE_BIG_SWITCH(KERNEL, NAME, GRID, GRIDY)                                                                                 \
+// a.log_n2 = log2(2n); the kernels are instantiated on the block size n = 2^(log_n2 - 1); TABLES local twiddle tiles
+#define FHE_BIG_SWITCH(KERNEL, NAME, GRID, GRIDY, TABLES)                                                                      \
     switch (a.log_n2) {                                                                                                      \
-        case 11: return launch_big(KERNEL<11>, NAME, 11, Big32<11>::TILE_BYTES + 3 * Big32<11>::TW_BYTES, Big32<11>::TH, GRID, a, st, GRIDY); \
-        case 12: return launch_big(KERNEL<12>, NAME, 12, Big32<12>::TILE_BYTES + 3 * Big32<12>::TW_BYTES, Big32<12>::TH, GRID, a, st, GRIDY); \
-        case 13: return launch_big(KERNEL<13>, NAME, 13, Big32<13>::TILE_BYTES + 3 * Big32<13>::TW_BYTES, Big32<13>::TH, GRID, a, st, GRIDY); \
-        case 14: return launch_big(KERNEL<14>, NAME, 14, Big32<14>::TILE_BYTES + 3 * Big32<14>::TW_BYTES, Big32<14>::TH, GRID, a, st, GRIDY); \
+        case 11: return launch_big(KERNEL<10>, NAME, 11, Blk<10>::LDS(TABLES), Big32<10>::TH, GRID, a, st, GRIDY); \
+        case 12: return launch_big(KERNEL<11>, NAME, 12, Blk<11>::LDS(TABLES), Big32<11>::TH, GRID, a, st, GRIDY); \
+        case 13: return launch_big(KERNEL<12>, NAME, 13, Blk<12>::LDS(TABLES), Big32<12>::TH, GRID, a, st, GRIDY); \
+        case 14: return launch_big(KERNEL<13>, NAME, 14, Blk<13>::LDS(TABLES), Big32<13>::TH, GRID, a, st, GRIDY); \
     }                                                                                                                        \
     return hipErrorNotSupported;
 
-template <int LP> static constexpr auto bfv32_forward2 = bfv32_forward_kernel<LP, 2, true>;
-template <int LP> static constexpr auto bfv32_forward3 = bfv32_forward_kernel<LP, 3, true>;
-template <int LP> static constexpr auto bfv32_forward1w = bfv32_forward_kernel<LP, 1, false>;
+template <int LB> static constexpr auto bfv32_forward2 = bfv32_forward_kernel<LB, 2, true>;
+template <int LB> static constexpr auto bfv32_forward3 = bfv32_forward_kernel<LB, 3, true>;
+template <int LB> static constexpr auto bfv32_forward1w = bfv32_forward_kernel<LB, 1, false>;
 hipError_t launch_bfv32_forward(const Bfv32Args &a, hipStream_t st) {
-    if (a.primes == 2 && a.word32) { FHE_BIG_SWITCH(bfv32_forward2, "bfv32_forward", a.rows, 1) }
-    if (a.primes == 3 && a.word32) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", a.rows, 1) }
-    if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward1w, "bfv32_forward_key", a.rows, 3) }      // grid (rows, primes)
+    const u64 grid = 16 * ((a.rows + 7) / 8);                                                   // (row, block) pairs, 8 rows x 2 blocks per group
+    if (a.primes == 2 && a.word32) { FHE_BIG_SWITCH(bfv32_forward2, "bfv32_forward", grid, 1, 2) }
+    if (a.primes == 3 && a.word32) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", grid, 1, 3) }
+    if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward1w, "bfv32_forward_key", grid, 3, 1) }      // grid (row-blocks, primes)
     return hipErrorNotSupported;
 }
-hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_tensor_inverse_kernel, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1) }
-hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) { FHE_BIG_SWITCH(bfv32_relin_inverse_kernel, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1) }
+template <int LB> static constexpr auto bfv32_tensor_inverse_f64 = bfv32_tensor_inverse_kernel<LB, false, false>;
+template <int LB> static constexpr auto bfv32_tensor_inverse_f64s = bfv32_tensor_inverse_kernel<LB, false, true>;
+template <int LB> static constexpr auto bfv32_tensor_inverse_int = bfv32_tensor_inverse_kernel<LB, true, false>;
+hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) {
+    if (a.int_num) { FHE_BIG_SWITCH(bfv32_tensor_inverse_int, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4) }
+    if (a.small_f64) { FHE_BIG_SWITCH(bfv32_tensor_inverse_f64s, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4) }
+    FHE_BIG_SWITCH(bfv32_tensor_inverse_f64, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4)
+}
+template <int LB> static constexpr auto bfv32_relin_inverse_gen = bfv32_relin_inverse_kernel<LB, false>;
+template <int LB> static constexpr auto bfv32_relin_inverse_small = bfv32_relin_inverse_kernel<LB, true>;
+hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) {
+    if (a.small_f64) { FHE_BIG_SWITCH(bfv32_relin_inverse_small, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1, 6) }
+    FHE_BIG_SWITCH(bfv32_relin_inverse_gen, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1, 6)
+}
 #undef FHE_BIG_SWITCH
 
 // timing-only builds (tools/abl_build.sh) produce wrong words by design: fhe_ntt_version() says so (capi.hip)

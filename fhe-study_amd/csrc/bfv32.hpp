@@ -24,6 +24,9 @@ struct Bfv32Args {
     u64 batch, q;
     u64 qmu;                   // floor(2^64 / q)
     double numf, denf;
+    u64 int_num;               // tensor: numf as an integer when numf * v < 2^52 for every coefficient v (integer epilogue), else 0
+    uint32_t small_f64;        // |numf * v / denf| < 2^50 for every coefficient: Zq::from_f64 stays in f64 (zq_from_f64_small)
+    double qinvf;              // fl(1 / q)
 };
 
 // q, n, pq for which the small-prime form applies: the tensor's integers below pA pB, the relinearisation's (pq != 0)

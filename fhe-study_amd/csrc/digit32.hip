@@ -141,11 +141,24 @@ struct Cfg32 {
 // At n = 1024 (630 external products, lockstep 320 us): the primes taking turns in 168 registers, three workgroups per
 // CU, 340 us; the multiply phase made unconditional so that a step's key loads issue together, 322 us (351 -> 371 at
 // n = 4096).
+// Shape experiments at n = 1024 (tools: -DFHE_D32_TH10=512 -DFHE_D32_WAVES10=4 -DFHE_D32_MAC_UNROLL=1 ...): defaults = production
+#ifndef FHE_D32_TH10
+#define FHE_D32_TH10 256          // threads per workgroup at n = 1024
+#endif
+#ifndef FHE_D32_WAVES10
+#define FHE_D32_WAVES10 2         // waves per SIMD the register allocation must allow at n = 1024
+#endif
+#ifndef FHE_D32_MAC_UNROLL
+#define FHE_D32_MAC_UNROLL 0      // digits of a step whose key loads the multiply phase has in flight at once (0 = all W)
+#endif
+#define FHE_D32_PRAGMA_(x) _Pragma(#x)
+#define FHE_D32_PRAGMA(x) FHE_D32_PRAGMA_(x)
 template <int LP>
 struct Mac32Cfg {
     using C = ContigCfg<LP>;
     static constexpr int M = C::M, TPB = C::TPB;
-    static constexpr int TH = LP == 12 ? 512 : 256;
+    static constexpr int TH = LP == 12 ? 512 : LP == 10 ? FHE_D32_TH10 : 256;
+    static constexpr int WAVES = LP == 10 ? FHE_D32_WAVES10 : 512 / TH;     // __launch_bounds__: minimum waves per SIMD
     static constexpr int W = TH / TPB, PPT = M / TH;
     static constexpr bool LOCK = PPT <= 4;
     static constexpr size_t TILE_BYTES = (size_t)(W * M + W * M / 16) * 4;
@@ -205,7 +218,7 @@ __device__ __forceinline__ u32 digit32_of(u64 x, u32 l, u32 d) {
 // key32 layout: [prime][t][c][n], t = row*l + digit, c < NC (NC = 2 * output rows: half-major, then component).
 // out: partial sums [b][part][prime][c][n] u32 canonical.
 template <int LP, int NC, int SRC>
-__global__ __launch_bounds__((Mac32Cfg<LP>::TH), (512 / Mac32Cfg<LP>::TH)) void digit_mac32_kernel(Ext32Args a) {
+__global__ __launch_bounds__((Mac32Cfg<LP>::TH), (Mac32Cfg<LP>::WAVES)) void digit_mac32_kernel(Ext32Args a) {
     using C = ContigCfg<LP>;
     using K = Mac32Cfg<LP>;
     constexpr int PPT = K::PPT, W = K::W, TH = K::TH, NP = 2;
@@ -296,7 +309,11 @@ __global__ __launch_bounds__((Mac32Cfg<LP>::TH), (512 / Mac32Cfg<LP>::TH)) void 
 #ifdef FHE_D32_ABLATE_MAC
         if (a.T == 0xffffffffu)
 #endif
+#if FHE_D32_MAC_UNROLL == 0
 #pragma unroll
+#else
+        FHE_D32_PRAGMA(unroll FHE_D32_MAC_UNROLL)
+#endif
         for (int u = 0; u < W; u++) {
             if ((u32)u < nu) {
 #pragma unroll

@@ -22,7 +22,7 @@ struct Big32 {
     static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
     static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
     static constexpr bool in_lds(int j) { return ls0_of(j) + (j == 0 ? R0 : 4) <= LTW_LOG; }
-    static_assert(LP >= 11 && LP <= 14 && NR >= 3 && NR <= 4, "2048 .. 16384 points");
+    static_assert(LP >= 10 && LP <= 14 && NR >= 3 && NR <= 4, "1024 .. 16384 points");
 };
 
 // the register windows of a thread through the tile: barrier (the tile may have been gathered from by the transform or
@@ -109,6 +109,32 @@ __device__ __forceinline__ void inv_round_big(u32 (&v)[Big32<LP>::VT][16], Tw32 
         for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J - 1) ? ltw : gtw, big_t0<LP, J - 1>(s0, blk, (tf + s * C::TH) >> AN));
     }
     exchange_big<LP, A, C::a_of(J - 1)>(v, lds, tf);
+}
+// The same without the 30 twiddle registers: every round reads its table (LDS tile or global) as it goes.  For kernels
+// that hold other results across the transform (bfv32.hip's block kernels: residues of the primes done so far) and run
+// two workgroups per CU, where the other workgroup covers the table latency the preloading was there to hide.
+// STAGED: a scheduling barrier after every stage (round_inv32_staged), so that at most 8 table entries are in flight
+template <int LP, int J, bool STAGED>
+__device__ __forceinline__ void inv_round_big_direct(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2,
+                                                     u32 s0, u32 blk) {
+    using C = Big32<LP>;
+    constexpr int A = C::a_of(J);
+#pragma unroll
+    for (int s = 0; s < C::VT; s++) {
+        if constexpr (STAGED) round_inv32_staged<4>(v[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A), p, p2);
+        else round_inv32<4>(v[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A), p, p2);
+    }
+    exchange_big<LP, A, C::a_of(J - 1)>(v, lds, tf);
+}
+template <int LP, bool STAGED = true>
+__device__ __forceinline__ void inv_big_direct(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2,
+                                               u32 s0 = 0, u32 blk = 0) {
+    using C = Big32<LP>;
+    if constexpr (C::NR > 3) inv_round_big_direct<LP, 3, STAGED>(v, lds, ltw, gtw, tf, p, p2, s0, blk);
+    inv_round_big_direct<LP, 2, STAGED>(v, lds, ltw, gtw, tf, p, p2, s0, blk);
+    inv_round_big_direct<LP, 1, STAGED>(v, lds, ltw, gtw, tf, p, p2, s0, blk);
+#pragma unroll
+    for (int s = 0; s < C::VT; s++) round_inv32<C::R0>(v[s], ltw, 1u, p, p2);
 }
 template <int LP>
 __device__ __forceinline__ void inv_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2,

@@ -69,6 +69,23 @@ __device__ __forceinline__ void round_inv32(u32 (&v)[16], const Tw32 *__restrict
     }
 }
 
+// The inverse round with its table reads kept INSIDE their stage (a scheduling barrier between stages): the compiler
+// otherwise hoists the 15 reads of a round to its top — 30 registers that kernels holding other results cannot spare.
+template <int R>
+__device__ __forceinline__ void round_inv32_staged(u32 (&v)[16], const Tw32 *__restrict__ tw, u32 T0, u32 p, u32 p2) {
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            const Tw32 t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) gs32(v[g * 2 * span + l], v[g * 2 * span + l + span], t, p, p2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // The same rounds with their twiddles in registers: load_tw32 BEFORE the LDS exchange that precedes the round, so that
 // the latency of the table (L2 for the late rounds, whose twiddles are unique per thread) runs under the exchange's
 // barriers instead of after them.  t[(1 << i) - 1 + g] = stage i, group g.

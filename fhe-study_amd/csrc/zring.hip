@@ -551,6 +551,13 @@ static int bfv32_args(uint64_t n, fhe::Bfv32Args *a) {
     }
     return FHE_OK;
 }
+// Opt-in (FHE_BFV_SMALL_F64=1): bit-identical (tests/test_round3_gpu.py) and ~90 instructions shorter per coefficient, but
+// measured SLOWER inside the block kernels (tensor 954 vs 854 us, relinearisation 962 vs 899 us per 2048 pairs): the shorter
+// epilogue lets the compiler keep more of it in flight and the kernels, already at their 128 registers, spill more.
+static bool bfv32_small_f64_on() {
+    static const bool on = [] { const char *e = getenv("FHE_BFV_SMALL_F64"); return e && e[0] == '1'; }();
+    return on;
+}
 static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, void *d_c, size_t batch, hipStream_t st) {
     fhe::Bfv32Args a{};
     int rc = bfv32_args(n, &a);
@@ -562,6 +569,17 @@ static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, vo
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.batch = batch; a.out = (u64 *)d_c; a.q = q; a.qmu = ~0ull / q; a.numf = (double)t; a.denf = (double)q;
+    {   // the integer epilogue (bfv32.hip: zq_scale_round_int) where t * v < 2^52 for every coefficient v <= 2 n (q - 1)^2
+        // — opt-in with FHE_BFV_INT_ROUND=1: bit-identical (tests/test_round3_gpu.py) but measured SLOWER than the f64 form
+        // on MI355X (951 vs 855 us per 2048 pairs: f64 runs at full rate here, two 64-bit quotients cost more than one division)
+        static const bool on = [] { const char *e = getenv("FHE_BFV_INT_ROUND"); return e && e[0] == '1'; }();
+        const unsigned __int128 vmax = (unsigned __int128)2 * n * (q - 1) * (q - 1);
+        a.int_num = (on && t != 0 && vmax * t < ((unsigned __int128)1 << 52)) ? t : 0;
+        // Zq::from_f64 in f64 alone (bfv32.hip: zq_from_f64_small) where every scaled coefficient stays below 2^50
+        // (opt-in, see bfv32_small_f64_on)
+        a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 31) && vmax * t / q < ((unsigned __int128)1 << 50)) ? 1u : 0u;
+        a.qinvf = 1.0 / (double)q;
+    }
     e = fhe::launch_bfv32_tensor_inverse(a, st);
     return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "bfv32_tensor_inverse_kernel");
 }
@@ -586,6 +604,9 @@ static int bfv32_relinearize(uint64_t q, uint64_t n, uint64_t pq, const void *d_
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.x = (const uint32_t *)wsv; a.key = (const uint32_t *)d_prep;
     a.addend = (const u64 *)d_c; a.out = (u64 *)d_out; a.batch = batch; a.q = q; a.qmu = ~0ull / q; a.numf = 1.0; a.denf = (double)(pq / q);
+    // |R| <= 2^63 (an i64): R / p stays below 2^50 for p >= 2^14
+    a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 31) && pq / q >= (1ull << 14)) ? 1u : 0u;
+    a.qinvf = 1.0 / (double)q;
     e = fhe::launch_bfv32_relin_inverse(a, st);
     return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "bfv32_relin_inverse_kernel");
 }

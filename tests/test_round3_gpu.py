@@ -384,3 +384,85 @@ def test_version_string_and_ablation_guard(pkg):
 
     src = inspect.getsource(pkg.binding.load_library)
     assert "ABLATED" in src and "FHE_NTT_ALLOW_ABLATED" in src
+
+
+# ---- BFV: the tensor's scale-and-round in integers --------------------------------------------------
+
+
+def _scale_round_int(N, q):
+    """bfv32.hip: zq_scale_round_int, in Python integers"""
+    a, f = divmod(N, q)
+    return (a + (1 if 2 * f >= q else 0)) % q
+
+
+def test_integer_scale_round_equals_the_f64_form_where_the_kernel_uses_it():
+    """Zq::from_f64(round(num * v / q)) (ring_n.rs:130-138, zq.rs:32-39) in IEEE f64 — what the reference computes —
+    against the integer form the tensor kernel uses when num * v < 2^52: every residue class around the half-integer
+    boundaries (2f = q - 1, q, q + 1), the largest admitted N, and random values"""
+    rnd = random.Random(0xF4E5_0303)
+    for q in (65537, 12289, 786433, 1021, 2, 4, 6, 1 << 20, (1 << 21) - 9):
+        cases = []
+        for k in (0, 1, 2, 1000, (1 << 52) // q - 2, rnd.randrange((1 << 52) // q - 2)):
+            for f in {0, 1, (q - 1) // 2 - 1, (q - 1) // 2, q // 2, q // 2 + 1, (q + 1) // 2, q - 1}:
+                if 0 <= f < q:
+                    cases.append(k * q + f)
+        cases += [(1 << 52) - 1, (1 << 52) - q, (1 << 50) - 1, (1 << 50) + 1] + [rnd.randrange(1 << 52) for _ in range(1500)]
+        N = np.array([c for c in cases if c < (1 << 52)], dtype=np.uint64)
+        x = np.round(np.float64(1.0) * N.astype(np.float64) / np.float64(q))           # N is exact in f64: N < 2^53
+        # np.round is half-to-even: the reference's f64::round is half away from zero — they differ only ON a half-integer
+        frac_half = (2 * (N % np.uint64(q)) == np.uint64(q))
+        x = np.where(frac_half, np.floor(N.astype(np.float64) / np.float64(q)) + 1.0, x)
+        want = (x.astype(np.int64) % q).astype(np.uint64)
+        got = np.array([_scale_round_int(int(v), q) for v in N], dtype=np.uint64)
+        assert np.array_equal(got, want), q
+
+
+def test_zq_from_f64_in_f64_alone_is_the_same_residue():
+    """bfv32.hip: zq_from_f64_small — e = round(ef) exact, k = rint(e * fl(1/q)) within one of the quotient, r = e - k q
+    adjusted into [0, q) — against ((e % q) + q) % q (zq.rs:32-39) for |e| < 2^50, negative values included"""
+    rnd = random.Random(0xF4E5_0304)
+    for q in (65537, 12289, 786433, 1021, 3, (1 << 21) - 9, (1 << 31) - 1):
+        es = [0, 1, -1, q, -q, q - 1, 1 - q, (1 << 50) - 1, -(1 << 50) + 1] + [rnd.randrange(-(1 << 50), 1 << 50) for _ in range(3000)] + \
+             [k * q + d for k in (1, 7, (1 << 50) // q - 1) for d in (-1, 0, 1)]
+        e = np.array(es, dtype=np.float64)
+        assert all(float(x) == y for x, y in zip(es, e))                      # exact integers in f64
+        k = np.rint(e * np.float64(1.0 / q))
+        for ei, ki in zip(es, k):
+            r = ei - int(ki) * q                                               # the fma is exact: |k q| < 2^52
+            assert -3 * q < 2 * r < 3 * q
+            r = r + q if r < 0 else r
+            r = r + q if r < 0 else r
+            r = r - q if r >= q else r
+            assert r == ei % q, (q, ei)
+
+
+@pytest.mark.gpu
+def test_bfv_epilogue_forms_give_the_same_words(pkg, oracle, need_gpu):
+    """The tensor / relinearisation epilogues have three forms of Zq::from_f64(round(num * v / den)): f64 with the
+    general saturating conversion (the default: measured fastest inside these kernels), f64 alone (FHE_BFV_SMALL_F64=1,
+    where the scaled coefficients stay below 2^50), and the integer form (FHE_BFV_INT_ROUND=1, tensor only).  Identical ciphertext words on the reference's
+    parameters and on config 3's, where ~2/q of the coefficients sit next to a half-integer boundary; RLWE::mul
+    covers the relinearisation's epilogue."""
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "import fhe_study_amd as pkg\n"
+        "B = pkg.binding\n"
+        "for q, n, t, batch in ((65537, 8192, 2, 24), (65537, 1024, 2, 9), (12289, 2048, 3, 5), (786433, 4096, 2, 4)):\n"
+        "    rng = np.random.default_rng(q + n)\n"
+        "    ab = [rng.integers(0, q, (batch, n), dtype=np.uint64) for _ in range(4)]\n"
+        "    ab[0][0, :] = q - 1; ab[2][0, :] = q - 1; ab[1][0, :] = q - 1; ab[3][0, :] = q - 1\n"
+        "    c = B.bfv_tensor(q, n, t, *ab)\n"
+        "    pq = q * q * q\n"
+        "    rlk = rng.integers(0, pq, (2, n), dtype=np.uint64)\n"
+        "    o = B.bfv_mul(q, n, t, pq, rlk[0], rlk[1], *ab)\n"
+        "    h = hashlib.sha256()\n"
+        "    for x in list(c) + list(o): h.update(np.ascontiguousarray(x).tobytes())\n"
+        "    print('digest', q, n, h.hexdigest())\n" % ROOT)
+    outs = {}
+    for name, extra in (("general", {}), ("f64", {"FHE_BFV_SMALL_F64": "1"}), ("int", {"FHE_BFV_INT_ROUND": "1"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, name + r.stdout + r.stderr
+        outs[name] = [l for l in r.stdout.splitlines() if l.startswith("digest")]
+        assert len(outs[name]) == 4
+    assert outs["general"] == outs["f64"] == outs["int"]

@@ -10,6 +10,10 @@
 // keeps the 61-bit kernels (2^15 points — 1024 threads x 32 coefficients in 128 registers — were tried: 64-143 registers
 // spilled, 3.8 M NTT/s against 4.8 M on the 61-bit two-pass kernels).  Same values, word for word: every result is canonical
 // modulo the same q.
+// NOT covered, and therefore on the 61-bit kernels (stated here and in include/fhe_ntt.h): moduli between
+// 2^32 / 25 (2^27.36) and 2^32 — the no-conditional-subtraction butterflies need 25 q in a word; a Harvey form with 4 q < 2^32
+// would reach 2^30 —, n < 2^8 and n >= 2^18 (a second strided level), and n = 8192 / 16384 run as ONE 1024-thread workgroup per
+// CU (4.7 / 3.9 TB/s where the 256-thread sizes reach 5.5 - 5.8).
 //   sq_forward_kernel   n words in (natural order) -> forward transform -> n words out (the reference's bit-reversed order)
 //   sq_inverse_kernel   the inverse, n^-1 folded in
 //   sq_rq_mul_kernel    both forward transforms in lockstep (one twiddle load for both), pointwise Montgomery product,

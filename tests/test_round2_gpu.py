@@ -412,7 +412,8 @@ def test_small_modulus_transforms_in_32_bit_words(pkg, oracle, q, n, batch):
     names = set(B.kernel_timing_read())
     B.kernel_timing_enable(False)
     lg = n.bit_length() - 1
-    assert {f"sq_forward_{lg}", f"sq_inverse_{lg}", f"sq_rq_mul_{lg}"} <= names, names
+    if os.environ.get("FHE_EXT32", "1")[:1] != "0":            # FHE_EXT32=0 keeps these moduli on the 61-bit kernels: same words
+        assert {f"sq_forward_{lg}", f"sq_inverse_{lg}", f"sq_rq_mul_{lg}"} <= names, names
     assert np.array_equal(_u64(A), oracle.ntt(q, n, a).reshape(batch, n))
     assert np.array_equal(_u64(r), a)
     assert np.array_equal(_u64(c), oracle.rq_mul(q, n, a, b)[0].reshape(batch, n))
@@ -445,7 +446,8 @@ def test_small_modulus_product_with_cached_evals(pkg, oracle, q, n, batch):
             plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch, a_is_evals=a_ev, b_is_evals=b_ev,
                             d_c_evals=ce.data_ptr(), d_a_evals=ae.data_ptr(), d_b_evals=be.data_ptr())
             torch.cuda.synchronize()
-            assert {f"sq_rq_mul_{n.bit_length() - 1}", f"sq2_block_mul_{n.bit_length() - 1}"} & set(B.kernel_timing_read())
+            assert os.environ.get("FHE_EXT32", "1")[:1] == "0" or \
+                {f"sq_rq_mul_{n.bit_length() - 1}", f"sq2_block_mul_{n.bit_length() - 1}"} & set(B.kernel_timing_read())
             B.kernel_timing_enable(False)
             assert np.array_equal(_u64(c), wc) and np.array_equal(_u64(ce), wce), (a_ev, b_ev)
             assert np.array_equal(_u64(ae), wae) and np.array_equal(_u64(be), wbe), (a_ev, b_ev)
@@ -487,7 +489,8 @@ def test_small_modulus_two_pass_transforms(pkg, oracle, q, n, batch):
     names = set(B.kernel_timing_read())
     B.kernel_timing_enable(False)
     lg = n.bit_length() - 1
-    assert {f"sq2_strided_fwd_{lg}", f"sq2_block_fwd_{lg}", f"sq2_block_inv_{lg}", f"sq2_strided_inv_{lg}"} <= names, names
+    ext32 = os.environ.get("FHE_EXT32", "1")[:1] != "0"
+    assert not ext32 or {f"sq2_strided_fwd_{lg}", f"sq2_block_fwd_{lg}", f"sq2_block_inv_{lg}", f"sq2_strided_inv_{lg}"} <= names, names
     assert np.array_equal(_u64(A), oracle.ntt(q, n, a).reshape(batch, n))
     assert np.array_equal(_u64(r), a)
     x = da.clone()
@@ -499,7 +502,7 @@ def test_small_modulus_two_pass_transforms(pkg, oracle, q, n, batch):
     B.kernel_timing_reset(); B.kernel_timing_enable(True)
     plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), c.data_ptr(), batch)
     torch.cuda.synchronize()
-    assert f"sq2_block_mul_{lg}" in set(B.kernel_timing_read())
+    assert not ext32 or f"sq2_block_mul_{lg}" in set(B.kernel_timing_read())
     B.kernel_timing_enable(False)
     assert np.array_equal(_u64(c), oracle.rq_mul(q, n, a, b)[0].reshape(batch, n))
     plan.forward_dev(db.data_ptr(), Bv.data_ptr(), batch)

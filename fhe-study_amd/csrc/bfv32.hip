@@ -55,6 +55,12 @@ __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
 #ifndef FHE_B32_INV_R
 #define FHE_B32_INV_R 1          // relinearisation (measured, 2048 pairs at n = 8192: 937 / 897 / 1019 us for 0 / 1 / 2; tensor 863 / 898 / 853)
 #endif
+#ifndef FHE_B32_FWD_PRELOAD
+#define FHE_B32_FWD_PRELOAD 1    // forward blocks: twiddles of a round held across the exchange (1) or read as they go (0)
+#endif
+#ifndef FHE_B32_FWD_WAVES
+#define FHE_B32_FWD_WAVES 4      // forward kernels: waves per SIMD the register allocation must allow
+#endif
 template <int MODE, int LB>
 __device__ __forceinline__ void inv_block(u32 (&v)[1][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 blk) {
     if constexpr (MODE == 0) inv_big<LB>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
@@ -73,7 +79,7 @@ struct Blk {
 // WORD32: the source words are below 2^32 (ciphertext words modulo a q that small): reduced in one word.
 // Workgroup ids 16 g + 8 blk + (row % 8): the two blocks of a row read the same words through ONE XCD's L2.
 template <int LB, int NPR, bool WORD32>
-__global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_forward_kernel(Bfv32Args a) {
+__global__ __launch_bounds__((Big32<LB>::TH), FHE_B32_FWD_WAVES) void bfv32_forward_kernel(Bfv32Args a) {
     using C = Big32<LB>;
     using K = Blk<LB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -89,9 +95,10 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_forward_kernel(Bfv32
 #pragma unroll
     for (int i = 0; i < NPR; i++) stage_tw32_block<C::TH>(K::table(smem_raw, i), a.t.tw_fwd[NPR == 1 ? blockIdx.y : i], C::LTW_N, tf, 1u, blk);
     const u64 *__restrict__ src = a.src + row * K::M;
-    u64 x[16];                                                  // window [LB-4, LB): register k = word k * TH + tf
+    // window [LB-4, LB): register k = word k * TH + tf; WORD32: only the low words are kept across the primes
+    typename std::conditional<WORD32, u32, u64>::type x[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = src[(u32)k * C::TH + tf];
+    for (int k = 0; k < 16; k++) x[k] = (typename std::conditional<WORD32, u32, u64>::type)src[(u32)k * C::TH + tf];
     __syncthreads();                                            // the twiddle tiles
 #pragma unroll
     for (int i = 0; i < NPR; i++) {
@@ -101,7 +108,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_forward_kernel(Bfv32
 #pragma unroll
         for (int k = 0; k < 16; k++)
             v[0][k] = WORD32 ? csub_u32(barrett2p_32((u32)x[k], p, a.t.bq[pr]), p) : reduce64_32(x[k], p, a.t.mu[pr]);
-        fwd_big<LB, 0, 1>(v, lds, K::table(smem_raw, i), a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr], 1u, blk);
+        fwd_big<LB, 0, 1, FHE_B32_FWD_PRELOAD != 0>(v, lds, K::table(smem_raw, i), a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr], 1u, blk);
         // stored order (internal to this file): quad j of logical thread t at j * (M / 4) + 4 t of its block — a wave's
         // 16-byte accesses are contiguous (with the natural 16 t + 4 j every access would touch a quarter of each line)
         u32 *__restrict__ dst = a.fw + (((u64)pr * a.rows + row) << (LB + 1)) + blk * K::M + tf * 4u;

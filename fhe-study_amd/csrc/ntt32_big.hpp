@@ -63,15 +63,19 @@ __device__ __forceinline__ void stage_tw32_block(Tw32 *ltw, const Tw32 *__restri
         ltw[li] = tw[(1u << (s0 + ls)) + (blk << ls) + (l1 - (1u << ls))];
     }
 }
-template <int LP, int J, int B>
+// PRELOAD = false: the rounds read their table as they go instead of holding a round's 30 twiddle words across the
+// exchange (fewer registers: more workgroups per CU, which then cover the table latency)
+template <int LP, int J, int B, bool PRELOAD = true>
 __device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq,
                                               u32 s0 = 0, u32 blk = 0) {
     using C = Big32<LP>;
     if constexpr (J < C::NR) {
         constexpr int A = C::a_of(J);
         Tw32 t[C::VT][15];                                      // requested before the exchange: see load_tw32
+        if constexpr (PRELOAD) {
 #pragma unroll
-        for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A));
+            for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A));
+        }
         exchange_big<LP, C::a_of(J - 1), A>(v, lds, tf);
         constexpr bool RED = B + 8 > 25;
 #pragma unroll
@@ -80,19 +84,20 @@ __device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *
 #pragma unroll
                 for (int k = 0; k < 16; k++) v[s][k] = barrett2p_32(v[s][k], p, bq);
             }
-            round_fwd32_tw<4, 0, true>(v[s], t[s], p, p2);
+            if constexpr (PRELOAD) round_fwd32_tw<4, 0, true>(v[s], t[s], p, p2);
+            else round_fwd32<4, 0, true>(v[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A), p, p2);
         }
-        fwd_round_big<LP, J + 1, (RED ? 2 : B) + 8>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
+        fwd_round_big<LP, J + 1, (RED ? 2 : B) + 8, PRELOAD>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
     }
 }
 // B0: the bound (in p) of the values on entry
-template <int LP, int I0, int B0 = 1>
+template <int LP, int I0, int B0 = 1, bool PRELOAD = true>
 __device__ __forceinline__ void fwd_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq,
                                         u32 s0 = 0, u32 blk = 0) {
     using C = Big32<LP>;
 #pragma unroll
     for (int s = 0; s < C::VT; s++) round_fwd32<C::R0, I0, true>(v[s], ltw, 1u, p, p2);
-    fwd_round_big<LP, 1, B0 + 2 * C::R0>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
+    fwd_round_big<LP, 1, B0 + 2 * C::R0, PRELOAD>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
 }
 // Inverse stages (gs32: values below 2p throughout): window [0,4) -> window [LP-4, LP), not yet scaled.  `t` holds the
 // twiddles of round J on entry (requested by the caller / the round before, ahead of the exchange).

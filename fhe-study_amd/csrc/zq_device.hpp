@@ -294,6 +294,7 @@ __device__ __forceinline__ void gs_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, u64 kq
 #undef FHE_PM_GS_BODY
     y = yo;
 }
+#undef FHE_PM_PRODUCT
 
 // Rust `f64 as i64` (saturating, NaN -> 0)
 __device__ __forceinline__ long long f64_as_i64(double x) {

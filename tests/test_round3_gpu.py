@@ -310,7 +310,8 @@ def test_default_line_is_the_headline_configuration(pkg, need_gpu):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["config"]["global_batch"] == 65536 and out["config"]["batch_per_gpu"] == 65536
-    assert out["config"]["q"] == Q61 and out["config"]["n"] == 65536 and out["config"]["arithmetic"] == "pseudo-mersenne"
+    want = "pseudo-mersenne" if os.environ.get("FHE_PM", "1")[:1] != "0" else "shoup61"      # FHE_PM=0: the A/B switch
+    assert out["config"]["q"] == Q61 and out["config"]["n"] == 65536 and out["config"]["arithmetic"] == want
     assert out["scaling"] == "strong" and out["parity"]["mismatching_rows"] == 0
     assert out["roofline"]["step_frac"] > 0.2
 

@@ -667,7 +667,7 @@ extern "C" int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_
     return i;
 }
 
-// small moduli (q < 2^32 / 25, 2^8 <= n <= 2^12): one 32-bit word per coefficient (smallq.hip); FHE_EXT32=0 keeps the 61-bit kernels
+// small moduli (q < 2^30, 2^8 <= n <= 2^17): one 32-bit word per coefficient (smallq.hip); FHE_EXT32=0 keeps the 61-bit kernels
 bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a) {
     if (!dp.tw32_fwd || !fhe_ext32_enabled()) return false;
     const u64 q = plan->q;
@@ -680,6 +680,7 @@ bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::S
     const u64 nm = (plan->n_inv << 32) % q;
     a->ninv_mont = fhe::Tw32{(uint32_t)nm, (uint32_t)((nm << 32) / q)};
     a->mu = ~0ull / q;
+    a->loose = fhe::smallq_loose(q) ? 1u : 0u;
     return true;
 }
 // the u32 buffer between the passes of the two-pass sizes: its own workspace slot (the callers' slots 0 / 1 stay theirs)

@@ -65,7 +65,8 @@ __device__ __forceinline__ void stage_tw32_block(Tw32 *ltw, const Tw32 *__restri
 }
 // PRELOAD = false: the rounds read their table as they go instead of holding a round's 30 twiddle words across the
 // exchange (fewer registers: more workgroups per CU, which then cover the table latency)
-template <int LP, int J, int B, bool PRELOAD = true>
+// LOOSE = false (moduli up to 2^30, smallq.hip): Harvey's butterflies, values in [0, 4p) throughout, nothing to bring down
+template <int LP, int J, int B, bool PRELOAD = true, bool LOOSE = true>
 __device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq,
                                               u32 s0 = 0, u32 blk = 0) {
     using C = Big32<LP>;
@@ -77,27 +78,27 @@ __device__ __forceinline__ void fwd_round_big(u32 (&v)[Big32<LP>::VT][16], u32 *
             for (int s = 0; s < C::VT; s++) load_tw32<4>(t[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A));
         }
         exchange_big<LP, C::a_of(J - 1), A>(v, lds, tf);
-        constexpr bool RED = B + 8 > 25;
+        constexpr bool RED = LOOSE && B + 8 > 25;
 #pragma unroll
         for (int s = 0; s < C::VT; s++) {
             if constexpr (RED) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) v[s][k] = barrett2p_32(v[s][k], p, bq);
             }
-            if constexpr (PRELOAD) round_fwd32_tw<4, 0, true>(v[s], t[s], p, p2);
-            else round_fwd32<4, 0, true>(v[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A), p, p2);
+            if constexpr (PRELOAD) round_fwd32_tw<4, 0, LOOSE>(v[s], t[s], p, p2);
+            else round_fwd32<4, 0, LOOSE>(v[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A), p, p2);
         }
-        fwd_round_big<LP, J + 1, (RED ? 2 : B) + 8, PRELOAD>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
+        fwd_round_big<LP, J + 1, (RED ? 2 : B) + 8, PRELOAD, LOOSE>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
     }
 }
 // B0: the bound (in p) of the values on entry
-template <int LP, int I0, int B0 = 1, bool PRELOAD = true>
+template <int LP, int I0, int B0 = 1, bool PRELOAD = true, bool LOOSE = true>
 __device__ __forceinline__ void fwd_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq,
                                         u32 s0 = 0, u32 blk = 0) {
     using C = Big32<LP>;
 #pragma unroll
-    for (int s = 0; s < C::VT; s++) round_fwd32<C::R0, I0, true>(v[s], ltw, 1u, p, p2);
-    fwd_round_big<LP, 1, B0 + 2 * C::R0, PRELOAD>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
+    for (int s = 0; s < C::VT; s++) round_fwd32<C::R0, I0, LOOSE>(v[s], ltw, 1u, p, p2);
+    fwd_round_big<LP, 1, B0 + 2 * C::R0, PRELOAD, LOOSE>(v, lds, ltw, gtw, tf, p, p2, bq, s0, blk);
 }
 // Inverse stages (gs32: values below 2p throughout): window [0,4) -> window [LP-4, LP), not yet scaled.  `t` holds the
 // twiddles of round J on entry (requested by the caller / the round before, ahead of the exchange).

@@ -1,9 +1,10 @@
 // smallq.hip — NTT::ntt / NTT::intt / Rq x Rq (arith/src/ntt.rs:44-104, ring_nq.rs:586-607) for SMALL moduli in 32-bit words.
 //
 // The reference's own tests and its BFV / GLWE demos run at q = 65537 (and 12289, 1021, ...): 64-bit Shoup butterflies —
-// ten 32-bit multiplies and ~22 instructions each — for 17-bit numbers.  For an NTT-friendly q below 2^32 / 25 the same
+// ten 32-bit multiplies and ~22 instructions each — for 17-bit numbers.  For an NTT-friendly q below 2^30 the same
 // transform (same psi, same tables, same bit-reversed layout: the plan's) runs in one word per coefficient with the
-// butterflies of ntt32_rounds.hpp: 3 multiplies + 3 additions, no conditional subtraction on the forward side.  The
+// butterflies of ntt32_rounds.hpp: 3 multiplies + 3 additions and, below 2^32 / 25, no conditional subtraction on the forward side
+// (between 2^32 / 25 and 2^30 — round 3 — Harvey's form with one per butterfly: 4 q fits the word).  The
 // interface stays 64-bit words; a transform is then bound by its 16 n bytes of traffic instead of by multiplier issue.
 // Two passes with a u32 intermediate for 2^15 <= n <= 2^17; single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
 // one workgroup of n / 16 threads around a whole-transform LDS tile, ntt32_big.hpp); everything else (and FHE_EXT32=0)
@@ -11,8 +12,7 @@
 // spilled, 3.8 M NTT/s against 4.8 M on the 61-bit two-pass kernels).  Same values, word for word: every result is canonical
 // modulo the same q.
 // NOT covered, and therefore on the 61-bit kernels (stated here and in include/fhe_ntt.h): moduli between
-// 2^32 / 25 (2^27.36) and 2^32 — the no-conditional-subtraction butterflies need 25 q in a word; a Harvey form with 4 q < 2^32
-// would reach 2^30 —, n < 2^8 and n >= 2^18 (a second strided level), and n = 8192 / 16384 run as ONE 1024-thread workgroup per
+// 2^30 and 2^32 (4 q no longer fits a word), n < 2^8 and n >= 2^18 (a second strided level), and n = 8192 / 16384 run as ONE 1024-thread workgroup per
 // CU (4.7 / 3.9 TB/s where the 256-thread sizes reach 5.5 - 5.8).
 //   sq_forward_kernel   n words in (natural order) -> forward transform -> n words out (the reference's bit-reversed order)
 //   sq_inverse_kernel   the inverse, n^-1 folded in
@@ -52,49 +52,51 @@ __device__ __forceinline__ void sq_exchange2(u32 (&va)[16], u32 (&vb)[16], u32 *
 }
 
 // forward stages of two polynomials in lockstep, ct32_loose (canonical inputs: values end below (1 + 2 LP) q <= 25 q)
-template <int LP>
+// LOOSE (25 q < 2^32): ct32_loose, no conditional subtraction; otherwise (4 q < 2^32: moduli up to 2^30) Harvey's
+// butterflies with one conditional subtraction each, values in [0, 4q) throughout
+template <int LP, bool LOOSE>
 __device__ __forceinline__ void sq_fwd2(u32 (&va)[16], u32 (&vb)[16], u32 *la, u32 *lb, const Tw32 *ltw, const Tw32 *gtw, u32 w, u32 tf,
                                         u32 q, u32 q2) {
     using C = ContigCfg<LP>;
     Tw32 t[15];
     load_tw32<C::R0>(t, gtw, 1u);
-    round_fwd32_tw<C::R0, 0, true>(va, t, q, q2);
-    round_fwd32_tw<C::R0, 0, true>(vb, t, q, q2);
+    round_fwd32_tw<C::R0, 0, LOOSE>(va, t, q, q2);
+    round_fwd32_tw<C::R0, 0, LOOSE>(vb, t, q, q2);
     {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         load_tw32<4>(t, C::in_lds(1) ? ltw : gtw, (1u << LS) + (tf >> A));
         sq_exchange2<LP, C::A0, A, true>(va, vb, la, lb, w, tf);
-        round_fwd32_tw<4, 0, true>(va, t, q, q2);
-        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(va, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(vb, t, q, q2);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         load_tw32<4>(t, C::in_lds(2) ? ltw : gtw, (1u << LS) + (tf >> A));
         sq_exchange2<LP, C::a_of(1), A, false>(va, vb, la, lb, w, tf);
-        round_fwd32_tw<4, 0, true>(va, t, q, q2);
-        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(va, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(vb, t, q, q2);
     }
     static_assert(C::NR >= 2 && C::NR <= 3, "256 .. 4096 points");
 }
 
 // forward stages of one polynomial (window [LP-4, LP) -> [0,4)); FRESH: nobody has touched the tile
-template <int LP>
+template <int LP, bool LOOSE>
 __device__ __forceinline__ void sq_fwd1(u32 (&v)[16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 w, u32 tf, u32 q, u32 q2) {
     using C = ContigCfg<LP>;
     Tw32 t[15];
     load_tw32<C::R0>(t, gtw, 1u);
-    round_fwd32_tw<C::R0, 0, true>(v, t, q, q2);
+    round_fwd32_tw<C::R0, 0, LOOSE>(v, t, q, q2);
     {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         load_tw32<4>(t, C::in_lds(1) ? ltw : gtw, (1u << LS) + (tf >> A));
         exchange32<LP, C::A0, A, true>(v, lds, w, tf);
-        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(v, t, q, q2);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         load_tw32<4>(t, C::in_lds(2) ? ltw : gtw, (1u << LS) + (tf >> A));
         exchange32<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(v, t, q, q2);
     }
 }
 // inverse stages (gs32, values below 2q throughout): window [0,4) -> [LP-4, LP); FRESH: the tile is untouched
@@ -154,7 +156,7 @@ __device__ __forceinline__ SqLds sq_lds(unsigned char *smem, const Tw32 *gtw, u3
 }
 
 // ---- forward: natural order in, the reference's bit-reversed order out --------------------------------------------------
-template <int LP>
+template <int LP, bool LOOSE>
 __global__ __launch_bounds__(256) void sq_forward_kernel(SmallQArgs a) {
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void sq_forward_kernel(SmallQArgs a) {
     const u64 row = min(R0 + w, a.rows - 1);                    // idle units redo the last row and store nothing
     u32 v[16];
     sq_load_natural<LP>(v, a.a + row * C::M, tf, a.q, a.bq);
-    sq_fwd1<LP>(v, l.tile_a, l.ltw, a.tw_fwd, w, tf, a.q, 2u * a.q);
+    sq_fwd1<LP, LOOSE>(v, l.tile_a, l.ltw, a.tw_fwd, w, tf, a.q, 2u * a.q);
     // window [0,4): register k = output word 16 tf + k.  Through the tile so that a wave stores 512 contiguous bytes
     __syncthreads();
 #pragma unroll
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void sq_inverse_kernel(SmallQArgs a) {
 // ring_nq.rs:586-607 with its cached evals: an operand flagged as evals (flags bit 0 / 1) is read as such (no forward
 // transform); c_evals / a_evals / b_evals, when given, receive the canonical transforms of the product and of the operands
 // (ring_nq.rs:568-573,606).  NTT-domain rows move through the tile so that a wave touches 512 contiguous bytes.
-template <int LP>
+template <int LP, bool LOOSE>
 __global__ __launch_bounds__(256) void sq_rq_mul_kernel(SmallQArgs a) {
     using C = ContigCfg<LP>;
     using K = SqCfg<LP>;
@@ -246,12 +248,12 @@ __global__ __launch_bounds__(256) void sq_rq_mul_kernel(SmallQArgs a) {
     if (a.flags == 0u) {
         sq_load_natural<LP>(va, a.a + row * C::M, tf, q, a.bq);
         sq_load_natural<LP>(vb, a.b + row * C::M, tf, q, a.bq);
-        sq_fwd2<LP>(va, vb, tile_a, tile_b, ltw, a.tw_fwd, w, tf, q, q2);
+        sq_fwd2<LP, LOOSE>(va, vb, tile_a, tile_b, ltw, a.tw_fwd, w, tf, q, q2);
     } else {
         if (a.flags & 1u) load_evals(va, a.a + row * C::M, tile_a);
-        else { sq_load_natural<LP>(va, a.a + row * C::M, tf, q, a.bq); sq_fwd1<LP>(va, tile_a, ltw, a.tw_fwd, w, tf, q, q2); }
+        else { sq_load_natural<LP>(va, a.a + row * C::M, tf, q, a.bq); sq_fwd1<LP, LOOSE>(va, tile_a, ltw, a.tw_fwd, w, tf, q, q2); }
         if (a.flags & 2u) load_evals(vb, a.b + row * C::M, tile_b);
-        else { sq_load_natural<LP>(vb, a.b + row * C::M, tf, q, a.bq); sq_fwd1<LP>(vb, tile_b, ltw, a.tw_fwd, w, tf, q, q2); }
+        else { sq_load_natural<LP>(vb, a.b + row * C::M, tf, q, a.bq); sq_fwd1<LP, LOOSE>(vb, tile_b, ltw, a.tw_fwd, w, tf, q, q2); }
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {                              // canonical: what the evals outputs hold
@@ -291,7 +293,7 @@ __device__ __forceinline__ void sq_big_load(u32 (&v)[1][16], const u64 *__restri
 #pragma unroll
     for (int k = 0; k < 16; k++) v[0][k] = csub_u32(barrett2p_32((u32)src[(u32)k * Big32<LP>::TH + tf], q, bq), q);
 }
-template <int LP>
+template <int LP, bool LOOSE>
 __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_forward_kernel(SmallQArgs a) {
     using C = Big32<LP>;
     static_assert(C::VT == 1, "one register window per thread");
@@ -303,7 +305,7 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_forward_kernel(SmallQA
     const u64 row = blockIdx.x;
     u32 v[1][16];
     sq_big_load<LP>(v, a.a + row * C::M, tf, a.q, a.bq);
-    fwd_big<LP, 0>(v, lds, ltw, a.tw_fwd, tf, a.q, 2u * a.q, a.bq);
+    fwd_big<LP, 0, 1, true, LOOSE>(v, lds, ltw, a.tw_fwd, tf, a.q, 2u * a.q, a.bq);
     __syncthreads();                                            // window [0,4) out through the tile: 512 contiguous bytes per wave
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[pad16(tf * 16u + k)] = csub_u32(barrett2p_32(v[0][k], a.q, a.bq), a.q);
@@ -332,7 +334,7 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_inverse_kernel(SmallQA
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(mul_shoup32(v[0][k], a.ninv, a.q), a.q);
 }
-template <int LP>
+template <int LP, bool LOOSE>
 __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQArgs a) {
     using C = Big32<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -362,9 +364,9 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQAr
     };
     u32 va[1][16], vb[1][16];
     if (a.flags & 1u) load_evals(va, a.a + row * C::M);
-    else { sq_big_load<LP>(va, a.a + row * C::M, tf, q, a.bq); fwd_big<LP, 0>(va, lds, ltw, a.tw_fwd, tf, q, q2, a.bq); }
+    else { sq_big_load<LP>(va, a.a + row * C::M, tf, q, a.bq); fwd_big<LP, 0, 1, true, LOOSE>(va, lds, ltw, a.tw_fwd, tf, q, q2, a.bq); }
     if (a.flags & 2u) load_evals(vb, a.b + row * C::M);
-    else { sq_big_load<LP>(vb, a.b + row * C::M, tf, q, a.bq); fwd_big<LP, 0>(vb, lds, ltw, a.tw_fwd, tf, q, q2, a.bq); }
+    else { sq_big_load<LP>(vb, a.b + row * C::M, tf, q, a.bq); fwd_big<LP, 0, 1, true, LOOSE>(vb, lds, ltw, a.tw_fwd, tf, q, q2, a.bq); }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         va[0][k] = csub_u32(barrett2p_32(va[0][k], q, a.bq), q);
@@ -397,7 +399,7 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQAr
 // were built first: N = 2^16 forward 1.42 ms per 4096 polynomials (their block pass bound by butterflies: 0.84 ms) against
 // 1.21 ms with 4096-point blocks, where both passes run at the memory system's rate.)
 constexpr int kSqBlockLog = 12;
-template <int LA>
+template <int LA, bool LOOSE>
 __global__ __launch_bounds__(256) void sq2_strided_fwd_kernel(SmallQArgs a) {
     constexpr u32 M = 1u << kSqBlockLog, R = 1u << LA;
     const u64 row = blockIdx.x / (M / 256);
@@ -414,7 +416,10 @@ __global__ __launch_bounds__(256) void sq2_strided_fwd_kernel(SmallQArgs a) {
         for (int g = 0; g < (1 << s); g++) {
             const Tw32 t = a.tw_fwd[(1u << s) + g];
 #pragma unroll
-            for (int l = 0; l < span; l++) ct32_loose(v[g * 2 * span + l], v[g * 2 * span + l + span], t, q, q2);
+            for (int l = 0; l < span; l++) {
+                if constexpr (LOOSE) ct32_loose(v[g * 2 * span + l], v[g * 2 * span + l + span], t, q, q2);
+                else ct32(v[g * 2 * span + l], v[g * 2 * span + l + span], t, q, q2);
+            }
         }
     }
     u32 *__restrict__ dst = a.mid + (row << (kSqBlockLog + LA)) + c;
@@ -461,6 +466,7 @@ __device__ __forceinline__ void sq_stage_block(Tw32 *ltw, const Tw32 *__restrict
     }
 }
 // block `blk` of row `row`: u32 intermediate (natural order) -> 12 stages -> the block's 4096 output words
+template <bool LOOSE>
 __global__ __launch_bounds__(256) void sq2_block_fwd_kernel(SmallQArgs a, u32 la) {
     constexpr int LP = kSqBlockLog;
     using C = ContigCfg<LP>;
@@ -481,13 +487,13 @@ __global__ __launch_bounds__(256) void sq2_block_fwd_kernel(SmallQArgs a, u32 la
     for (int k = 0; k < 16; k++) v[k] = src[(u32)k * C::TPB + tf];
     Tw32 t[15];
     load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
-    round_fwd32_tw<C::R0, 0, true>(v, t, q, q2);
+    round_fwd32_tw<C::R0, 0, LOOSE>(v, t, q, q2);
     load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
     exchange32<LP, C::A0, C::a_of(1), true>(v, lds, 0u, tf);
-    round_fwd32_tw<4, 0, true>(v, t, q, q2);
+    round_fwd32_tw<4, 0, LOOSE>(v, t, q, q2);
     load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
     exchange32<LP, C::a_of(1), C::a_of(2), false>(v, lds, 0u, tf);
-    round_fwd32_tw<4, 0, true>(v, t, q, q2);
+    round_fwd32_tw<4, 0, LOOSE>(v, t, q, q2);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[pad16(tf * 16u + k)] = csub_u32(barrett2p_32(v[k], q, a.bq), q);
@@ -532,6 +538,7 @@ __global__ __launch_bounds__(256) void sq2_block_inv_kernel(SmallQArgs a, u32 la
 // the MIDDLE of Rq x Rq at the two-pass sizes: block-forward(a), block-forward(b) in lockstep, pointwise Montgomery
 // product, block-inverse — on one 4096-point block; reads the two u32 intermediates of the strided forward passes, leaves
 // the u32 intermediate the strided inverse pass consumes (in place of a's)
+template <bool LOOSE>
 __global__ __launch_bounds__(256) void sq2_block_mul_kernel(SmallQArgs a, u32 la) {
     constexpr int LP = kSqBlockLog;
     using C = ContigCfg<LP>;
@@ -568,13 +575,13 @@ __global__ __launch_bounds__(256) void sq2_block_mul_kernel(SmallQArgs a, u32 la
         for (int k = 0; k < 16; k++) v[k] = mid[base + (u32)k * C::TPB + tf];
         Tw32 t[15];
         load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
-        round_fwd32_tw<C::R0, 0, true>(v, t, q, q2);
+        round_fwd32_tw<C::R0, 0, LOOSE>(v, t, q, q2);
         load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
         exchange32<LP, C::A0, C::a_of(1), true>(v, tile, 0u, tf);
-        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(v, t, q, q2);
         load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
         exchange32<LP, C::a_of(1), C::a_of(2), false>(v, tile, 0u, tf);
-        round_fwd32_tw<4, 0, true>(v, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(v, t, q, q2);
     };
     u32 va[16], vb[16];
     Tw32 t[15];
@@ -585,16 +592,16 @@ __global__ __launch_bounds__(256) void sq2_block_mul_kernel(SmallQArgs a, u32 la
             vb[k] = a.mid_b[base + (u32)k * C::TPB + tf];
         }
         load_tw32<C::R0>(t, a.tw_fwd, (1u << la) + blk);
-        round_fwd32_tw<C::R0, 0, true>(va, t, q, q2);
-        round_fwd32_tw<C::R0, 0, true>(vb, t, q, q2);
+        round_fwd32_tw<C::R0, 0, LOOSE>(va, t, q, q2);
+        round_fwd32_tw<C::R0, 0, LOOSE>(vb, t, q, q2);
         load_tw32<4>(t, C::in_lds(1) ? ltw : a.tw_fwd, sq_block_t0<LP, 1>(la, blk, tf >> C::a_of(1)));
         sq_exchange2<LP, C::A0, C::a_of(1), true>(va, vb, la_tile, lb_tile, 0u, tf);
-        round_fwd32_tw<4, 0, true>(va, t, q, q2);
-        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(va, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(vb, t, q, q2);
         load_tw32<4>(t, C::in_lds(2) ? ltw : a.tw_fwd, sq_block_t0<LP, 2>(la, blk, tf >> C::a_of(2)));
         sq_exchange2<LP, C::a_of(1), C::a_of(2), false>(va, vb, la_tile, lb_tile, 0u, tf);
-        round_fwd32_tw<4, 0, true>(va, t, q, q2);
-        round_fwd32_tw<4, 0, true>(vb, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(va, t, q, q2);
+        round_fwd32_tw<4, 0, LOOSE>(vb, t, q, q2);
     } else {
         if (a.flags & 1u) load_evals(va, a.a, la_tile); else forward1(va, a.mid, la_tile);
         if (a.flags & 2u) load_evals(vb, a.b, lb_tile); else forward1(vb, a.mid_b, lb_tile);
@@ -630,9 +637,11 @@ __global__ __launch_bounds__(256) void sq2_block_mul_kernel(SmallQArgs a, u32 la
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
+// q < 2^30: 4 q fits a word (Harvey's butterflies); q < 2^32 / 25: twelve stages without any conditional subtraction
 bool smallq_supported(uint64_t q, unsigned log_n) {
-    return q >= 3 && (q & 1) && q * 25 < (1ull << 32) && log_n >= 8 && log_n <= 17;
+    return q >= 3 && (q & 1) && q < (1ull << 30) && log_n >= 8 && log_n <= 17;
 }
+bool smallq_loose(uint64_t q) { return q * 25 < (1ull << 32); }
 size_t smallq_scratch_bytes(unsigned log_n, uint64_t rows) { return log_n > 14 ? (rows << log_n) * 4 : 0; }      // per operand
 
 template <typename K>
@@ -645,6 +654,7 @@ static hipError_t sq_launch(K kernel, const char *name, int lp, size_t lds, unsi
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError();
 }
+// KERNEL<LP>: an alias template with the butterfly form already chosen (the _l / _h variables below)
 #define FHE_SQ_SWITCH(KERNEL, NAME, TILES, TWS)                                                                                         \
     switch (log_n) {                                                                                                                    \
         case 8: return sq_launch(KERNEL<8>, NAME, 8, TILES * SqCfg<8>::TILE_BYTES + TWS * SqCfg<8>::TW_BYTES, ContigCfg<8>::W, a, st);      \
@@ -690,12 +700,29 @@ static hipError_t sq2_launch(KS strided, KB block, bool forward, int log_n, cons
     if (hipError_t e = run_block()) return e;
     return run_strided();
 }
+template <int LP> static constexpr auto sq_forward_l = sq_forward_kernel<LP, true>;
+template <int LP> static constexpr auto sq_forward_h = sq_forward_kernel<LP, false>;
+template <int LP> static constexpr auto sq_big_forward_l = sq_big_forward_kernel<LP, true>;
+template <int LP> static constexpr auto sq_big_forward_h = sq_big_forward_kernel<LP, false>;
+template <int LP> static constexpr auto sq_rq_mul_l = sq_rq_mul_kernel<LP, true>;
+template <int LP> static constexpr auto sq_rq_mul_h = sq_rq_mul_kernel<LP, false>;
+template <int LP> static constexpr auto sq_big_rq_mul_l = sq_big_rq_mul_kernel<LP, true>;
+template <int LP> static constexpr auto sq_big_rq_mul_h = sq_big_rq_mul_kernel<LP, false>;
+template <bool LOOSE>
+static hipError_t launch_sq_forward_t(const SmallQArgs &a, int log_n, hipStream_t st) {
+    if (log_n == 15) return sq2_launch(sq2_strided_fwd_kernel<3, LOOSE>, sq2_block_fwd_kernel<LOOSE>, true, log_n, a, st);
+    if (log_n == 16) return sq2_launch(sq2_strided_fwd_kernel<4, LOOSE>, sq2_block_fwd_kernel<LOOSE>, true, log_n, a, st);
+    if (log_n == 17) return sq2_launch(sq2_strided_fwd_kernel<5, LOOSE>, sq2_block_fwd_kernel<LOOSE>, true, log_n, a, st);
+    if constexpr (LOOSE) {
+        FHE_SQ_BIG(sq_big_forward_l, "sq_forward", 1)
+        FHE_SQ_SWITCH(sq_forward_l, "sq_forward", 1, 1)
+    } else {
+        FHE_SQ_BIG(sq_big_forward_h, "sq_forward", 1)
+        FHE_SQ_SWITCH(sq_forward_h, "sq_forward", 1, 1)
+    }
+}
 hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st) {
-    if (log_n == 15) return sq2_launch(sq2_strided_fwd_kernel<3>, sq2_block_fwd_kernel, true, log_n, a, st);
-    if (log_n == 16) return sq2_launch(sq2_strided_fwd_kernel<4>, sq2_block_fwd_kernel, true, log_n, a, st);
-    if (log_n == 17) return sq2_launch(sq2_strided_fwd_kernel<5>, sq2_block_fwd_kernel, true, log_n, a, st);
-    FHE_SQ_BIG(sq_big_forward_kernel, "sq_forward", 1)
-    FHE_SQ_SWITCH(sq_forward_kernel, "sq_forward", 1, 1)
+    return a.loose ? launch_sq_forward_t<true>(a, log_n, st) : launch_sq_forward_t<false>(a, log_n, st);
 }
 hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) {
     if (log_n == 15) return sq2_launch(sq2_strided_inv_kernel<3>, sq2_block_inv_kernel, false, log_n, a, st);
@@ -704,8 +731,8 @@ hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) {
     FHE_SQ_BIG(sq_big_inverse_kernel, "sq_inverse", 1)
     FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1)
 }
-template <typename KF, typename KI>
-static hipError_t sq2_mul_launch(KF sfwd, KI sinv, int log_n, const SmallQArgs &a, hipStream_t st) {
+template <typename KF, typename KI, typename KM>
+static hipError_t sq2_mul_launch(KF sfwd, KI sinv, KM smid, int log_n, const SmallQArgs &a, hipStream_t st) {
     const unsigned la = (unsigned)(log_n - kSqBlockLog);
     if (a.rows == 0) return hipSuccess;
     if (!a.mid || !a.mid_b) return hipErrorInvalidValue;
@@ -723,19 +750,28 @@ static hipError_t sq2_mul_launch(KF sfwd, KI sinv, int log_n, const SmallQArgs &
     if (hipError_t e = hipGetLastError()) return e;
     {
         KernelTimer kt("sq2_block_mul", log_n, st);
-        hipLaunchKernelGGL(sq2_block_mul_kernel, dim3((unsigned)gb), dim3(256), lds, st, a, la);
+        hipLaunchKernelGGL(smid, dim3((unsigned)gb), dim3(256), lds, st, a, la);
     }
     if (hipError_t e = hipGetLastError()) return e;
     KernelTimer kt("sq2_strided_inv", log_n, st);
     hipLaunchKernelGGL(sinv, dim3((unsigned)gs), dim3(256), 0, st, inv);
     return hipGetLastError();
 }
+template <bool LOOSE>
+static hipError_t launch_sq_rq_mul_t(const SmallQArgs &a, int log_n, hipStream_t st) {
+    if (log_n == 15) return sq2_mul_launch(sq2_strided_fwd_kernel<3, LOOSE>, sq2_strided_inv_kernel<3>, sq2_block_mul_kernel<LOOSE>, log_n, a, st);
+    if (log_n == 16) return sq2_mul_launch(sq2_strided_fwd_kernel<4, LOOSE>, sq2_strided_inv_kernel<4>, sq2_block_mul_kernel<LOOSE>, log_n, a, st);
+    if (log_n == 17) return sq2_mul_launch(sq2_strided_fwd_kernel<5, LOOSE>, sq2_strided_inv_kernel<5>, sq2_block_mul_kernel<LOOSE>, log_n, a, st);
+    if constexpr (LOOSE) {
+        FHE_SQ_BIG(sq_big_rq_mul_l, "sq_rq_mul", 2)
+        FHE_SQ_SWITCH(sq_rq_mul_l, "sq_rq_mul", 2, 2)
+    } else {
+        FHE_SQ_BIG(sq_big_rq_mul_h, "sq_rq_mul", 2)
+        FHE_SQ_SWITCH(sq_rq_mul_h, "sq_rq_mul", 2, 2)
+    }
+}
 hipError_t launch_sq_rq_mul(const SmallQArgs &a, int log_n, hipStream_t st) {
-    if (log_n == 15) return sq2_mul_launch(sq2_strided_fwd_kernel<3>, sq2_strided_inv_kernel<3>, log_n, a, st);
-    if (log_n == 16) return sq2_mul_launch(sq2_strided_fwd_kernel<4>, sq2_strided_inv_kernel<4>, log_n, a, st);
-    if (log_n == 17) return sq2_mul_launch(sq2_strided_fwd_kernel<5>, sq2_strided_inv_kernel<5>, log_n, a, st);
-    FHE_SQ_BIG(sq_big_rq_mul_kernel, "sq_rq_mul", 2)
-    FHE_SQ_SWITCH(sq_rq_mul_kernel, "sq_rq_mul", 2, 2)
+    return a.loose ? launch_sq_rq_mul_t<true>(a, log_n, st) : launch_sq_rq_mul_t<false>(a, log_n, st);
 }
 #undef FHE_SQ_SWITCH
 #undef FHE_SQ_BIG

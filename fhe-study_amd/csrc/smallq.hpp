@@ -20,9 +20,11 @@ struct SmallQArgs {
     u64 mu;                        // floor(2^64 / q)
     uint32_t *mid, *mid_b;         // two-pass sizes (n > 2^14): rows * n u32 words between the passes, per operand (smallq_scratch_bytes)
     u64 rows;
+    uint32_t loose;                // 25 q < 2^32: forward butterflies without conditional subtractions (smallq_loose)
 };
 
 bool smallq_supported(uint64_t q, unsigned log_n);
+bool smallq_loose(uint64_t q);
 size_t smallq_scratch_bytes(unsigned log_n, uint64_t rows);
 hipError_t launch_sq_forward(const SmallQArgs &a, int log_n, hipStream_t st);
 hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st);

@@ -13,8 +13,9 @@
  *     VALUES (the `v` of `Zq{q,v}`, arith/src/zq.rs:6-10), canonical: v < q.
  *   - The caller owns every buffer; `out` may alias `in` (in-place).
  *   - The arithmetic behind an entry point is the library's choice and never
- *     shows in the words: moduli up to 2^62 run on 64-bit Shoup butterflies; a
- *     modulus below 2^32 / 25 (e.g. the reference's test moduli 65537, 12289)
+ *     shows in the words: moduli up to 2^62 run on 64-bit Shoup butterflies (a
+ *     pseudo-Mersenne one on five-multiply butterflies: fhe_ntt_plan_arithmetic); a
+ *     modulus below 2^30 (e.g. the reference's test moduli 65537, 12289)
  *     and the keyed products whose integers are small run in 32-bit words on
  *     the same tables (env FHE_EXT32=0 disables that; results are identical).
  *   - No function unwinds or aborts: every failure is a negative FHE_E_* code
@@ -103,8 +104,9 @@ int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan);
  *   FHE_ARITH_SHOUP61   q < 2^61: the same with compile-time value bounds (a correction every other stage)
  *   FHE_ARITH_PMERSENNE q = 2^k - delta, 56 <= k <= 61, delta <= 2^(k-39) (2^61 - 2^21 + 1 is one): split
  *                       multiplicand, no quotient, 5 multiplies (FHE_PM=0 in the environment selects SHOUP61 instead)
- *   FHE_ARITH_WORD32    q < 2^32/25 and 2^8 <= n <= 2^17: one 32-bit word per coefficient (FHE_EXT32=0: SHOUP61).
- *                       Moduli between 2^32/25 and 2^32, and n outside that range, are NOT covered by this form.
+ *   FHE_ARITH_WORD32    q < 2^30 and 2^8 <= n <= 2^17: one 32-bit word per coefficient (FHE_EXT32=0: SHOUP61); without
+ *                       any conditional subtraction in the forward transform below 2^32/25, Harvey's form above.
+ *                       Moduli between 2^30 and 2^32, and n outside that range, are NOT covered by this form.
  * Results are the same words in every case.  Returns a negative FHE_E_* for a NULL plan. */
 #define FHE_ARITH_SHOUP62 0
 #define FHE_ARITH_SHOUP61 1

@@ -343,6 +343,65 @@ def test_small_modulus_kernels_at_the_top_of_their_range(pkg, oracle, need_gpu, 
             assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, want)), (q, n)
 
 
+def _prime_below(limit, step):
+    """largest prime q < limit with q = 1 (mod step)"""
+    def is_prime(n):
+        if n < 2:
+            return False
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            if n % p == 0:
+                return n == p
+        d, r = n - 1, 0
+        while d % 2 == 0:
+            d //= 2
+            r += 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            x = pow(a, d, n)
+            if x in (1, n - 1):
+                continue
+            for _ in range(r - 1):
+                x = x * x % n
+                if x == n - 1:
+                    break
+            else:
+                return False
+        return True
+
+    k = (limit - 2) // step
+    while not is_prime(k * step + 1):
+        k -= 1
+    return k * step + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [28, 29, 30])
+def test_small_modulus_kernels_between_2_27_and_2_30(pkg, oracle, need_gpu, bits):
+    """round 3: moduli between 2^32 / 25 and 2^30 run in 32-bit words too, on Harvey's butterflies (4 q fits the word; one
+    conditional subtraction per butterfly instead of none).  The largest NTT-friendly prime below 2^bits — 4 q within
+    a few thousand of 2^32 at bits = 30 — at every kernel shape: 256 threads x W polynomials, the one-workgroup sizes
+    8192 / 16384, the two-pass sizes; forward, inverse, product with every evals combination, extreme inputs."""
+    q = _prime_below(1 << bits, 1 << 18)
+    assert 25 * q >= 1 << 32 and 4 * q < 1 << 32
+    for n in (256, 2048, 4096, 8192, 16384, 1 << 15, 1 << 16, 1 << 17):
+        a = _extreme_rows(oracle, q, n, 5000 + n)
+        b = a[::-1].copy()
+        plan = pkg.Plan(q, n)
+        assert plan.arithmetic() == (3 if os.environ.get("FHE_EXT32", "1")[:1] != "0" else 1)
+        A = plan.forward(a)
+        assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (q, n)
+        want = oracle.rq_mul(q, n, a, b)
+        ae, be = want[2], want[3]
+        for got in (plan.rq_mul(a, b), plan.rq_mul(ae, b, a_is_evals=True), plan.rq_mul(a, be, b_is_evals=True),
+                    plan.rq_mul(ae, be, a_is_evals=True, b_is_evals=True)):
+            assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, want)), (q, n)
+    # 2^30 itself is past the form: 61-bit kernels, same words
+    q31 = _prime_below(1 << 31, 1 << 18)
+    assert pkg.Plan(q31, 4096).arithmetic() == 1
+    a = _extreme_rows(oracle, q31, 4096, 6000)
+    assert np.array_equal(pkg.Plan(q31, 4096).forward(a).reshape(-1), oracle.ntt(q31, 4096, a).reshape(-1))
+
+
 @pytest.mark.gpu
 def test_release_stream_workspace_frees_every_slot(pkg, oracle, need_gpu):
     """the small-modulus two-pass sizes keep their u32 intermediates in a library workspace of their own slot;

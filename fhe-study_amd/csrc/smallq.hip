@@ -6,13 +6,13 @@
 // butterflies of ntt32_rounds.hpp: 3 multiplies + 3 additions and, below 2^32 / 25, no conditional subtraction on the forward side
 // (between 2^32 / 25 and 2^30 — round 3 — Harvey's form with one per butterfly: 4 q fits the word).  The
 // interface stays 64-bit words; a transform is then bound by its 16 n bytes of traffic instead of by multiplier issue.
-// Two passes with a u32 intermediate for 2^15 <= n <= 2^17; single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
+// Two passes with a u32 intermediate for 2^15 <= n <= 2^18; single-workgroup sizes 2^8 <= n <= 2^14 (256 threads holding W = 4096 / n polynomials up to n = 4096; n = 8192 / 16384 as
 // one workgroup of n / 16 threads around a whole-transform LDS tile, ntt32_big.hpp); everything else (and FHE_EXT32=0)
 // keeps the 61-bit kernels (2^15 points — 1024 threads x 32 coefficients in 128 registers — were tried: 64-143 registers
 // spilled, 3.8 M NTT/s against 4.8 M on the 61-bit two-pass kernels).  Same values, word for word: every result is canonical
 // modulo the same q.
 // NOT covered, and therefore on the 61-bit kernels (stated here and in include/fhe_ntt.h): moduli between
-// 2^30 and 2^32 (4 q no longer fits a word), n < 2^8 and n >= 2^18 (a second strided level), and n = 8192 / 16384 run as ONE 1024-thread workgroup per
+// 2^30 and 2^32 (4 q no longer fits a word), n < 2^8 and n >= 2^19 (a second strided level), and n = 8192 / 16384 run as ONE 1024-thread workgroup per
 // CU (4.7 / 3.9 TB/s where the 256-thread sizes reach 5.5 - 5.8).
 //   sq_forward_kernel   n words in (natural order) -> forward transform -> n words out (the reference's bit-reversed order)
 //   sq_inverse_kernel   the inverse, n^-1 folded in
@@ -390,7 +390,7 @@ __global__ __launch_bounds__((Big32<LP>::TH)) void sq_big_rq_mul_kernel(SmallQAr
     for (int k = 0; k < 16; k++) dst[(u32)k * C::TH + tf] = csub_u32(mul_shoup32(va[0][k], scale, q), q);
 }
 
-// ---- two-pass sizes 2^15 <= n <= 2^17 ----------------------------------------------------------------------------------
+// ---- two-pass sizes 2^15 <= n <= 2^18 ----------------------------------------------------------------------------------
 // The first LA = log2(n) - 12 stages pair rows of the 2^LA x 4096 view (uniform twiddles per row pair: an element-wise
 // pass of 2^LA registers per thread, lanes along the columns — bound by its traffic); the remaining 12 stages are 2^LA
 // independent 4096-point blocks (256 threads each; block `blk` after s0 = LA stages reads the table at
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void sq2_block_mul_kernel(SmallQArgs a, u32 la
 // ---- host side ----------------------------------------------------------------------------------------------------------
 // q < 2^30: 4 q fits a word (Harvey's butterflies); q < 2^32 / 25: twelve stages without any conditional subtraction
 bool smallq_supported(uint64_t q, unsigned log_n) {
-    return q >= 3 && (q & 1) && q < (1ull << 30) && log_n >= 8 && log_n <= 17;
+    return q >= 3 && (q & 1) && q < (1ull << 30) && log_n >= 8 && log_n <= 18;
 }
 bool smallq_loose(uint64_t q) { return q * 25 < (1ull << 32); }
 size_t smallq_scratch_bytes(unsigned log_n, uint64_t rows) { return log_n > 14 ? (rows << log_n) * 4 : 0; }      // per operand
@@ -713,6 +713,7 @@ static hipError_t launch_sq_forward_t(const SmallQArgs &a, int log_n, hipStream_
     if (log_n == 15) return sq2_launch(sq2_strided_fwd_kernel<3, LOOSE>, sq2_block_fwd_kernel<LOOSE>, true, log_n, a, st);
     if (log_n == 16) return sq2_launch(sq2_strided_fwd_kernel<4, LOOSE>, sq2_block_fwd_kernel<LOOSE>, true, log_n, a, st);
     if (log_n == 17) return sq2_launch(sq2_strided_fwd_kernel<5, LOOSE>, sq2_block_fwd_kernel<LOOSE>, true, log_n, a, st);
+    if (log_n == 18) return sq2_launch(sq2_strided_fwd_kernel<6, LOOSE>, sq2_block_fwd_kernel<LOOSE>, true, log_n, a, st);
     if constexpr (LOOSE) {
         FHE_SQ_BIG(sq_big_forward_l, "sq_forward", 1)
         FHE_SQ_SWITCH(sq_forward_l, "sq_forward", 1, 1)
@@ -728,6 +729,7 @@ hipError_t launch_sq_inverse(const SmallQArgs &a, int log_n, hipStream_t st) {
     if (log_n == 15) return sq2_launch(sq2_strided_inv_kernel<3>, sq2_block_inv_kernel, false, log_n, a, st);
     if (log_n == 16) return sq2_launch(sq2_strided_inv_kernel<4>, sq2_block_inv_kernel, false, log_n, a, st);
     if (log_n == 17) return sq2_launch(sq2_strided_inv_kernel<5>, sq2_block_inv_kernel, false, log_n, a, st);
+    if (log_n == 18) return sq2_launch(sq2_strided_inv_kernel<6>, sq2_block_inv_kernel, false, log_n, a, st);
     FHE_SQ_BIG(sq_big_inverse_kernel, "sq_inverse", 1)
     FHE_SQ_SWITCH(sq_inverse_kernel, "sq_inverse", 1, 1)
 }
@@ -762,6 +764,7 @@ static hipError_t launch_sq_rq_mul_t(const SmallQArgs &a, int log_n, hipStream_t
     if (log_n == 15) return sq2_mul_launch(sq2_strided_fwd_kernel<3, LOOSE>, sq2_strided_inv_kernel<3>, sq2_block_mul_kernel<LOOSE>, log_n, a, st);
     if (log_n == 16) return sq2_mul_launch(sq2_strided_fwd_kernel<4, LOOSE>, sq2_strided_inv_kernel<4>, sq2_block_mul_kernel<LOOSE>, log_n, a, st);
     if (log_n == 17) return sq2_mul_launch(sq2_strided_fwd_kernel<5, LOOSE>, sq2_strided_inv_kernel<5>, sq2_block_mul_kernel<LOOSE>, log_n, a, st);
+    if (log_n == 18) return sq2_mul_launch(sq2_strided_fwd_kernel<6, LOOSE>, sq2_strided_inv_kernel<6>, sq2_block_mul_kernel<LOOSE>, log_n, a, st);
     if constexpr (LOOSE) {
         FHE_SQ_BIG(sq_big_rq_mul_l, "sq_rq_mul", 2)
         FHE_SQ_SWITCH(sq_rq_mul_l, "sq_rq_mul", 2, 2)

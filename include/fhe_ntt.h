@@ -104,7 +104,7 @@ int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan);
  *   FHE_ARITH_SHOUP61   q < 2^61: the same with compile-time value bounds (a correction every other stage)
  *   FHE_ARITH_PMERSENNE q = 2^k - delta, 56 <= k <= 61, delta <= 2^(k-39) (2^61 - 2^21 + 1 is one): split
  *                       multiplicand, no quotient, 5 multiplies (FHE_PM=0 in the environment selects SHOUP61 instead)
- *   FHE_ARITH_WORD32    q < 2^30 and 2^8 <= n <= 2^17: one 32-bit word per coefficient (FHE_EXT32=0: SHOUP61); without
+ *   FHE_ARITH_WORD32    q < 2^30 and 2^8 <= n <= 2^18: one 32-bit word per coefficient (FHE_EXT32=0: SHOUP61); without
  *                       any conditional subtraction in the forward transform below 2^32/25, Harvey's form above.
  *                       Moduli between 2^30 and 2^32, and n outside that range, are NOT covered by this form.
  * Results are the same words in every case.  Returns a negative FHE_E_* for a NULL plan. */

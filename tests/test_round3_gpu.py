@@ -403,6 +403,24 @@ def test_small_modulus_kernels_between_2_27_and_2_30(pkg, oracle, need_gpu, bits
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("limit", [1 << 27, 1 << 30])
+def test_small_modulus_n_2_18(pkg, oracle, need_gpu, limit):
+    """round 3: n = 2^18 at a small modulus — six element-wise strided stages (64 registers per thread) + 4096-point blocks
+    — in both butterfly forms; forward, inverse, product with cached evals"""
+    q, n = _prime_below(limit, 1 << 19), 1 << 18
+    a = _extreme_rows(oracle, q, n, 7000)[1:5]
+    b = a[::-1].copy()
+    plan = pkg.Plan(q, n)
+    assert plan.arithmetic() == (3 if os.environ.get("FHE_EXT32", "1")[:1] != "0" else 1)
+    A = plan.forward(a)
+    assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), q
+    assert np.array_equal(plan.inverse(A).reshape(-1), a.reshape(-1)), q
+    want = oracle.rq_mul(q, n, a, b)
+    for got in (plan.rq_mul(a, b), plan.rq_mul(want[2], b, a_is_evals=True)):
+        assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, want)), q
+
+
+@pytest.mark.gpu
 def test_release_stream_workspace_frees_every_slot(pkg, oracle, need_gpu):
     """the small-modulus two-pass sizes keep their u32 intermediates in a library workspace of their own slot;
     fhe_ntt_release_stream_workspace must hand that one back too (it used to free slots 0 and 1 only)"""

@@ -401,11 +401,14 @@ static int check_canonical_dev(const fhe_ntt_plan *plan, const void *d_x, size_t
 // polynomials per launch for two-pass sizes
 static std::mutex g_cfg_lock;
 static size_t g_batch_tile_override = 0;
-// Default: the whole batch in one launch per pass.  Measured on MI355X (r01, n = 2^16,
-// 16384 polynomials): 128-polynomial tiles (64 MiB, Infinity-Cache sized) 9.9 ms, 2048 8.5 ms,
-// untiled 8.3 ms — the cache buys ~13 % on a pure copy (tools/ubench_mall.hip) but short
-// launches lose more in ramp-up and tail than that.
+// Default for the two-pass sizes: 1 GiB of coefficients per launch pair (2048 polynomials at n = 2^16).  Rounds 1-2 ran the
+// whole batch in one launch per pass (VALU-bound kernels: 128-polynomial, Infinity-Cache-sized tiles 9.9 ms per 16384, 2048
+// 8.5 ms, untiled 8.3 ms).  With the passes memory-bound (round 3) the contiguous pass runs 8-11 % faster on a 32 k-workgroup
+// grid that follows its strided pass than on a 1 M-workgroup one: 65536 polynomials at n = 2^16, three repetitions on one box,
+// ms per step: untiled 24.74-25.04, 1024-polynomial tiles 24.26-24.39, 1536 24.08-24.18, 2048 24.01-24.07, 3072 24.00-24.28;
+// tiles the size of the Infinity Cache still lose (256: 26.3, 512: 25.0: launch ramp and tail).
 static constexpr u64 kMaxTilePolys = 1ull << 22;  // keeps every grid below 2^31 workgroups up to n = 2^20
+static constexpr unsigned kTileCoeffLog = 27;      // 2^27 coefficients = 1 GiB per launch pair
 
 u64 fhe_batch_tile_for(const fhe_ntt_plan *plan) {
     size_t ov;
@@ -420,8 +423,9 @@ u64 fhe_batch_tile_for(const fhe_ntt_plan *plan) {
         }();
         ov = env;
     }
-    (void)plan;
-    return ov ? ov : kMaxTilePolys;
+    if (ov) return ov;
+    if (plan && (int)plan->log_n > fhe::kMaxSinglePassLog && plan->log_n < kTileCoeffLog) return 1ull << (kTileCoeffLog - plan->log_n);
+    return plan && plan->log_n >= kTileCoeffLog ? 1 : kMaxTilePolys;
 }
 
 extern "C" int fhe_ntt_set_batch_tile(size_t polys) {

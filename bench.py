@@ -523,9 +523,13 @@ def main():
 
         eng = pkg.sharding.ShardedNTT(transform)
         full = eng.forward_sharded(rows_fn, gbatch, gather=True)
+        # the same with the shard transformed a quarter at a time, every finished piece on the links while the next is transformed
+        piece = max(1, -(-gbatch // world) // 4)
+        over = eng.forward_sharded(rows_fn, gbatch, gather=True, overlap_rows=piece)
         if rank == 0:
             whole = transform(rows_fn(0, gbatch))
-            out["gather_check"] = {"rows": gbatch, "equal_to_single_rank_transform": bool(torch.equal(full, whole))}
+            out["gather_check"] = {"rows": gbatch, "equal_to_single_rank_transform": bool(torch.equal(full, whole)),
+                                   "overlapped_pieces_of_rows": piece, "overlapped_equal": bool(torch.equal(over, whole))}
 
     if args.allgather and dist is not None and args.config == 5:
         # optional: the one collective of SURVEY.md §8e — every rank's REAL result shard onto every rank — timed on its

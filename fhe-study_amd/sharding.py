@@ -58,9 +58,32 @@ class ShardedNTT:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
-    def forward_sharded(self, full_batch_rows_fn, batch, gather=False):
+    def forward_sharded(self, full_batch_rows_fn, batch, gather=False, overlap_rows=0):
         """full_batch_rows_fn(b0, b1) materialises this rank's input rows (inputs are
-        generated / loaded on the owning rank, never broadcast)."""
+        generated / loaded on the owning rank, never broadcast).
+        overlap_rows = R > 0 (with gather): the shard is transformed R rows at a time and each finished piece is put on the
+        links at once (async all-gather) while the next piece is transformed — the collective is link-bound and an order
+        of magnitude longer than the transform, so a consumer of the gathered batch waits for the links only."""
         b0, b1 = shard_range(batch, self.world, self.rank)
-        local = self.transform(full_batch_rows_fn(b0, b1))
-        return all_gather_rows(local, batch, self.group) if gather else local
+        if not (gather and overlap_rows):
+            local = self.transform(full_batch_rows_fn(b0, b1))
+            return all_gather_rows(local, batch, self.group) if gather else local
+        per = -(-batch // self.world)                      # rows every rank sends (the ragged tail is padded)
+        out, pending = None, []
+        for c0 in range(0, per, overlap_rows):
+            c1 = min(per, c0 + overlap_rows)
+            r0, r1 = min(b1, b0 + c0), min(b1, b0 + c1)     # this rank's real rows of the piece (may be fewer, or none)
+            piece = self.transform(full_batch_rows_fn(r0, r1)) if r1 > r0 else None
+            if out is None:
+                ref = piece if piece is not None else self.transform(full_batch_rows_fn(b0, min(b1, b0 + 1)))
+                n, dt, dev = ref.shape[1], ref.dtype, ref.device
+                out = torch.empty((self.world, per, n), dtype=dt, device=dev)
+            send = torch.zeros((c1 - c0, n), dtype=dt, device=dev)
+            if piece is not None:
+                send[: r1 - r0] = piece
+            stage = torch.empty((self.world * (c1 - c0), n), dtype=dt, device=dev)
+            pending.append((dist.all_gather_into_tensor(stage, send, group=self.group, async_op=True), stage, c0, c1))
+        for work, stage, c0, c1 in pending:
+            work.wait()
+            out[:, c0:c1] = stage.view(self.world, c1 - c0, n)
+        return out.view(self.world * per, n)[:batch]

@@ -296,6 +296,7 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(pkg, need_gpu):
     assert "strong scaling" in out["config"]["workload"]
     assert out["parity"]["mismatching_rows"] == 0 and out["parity"]["ranks_checked"] == 2
     assert out["gather_check"]["rows"] == 513 and out["gather_check"]["equal_to_single_rank_transform"] is True
+    assert out["gather_check"]["overlapped_equal"] is True and out["gather_check"]["overlapped_pieces_of_rows"] == 64
     assert out["allgather"]["rows_per_rank"] == 257 and out["allgather"]["rows_gathered"] == 513
     # value counts the GLOBAL batch once per step
     assert abs(out["value"] - 513 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6

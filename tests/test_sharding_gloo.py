@@ -50,6 +50,10 @@ def _worker(rank, world, port, batch, n, q, out_dir):
     assert local.shape == (b1 - b0, n)
     full = eng.forward_sharded(rows_fn, batch, gather=True)
     np.save(os.path.join(out_dir, f"full_{rank}.npy"), full.numpy())
+    # transform and gather overlapped piece by piece (async collectives): same batch
+    for rows in (1, 2, 5):
+        again = eng.forward_sharded(rows_fn, batch, gather=True, overlap_rows=rows)
+        assert torch.equal(again, full), (rank, rows)
     # the same gather in chunks of rows (several collectives + copies into place): same batch
     for chunk in (1, 2, 3, 64):
         again = pkg.sharding.all_gather_rows(local, batch, chunk_rows=chunk)

@@ -229,3 +229,33 @@ def test_plan_prepare_and_check_switch_need_no_gpu_to_fail_cleanly(pkg):
     if B.device_count() == 0:
         assert L.fhe_ntt_plan_prepare(pkg.Plan(Q16, 8).handle) == B.FHE_E_NO_DEVICE
     assert L.fhe_ntt_set_check_canonical(1) == 0 and L.fhe_ntt_set_check_canonical(0) == 0
+
+
+def test_plan_arithmetic_is_decided_on_the_host(pkg):
+    """fhe_ntt_plan_arithmetic (round 3): which exact form of Zq::mul the kernels run — no device needed.  The
+    pseudo-Mersenne rule is the one fhe-study_amd/arith.py restates (pm_params); FHE_PM / FHE_EXT32 are read once per
+    process, so the expectations follow the environment."""
+    from fhe_study_amd.arith import pm_params
+
+    L, B = pkg.load_library(), pkg.binding
+    assert L.fhe_ntt_plan_arithmetic(None) == B.FHE_E_NULL
+    pm_on = os.environ.get("FHE_PM", "1")[:1] != "0"
+    ext_on = os.environ.get("FHE_EXT32", "1")[:1] != "0"
+    cases = [
+        (Q61, 65536, 2 if pm_on else 1),                      # 2^61 - 2^21 + 1: the headline modulus
+        (2305843009210023937, 4096, 2 if pm_on else 1),       # 2^61 - 28 * 2^17 + 1
+        (1152921504606584833, 4096, 2 if pm_on else 1),       # 2^60 - 2^18 + 1
+        (2305843009208713217, 4096, 1),                       # 2^61 - 38 * 2^17 + 1: delta too large
+        (0x1fffffffff000001, 4096, 1),                        # 2^61 - 2^24 + 1 (a CRT prime of zring.hip): not of the form
+        (4611686018425815041, 4096, 0),                       # just below 2^62
+        (Q16, 4096, 3 if ext_on else 1),
+        (Q16, 64, 1),                                         # n below the 32-bit kernels' range
+        (1073479681, 4096, 3 if ext_on else 1),               # a 30-bit prime: Harvey form of the 32-bit kernels
+        (2147352577, 4096, 1),                                # 31 bits: past them
+    ]
+    for q, n, want in cases:
+        assert (q - 1) % (2 * n) == 0
+        plan = pkg.Plan(q, n)
+        assert plan.arithmetic() == want, (q, n)
+        assert (pm_params(q) is not None) == (want == 2 or (not pm_on and q in (Q61, 2305843009210023937, 1152921504606584833)))
+    assert set(pkg.Plan.ARITH_NAMES) == {0, 1, 2, 3}

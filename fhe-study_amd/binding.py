@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")  # env: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "ntt_kernels.hip", "digit_mac.hip", "digit32.hip", "bfv32.hip", "smallq.hip", "zring.hip", "glue.hip"]
+SOURCES = ["capi.hip", "ntt_kernels.hip", "digit_mac.hip", "digit32.hip", "bfv32.hip", "smallq.hip", "generic63.hip", "zring.hip", "glue.hip"]
 HEADERS = ["ntt_kernels.hpp", "ntt_rounds.hpp", "digit_mac.hpp", "digit32.hpp", "bfv32.hpp", "smallq.hpp", "ntt32_rounds.hpp", "ntt32_big.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp",
            os.path.join("..", "..", "include", "fhe_ntt.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
@@ -265,7 +265,7 @@ class Plan:
         self.handle = h
         self.q, self.n = int(q), int(n)
 
-    ARITH_NAMES = {0: "shoup62", 1: "shoup61", 2: "pseudo-mersenne", 3: "word32"}
+    ARITH_NAMES = {0: "shoup62", 1: "shoup61", 2: "pseudo-mersenne", 3: "word32", 4: "strict63"}
 
     def arithmetic(self):
         """fhe_ntt_plan_arithmetic: which exact form of Zq::mul the transform kernels run for this modulus"""

@@ -84,8 +84,8 @@ static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
     if ((int)log_n > fhe::kMaxLog)
         return fail(FHE_E_BAD_N, "n=%llu: engine supports n <= 2^%d", (unsigned long long)n, fhe::kMaxLog);
     if (q < 3) return fail(FHE_E_BAD_Q, "q=%llu: modulus too small", (unsigned long long)q);
-    if (q >> 62)
-        return fail(FHE_E_BAD_Q, "q=%llu: engine needs q < 2^62 (lazy-reduction headroom)",
+    if (q >> 63)   // the reference's own limit: Zq::add computes self.v + rhs.v in a u64 (zq.rs:225)
+        return fail(FHE_E_BAD_Q, "q=%llu: needs q < 2^63 (as the reference's Zq::add does, zq.rs:225)",
                     (unsigned long long)q);
     if ((q - 1) % (2 * n) != 0)
         return fail(FHE_E_BAD_Q, "q=%llu, n=%llu: (q-1) %% 2n != 0 (ntt.rs:117)",
@@ -322,8 +322,14 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     dp->tw_inv_pm = t.tw_inv_pm;
     dp->ninv_pm = plan->ninv_pm;
     dp->s_ninv_pm = plan->s_ninv_pm;
-    dp->arith = (t.tw_fwd_pm && fhe_pm_enabled()) ? 2 : dp->wide ? 1 : 0;
+    dp->arith = (plan->q >> 62) ? 3 : (t.tw_fwd_pm && fhe_pm_enabled()) ? 2 : dp->wide ? 1 : 0;
     return FHE_OK;
+}
+
+int fhe_keyed_rows_need_q62(const fhe::DevicePlan &dp, const char *who) {
+    if (dp.arith != 3) return FHE_OK;
+    return fail(FHE_E_BAD_Q, "%s: q=%llu: this row accumulates lazily and needs q < 2^62 (transforms, Rq products and the "
+                "element-wise operations cover q < 2^63)", who, (unsigned long long)dp.mod.q);
 }
 
 // FHE_PM=0 (read once): pseudo-Mersenne moduli stay on the Shoup kernels — how the A/B numbers of DESIGN.md were taken
@@ -336,6 +342,7 @@ extern "C" int fhe_ntt_plan_arithmetic(const fhe_ntt_plan *plan) {
     if (!plan) return fail(FHE_E_NULL, "plan is NULL");
     if (fhe::smallq_supported(plan->q, plan->log_n) && fhe_ext32_enabled()) return FHE_ARITH_WORD32;
     if (plan->mod.pm_k != 0 && fhe_pm_enabled()) return FHE_ARITH_PMERSENNE;
+    if (plan->q >> 62) return FHE_ARITH_STRICT63;
     return (plan->q >> 61) == 0 ? FHE_ARITH_SHOUP61 : FHE_ARITH_SHOUP62;
 }
 

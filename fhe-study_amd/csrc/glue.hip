@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const u64 *__restrict__ a, cons
         if (OP == Ew::Add) { r = x + b[i]; r = r >= m.q ? r - m.q : r; }                 // zq.rs:219-231
         else if (OP == Ew::Sub) { const u64 y = b[i]; r = x >= y ? x - y : (m.q + x) - y; }  // zq.rs:259-276
         else if (OP == Ew::Neg) r = x == 0 ? 0 : m.q - x;                                // zq.rs:301-313
-        else r = mul_mod_var(x, s, m);                                                   // zq.rs:315-328
+        else r = (m.q >> 62) ? mul_mod_var63(x, s, m) : mul_mod_var(x, s, m);            // zq.rs:315-328 (uniform branch)
         c[i] = r;
     }
 }
@@ -315,6 +315,7 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_b); REQUIRE_ALIGNED(d_c);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n, rows = batch * k;
     const bool a_ev = flags & FHE_A_IS_EVALS, b_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
@@ -343,6 +344,7 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_p); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n, total = batch * rows;
     const bool a_ev = flags & FHE_A_IS_EVALS, p_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
@@ -388,6 +390,7 @@ extern "C" int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l
     REQUIRE_ALIGNED(d_glev); REQUIRE_ALIGNED(d_v); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     const u64 n = plan->n;
     void *w = nullptr;
     if ((rc = fhe_workspace_get(1, ((u64)l * (k + 1) + batch * l) * n * 8, (hipStream_t)stream, &w)) != FHE_OK) return rc;
@@ -454,6 +457,7 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_ksk); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n;
     const u32 k1 = k + 1, T = k * l;
@@ -533,7 +537,7 @@ static int ksk_args_ok(const char *fn, const fhe_ntt_plan *plan, unsigned k, uns
     return check_decompose_args(fn, plan->q, beta, l);
 }
 extern "C" size_t fhe_glwe_ksk_prepared_words(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l) {
-    if (!plan || k == 0 || l == 0 || beta < 2) return 0;
+    if (!plan || k == 0 || l == 0 || beta < 2 || (plan->q >> 62)) return 0;   // q >= 2^62: the keyed rows reject the plan
     {   // the arguments fhe_glwe_ksk_prepare_dev would reject (check_decompose_args) have no prepared form: 0, and the
         // caller's fhe_last_error() is left as it was
         unsigned bad = beta == 2 ? l > 64 : 0;
@@ -554,6 +558,7 @@ extern "C" int fhe_glwe_ksk_prepare_dev(const fhe_ntt_plan *plan, unsigned k, un
     if (d_ksk == d_prepared) return fhe_fail(FHE_E_INVALID, "fhe_glwe_ksk_prepare_dev: the prepared key cannot overwrite the key");
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 rows = (u64)k * l * (k + 1);
     if (!ks32_usable(plan, k, beta, l)) return fwd(plan, dp, (const u64 *)d_ksk, (u64 *)d_prepared, rows, st);
@@ -574,6 +579,7 @@ extern "C" int fhe_glwe_key_switch_prepared_dev(const fhe_ntt_plan *plan, unsign
     REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_prepared); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
+    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     return ks32_run(plan, dp, k, l, d_glwe, (const uint32_t *)d_prepared, nullptr, d_out, batch, (hipStream_t)stream);
 }
 

@@ -742,6 +742,7 @@ static inline void set_tables(PassArgs &a, const DevicePlan &p, bool inverse) {
 
 hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
                               u64 batch_tile, hipStream_t st) {
+    if (p.arith == 3) return launch_g63_forward(p, in, out, batch, st);   // 2^62 <= q < 2^63: generic63.hip
     PassArgs a{};
     const int L = p.log_n;
     // n < 16: one thread per polynomial on the Shoup tables
@@ -791,7 +792,7 @@ static hipError_t launch_rq_mul_fused_lp(const PassArgs &a, hipStream_t st) {
 hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_evals, const u64 *b_, bool b_is_evals,
                                u64 *c, u64 *c_evals, u64 *a_evals, u64 *b_evals, u64 batch, hipStream_t st) {
     const int L = p.log_n;
-    if (L < 4 || L > kMaxSinglePassLog) return hipErrorNotSupported;
+    if (L < 4 || L > kMaxSinglePassLog || p.arith == 3) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     PassArgs a{};
     set_tables(a, p, false);
@@ -828,7 +829,7 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
                                   u64 *c, u64 *c_evals, u64 *wa, bool keep_a_evals, u64 *wb, bool keep_b_evals,
                                   u64 batch, u64 batch_tile, hipStream_t st) {
     const int L = p.log_n;
-    if (L <= kMaxSinglePassLog || L > kMaxLog) return hipErrorNotSupported;
+    if (L <= kMaxSinglePassLog || L > kMaxLog || p.arith == 3) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
@@ -951,6 +952,7 @@ hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *ou
 // evals_out when that is non-null).
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st) {
+    if (p.arith == 3) return launch_g63_inverse(p, in, in2, evals_out, out, batch, st);
     PassArgs a{};
     const int L = p.log_n;
     const int ar = L < 4 ? (p.wide ? 1 : 0) : p.arith;
@@ -996,7 +998,7 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
 // q < 2^61, < 2q otherwise) for a strided last pass the caller runs itself (zring.hip fuses its epilogue there)
 hipError_t launch_ntt_inverse_first_pass(const DevicePlan &p, const u64 *in, u64 *out, u64 batch, hipStream_t st) {
     const int L = p.log_n;
-    if (L <= kMaxSinglePassLog || L > kMaxLog) return hipErrorNotSupported;
+    if (L <= kMaxSinglePassLog || L > kMaxLog || p.arith == 3) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     PassArgs a{};
     a.tw = p.tw_inv; a.mod = p.mod; a.ninv = p.ninv; a.s_ninv = p.s_ninv; a.log_n = p.log_n;
@@ -1013,6 +1015,7 @@ static inline unsigned ew_grid(u64 count) {
 
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
                                 hipStream_t st) {
+    if (p.arith == 3) return launch_g63_pointwise(p, x, y, z, count, st);
     if (count == 0) return hipSuccess;
     KernelTimer kt("pointwise_mul", 0, st);
     hipLaunchKernelGGL(pointwise_mul_kernel, dim3(ew_grid(count)), dim3(256), 0, st, x, y, z, count, p.mod);

@@ -32,7 +32,7 @@ struct DevicePlan {
     const Tw *tw_fwd_pm = nullptr;
     const Tw *tw_inv_pm = nullptr;
     Tw ninv_pm{}, s_ninv_pm{};
-    int arith = 0;      // the transform kernels' AR: 0 = q < 2^62, 1 = wide, 2 = pseudo-Mersenne
+    int arith = 0;      // the transform kernels' AR: 0 = q < 2^62, 1 = wide, 2 = pseudo-Mersenne; 3 = 2^62 <= q < 2^63 (generic63.hip)
 };
 
 struct PassArgs {
@@ -104,6 +104,12 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a, bool a_is_e
                                   u64 batch, u64 batch_tile, hipStream_t st);
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
                                 hipStream_t st);
+// 2^62 <= q < 2^63 (DevicePlan::arith == 3, generic63.hip): strict butterflies, up to four stages per launch in global
+// memory.  launch_ntt_forward / launch_ntt_inverse / launch_pointwise_mul route here; the fused and transforming-load
+// entry points return hipErrorNotSupported for such a plan and their callers compose these three.
+hipError_t launch_g63_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch, hipStream_t st);
+hipError_t launch_g63_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out, u64 *out, u64 batch, hipStream_t st);
+hipError_t launch_g63_pointwise(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count, hipStream_t st);
 hipError_t launch_fill_synthetic(u64 *out, u64 count, u64 q, u64 seed, u64 first, hipStream_t st);
 hipError_t launch_check_canonical(const u64 *x, u64 count, u64 q, int *d_flag, hipStream_t st);
 // true when the translation unit was compiled with one of its timing-only switches (FHE_*_ABLATE_*): its kernels then

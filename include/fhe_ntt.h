@@ -14,7 +14,8 @@
  *   - The caller owns every buffer; `out` may alias `in` (in-place).
  *   - The arithmetic behind an entry point is the library's choice and never
  *     shows in the words: moduli up to 2^62 run on 64-bit Shoup butterflies (a
- *     pseudo-Mersenne one on five-multiply butterflies: fhe_ntt_plan_arithmetic); a
+ *     pseudo-Mersenne one on five-multiply butterflies: fhe_ntt_plan_arithmetic;
+ *     2^62 <= q < 2^63 on strict ones, several launches per transform); a
  *     modulus below 2^30 (e.g. the reference's test moduli 65537, 12289)
  *     and the keyed products whose integers are small run in 32-bit words on
  *     the same tables (env FHE_EXT32=0 disables that; results are identical).
@@ -62,8 +63,11 @@ extern "C" {
 /* n is not a power of two (assert, arith/src/ntt.rs:116), n < 2 (degenerate
  * in the reference, ntt.rs:139) or n > 2^20 (engine limit). */
 #define FHE_E_BAD_N (-1)
-/* (q-1) % 2n != 0 (assert, ntt.rs:117), q < 3, or q >= 2^62 (engine headroom
- * for lazy reduction; the reference itself needs q < 2^63, zq.rs:225). */
+/* (q-1) % 2n != 0 (assert, ntt.rs:117), q < 3, or q >= 2^63 (where the
+ * reference's own Zq::add overflows, zq.rs:225).  Also returned by the keyed
+ * rows (fhe_tr_*, fhe_glev_*, fhe_glwe_key_switch*) for 2^62 <= q < 2^63:
+ * their accumulators need 4q < 2^64; transforms, products and the element-wise
+ * operations cover the whole range. */
 #define FHE_E_BAD_Q (-2)
 /* the k = 1,2,... search found no primitive 2n-th root (panic, ntt.rs:130). */
 #define FHE_E_NO_ROOT (-3)
@@ -107,11 +111,15 @@ int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan);
  *   FHE_ARITH_WORD32    q < 2^30 and 2^8 <= n <= 2^18: one 32-bit word per coefficient (FHE_EXT32=0: SHOUP61); without
  *                       any conditional subtraction in the forward transform below 2^32/25, Harvey's form above.
  *                       Moduli between 2^30 and 2^32, and n outside that range, are NOT covered by this form.
+ *   FHE_ARITH_STRICT63  2^62 <= q < 2^63 (the top of the reference's range, zq.rs:225): 4q no longer fits a word, so
+ *                       every value is canonical between stages (three conditional subtractions per butterfly) and a
+ *                       transform is ceil(log2 n / 4) plain launches through global memory — exact, not fast
  * Results are the same words in every case.  Returns a negative FHE_E_* for a NULL plan. */
 #define FHE_ARITH_SHOUP62 0
 #define FHE_ARITH_SHOUP61 1
 #define FHE_ARITH_PMERSENNE 2
 #define FHE_ARITH_WORD32 3
+#define FHE_ARITH_STRICT63 4
 int fhe_ntt_plan_arithmetic(const fhe_ntt_plan *plan);
 
 /* ---- transforms: host buffers ------------------------------------------- */

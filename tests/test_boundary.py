@@ -70,7 +70,7 @@ def test_error_codes_mirror_reference_panics(pkg):
         (Q16, 1 << 16, B.FHE_E_BAD_Q),   # assert!((q-1) % n == 0), ntt.rs:117 (2n = 2^17 does not divide 2^16)
         (7, 4, B.FHE_E_BAD_Q),
         (Q61, 1 << 21, B.FHE_E_BAD_N),   # engine limit
-        ((1 << 62) + 1, 4, B.FHE_E_BAD_Q),
+        ((1 << 63) + 9, 4, B.FHE_E_BAD_Q),   # q >= 2^63: the reference's Zq::add overflows there (zq.rs:225)
         (2, 2, B.FHE_E_BAD_Q),
     ]
     for q, n, code in cases:
@@ -258,4 +258,4 @@ def test_plan_arithmetic_is_decided_on_the_host(pkg):
         plan = pkg.Plan(q, n)
         assert plan.arithmetic() == want, (q, n)
         assert (pm_params(q) is not None) == (want == 2 or (not pm_on and q in (Q61, 2305843009210023937, 1152921504606584833)))
-    assert set(pkg.Plan.ARITH_NAMES) == {0, 1, 2, 3}
+    assert set(pkg.Plan.ARITH_NAMES) == {0, 1, 2, 3, 4}     # 4: 2^62 <= q < 2^63, tests/test_round3_gpu.py

@@ -545,3 +545,107 @@ def test_bfv_epilogue_forms_give_the_same_words(pkg, oracle, need_gpu):
         outs[name] = [l for l in r.stdout.splitlines() if l.startswith("digest")]
         assert len(outs[name]) == 4
     assert outs["general"] == outs["f64"] == outs["int"]
+
+
+# ---- the top of the reference's modulus range: 2^62 <= q < 2^63 (csrc/generic63.hip) ------------------------------------
+# Zq::add computes `self.v + rhs.v` in a u64 (arith/src/zq.rs:225): the reference works for every q below 2^63.  The lazy
+# kernels need 4q < 2^64; this range runs strict butterflies in plain kernels, ceil(log2 n / 4) launches per transform.
+Q63_TOP = 9223372036844421121      # largest prime = 1 (mod 2^17) below 2^63
+Q63_BOTTOM = 4611686018429485057   # smallest one above 2^62
+
+
+def test_plans_exist_up_to_the_reference_limit(pkg, oracle):
+    B = pkg.binding
+    for q in (Q63_TOP, Q63_BOTTOM):
+        assert q >> 62 == 1 and (q - 1) % (1 << 17) == 0
+        for n in (2, 16, 1024):
+            plan = pkg.Plan(q, n)
+            r, ri = plan.tables()
+            orr, ori, n_inv, psi = oracle.roots(q, n)
+            assert np.array_equal(r, orr) and np.array_equal(ri, ori)
+            assert plan.info() == dict(q=q, n=n, psi=psi, n_inv=n_inv)
+            assert plan.arithmetic() == 4 and pkg.Plan.ARITH_NAMES[4] == "strict63"
+            assert pkg.load_library().fhe_glwe_ksk_prepared_words(plan.handle, 1, 2, 8) == 0     # the keyed rows reject such a plan
+    with pytest.raises(pkg.FheError) as ei:
+        pkg.Plan((1 << 63) + 2 * 1024 + 1, 1024)       # where the reference's Zq::add would overflow
+    assert ei.value.code == B.FHE_E_BAD_Q
+
+
+def test_strict_arithmetic_never_leaves_a_word():
+    """the bounds generic63.hip and reduce128_63 (zq_device.hpp) rely on, at the extremes of the range"""
+    M = 1 << 64
+    for q in (Q63_TOP, Q63_BOTTOM, (1 << 63) - 1, 1 << 62):
+        onep, r64 = M // q, M % q
+        r64p = (r64 << 64) // q
+        for y in (0, 1, q - 1, q, 2 * q - 1, M - 1, M - q, (1 << 63)):
+            for w in (0, 1, q - 1, q // 2, r64):
+                wp = (w << 64) // q
+                r = y * w - ((y * wp) >> 64) * q            # mul_shoup_lazy: exact, and below 2q < 2^64
+                assert 0 <= r < 2 * q < M and r % q == y * w % q
+            lo = y - ((y * onep) >> 64) * q                 # reduce_any / the low half of reduce128_63
+            assert 0 <= lo < 2 * q and lo % q == y % q
+        # canon2's sign test: x < 2q must satisfy x < 2^63 + q; and a canonical sum / difference stays below 2q
+        assert 2 * q <= (1 << 63) + q
+        for x, y in ((q - 1, q - 1), (0, q - 1), (q - 1, 0), (0, 0)):
+            assert x + y < 2 * q and 0 < x + (q - y) <= 2 * q - 1 + (y == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [Q63_TOP, Q63_BOTTOM])
+def test_moduli_between_2_62_and_2_63(pkg, oracle, need_gpu, q):
+    """forward, inverse, the product with every evals combination and the pointwise product against the oracle, at every
+    grouping of the stages (log2 n = 1 .. 16: short first group of 1, 2, 3 stages or none), on inputs that sit at the
+    top of the range"""
+    for n in (2, 4, 8, 16, 32, 64, 128, 256, 1024, 4096, 8192, 1 << 14, 1 << 16):
+        a = _extreme_rows(oracle, q, n, 6300 + n)
+        b = a[::-1].copy()
+        plan = pkg.Plan(q, n)
+        assert plan.arithmetic() == 4
+        A = plan.forward(a)
+        assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (q, n)
+        assert np.array_equal(plan.inverse(A).reshape(-1), a.reshape(-1)), (q, n)
+        want = oracle.rq_mul(q, n, a, b)
+        ae, be = want[2], want[3]
+        for got in (plan.rq_mul(a, b), plan.rq_mul(ae, b, a_is_evals=True), plan.rq_mul(a, be, b_is_evals=True),
+                    plan.rq_mul(ae, be, a_is_evals=True, b_is_evals=True)):
+            assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, want)), (q, n)
+        pw = plan.pointwise_mul(a, b).reshape(-1)
+        assert np.array_equal(pw, oracle.pointwise_mul(q, a.reshape(-1), b.reshape(-1))), (q, n)
+        if n <= 256:
+            assert pw.tolist() == [int(x) * int(y) % q for x, y in zip(a.reshape(-1), b.reshape(-1))]
+
+
+@pytest.mark.gpu
+def test_elementwise_rows_and_keyed_rows_at_2_63(pkg, oracle, need_gpu):
+    """Zq add / sub / neg / scalar product (zq.rs:219-328) in Python integers; the keyed rows say FHE_E_BAD_Q"""
+    import torch
+
+    q, n, batch = Q63_TOP, 64, 3
+    L, B, chk = pkg.load_library(), pkg.binding, pkg.binding._check
+    plan = pkg.Plan(q, n)
+    rng = np.random.default_rng(63)
+    a = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    b = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    a[0, :5] = [0, q - 1, 1, q // 2, q - 1]
+    b[0, :5] = [0, q - 1, q - 1, q // 2 + 1, 1]
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).cuda()
+    da, db = dev(a), dev(b)
+    dc = torch.empty_like(da)
+    got = lambda: dc.cpu().numpy().view(np.uint64).reshape(-1).tolist()
+    A, Bv = [int(x) for x in a.reshape(-1)], [int(x) for x in b.reshape(-1)]
+    chk(L.fhe_rq_add_dev(plan.handle, da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, None))
+    assert got() == [(x + y) % q for x, y in zip(A, Bv)]
+    chk(L.fhe_rq_sub_dev(plan.handle, da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, None))
+    assert got() == [(x - y) % q for x, y in zip(A, Bv)]
+    chk(L.fhe_rq_neg_dev(plan.handle, da.data_ptr(), dc.data_ptr(), batch, None))
+    assert got() == [(-x) % q for x in A]
+    for s in (0, 1, q - 1, q, (1 << 64) - 1, 0x9E3779B97F4A7C15):
+        chk(L.fhe_rq_mul_by_u64_dev(plan.handle, da.data_ptr(), s, dc.data_ptr(), batch, None))
+        assert got() == [x * (s % q) % q for x in A], s
+    k = 2
+    dk = torch.zeros((batch * k, n), dtype=torch.int64, device="cuda")
+    for rc in (L.fhe_tr_dot_dev(plan.handle, dk.data_ptr(), dk.data_ptr(), dc.data_ptr(), k, batch, 0, None),
+               L.fhe_tr_mul_r_dev(plan.handle, dk.data_ptr(), da.data_ptr(), dk.data_ptr(), k, batch, 0, None)):
+        assert rc == B.FHE_E_BAD_Q
+    assert b"2^62" in L.fhe_last_error()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/kbench.py — kernel-level timing sweeps (diagnostic; not the contract bench).
-usage: python tools/kbench.py [log_n] [batch] [tiles...]"""
+usage: python tools/kbench.py [log_n] [batch] [tiles...]      (env KBENCH_Q: another modulus than 2^61 - 2^21 + 1)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ B = pkg.binding
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 tiles = [int(t) for t in sys.argv[3:]] or [0]
-q, n = pkg.Q61, 1 << log_n
+q, n = int(os.environ.get("KBENCH_Q", pkg.Q61)), 1 << log_n
 plan = pkg.Plan(q, n)
 st = torch.cuda.current_stream().cuda_stream
 x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")

@@ -151,6 +151,9 @@ struct Cfg32 {
 #ifndef FHE_D32_MAC_UNROLL
 #define FHE_D32_MAC_UNROLL 0      // digits of a step whose key loads the multiply phase has in flight at once (0 = all W)
 #endif
+#ifndef FHE_D32_ONEP10
+#define FHE_D32_ONEP10 0          // 1: at n = 1024 a workgroup serves ONE prime (gridDim.y = 2): half the accumulators and tiles
+#endif
 #define FHE_D32_PRAGMA_(x) _Pragma(#x)
 #define FHE_D32_PRAGMA(x) FHE_D32_PRAGMA_(x)
 template <int LP>
@@ -160,10 +163,12 @@ struct Mac32Cfg {
     static constexpr int TH = LP == 12 ? 512 : LP == 10 ? FHE_D32_TH10 : 256;
     static constexpr int WAVES = LP == 10 ? FHE_D32_WAVES10 : 512 / TH;     // __launch_bounds__: minimum waves per SIMD
     static constexpr int W = TH / TPB, PPT = M / TH;
-    static constexpr bool LOCK = PPT <= 4;
+    static constexpr bool ONEP = LP == 10 && FHE_D32_ONEP10 != 0;
+    static constexpr int NP = ONEP ? 1 : 2;                                  // primes per workgroup
+    static constexpr bool LOCK = PPT <= 4 && !ONEP;
     static constexpr size_t TILE_BYTES = (size_t)(W * M + W * M / 16) * 4;
     static constexpr size_t TW_BYTES = Cfg32<LP>::TW_BYTES, LUT_BYTES = Cfg32<LP>::LUT_BYTES;
-    static constexpr size_t LDS_BYTES = 2 * (TILE_BYTES + TW_BYTES + LUT_BYTES);   // per prime: tile, twiddle tile, look-up table
+    static constexpr size_t LDS_BYTES = NP * (TILE_BYTES + TW_BYTES + LUT_BYTES);   // per prime: tile, twiddle tile, look-up table
 };
 
 // ---- key preparation: [T][k1][n] u64 words  ->  [prime][T][half][k1][n] u32, NTT domain (rows = T * 2 * k1) -------------------------
@@ -221,7 +226,8 @@ template <int LP, int NC, int SRC>
 __global__ __launch_bounds__((Mac32Cfg<LP>::TH), (Mac32Cfg<LP>::WAVES)) void digit_mac32_kernel(Ext32Args a) {
     using C = ContigCfg<LP>;
     using K = Mac32Cfg<LP>;
-    constexpr int PPT = K::PPT, W = K::W, TH = K::TH, NP = 2;
+    constexpr int PPT = K::PPT, W = K::W, TH = K::TH, NP = K::NP;
+    const u32 pr0 = K::ONEP ? blockIdx.y : 0u;                      // the first prime this workgroup serves
     static_assert(NP * NC * PPT <= 64, "accumulators");
     static_assert(1 + 2 * LP <= 25, "ct32_loose: the bound of the values after LP stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -243,9 +249,9 @@ __global__ __launch_bounds__((Mac32Cfg<LP>::TH), (Mac32Cfg<LP>::WAVES)) void dig
     const Tw32 *gtw[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        p[i] = a.p[i]; bq[i] = a.bq[i]; gtw[i] = a.tw_fwd[i];
+        p[i] = a.p[pr0 + i]; bq[i] = a.bq[pr0 + i]; gtw[i] = a.tw_fwd[pr0 + i];
         stage_tw32<TH>(ltw_w[i], gtw[i], C::LTW_N, tid);
-        for (u32 e = tid; e < (u32)kLut32Words; e += TH) llut_w[i][e] = a.lut[i][e];
+        for (u32 e = tid; e < (u32)kLut32Words; e += TH) llut_w[i][e] = a.lut[pr0 + i][e];
     }
     __syncthreads();
     const u64 *__restrict__ ct = a.src + b * a.ct_stride;
@@ -321,7 +327,7 @@ __global__ __launch_bounds__((Mac32Cfg<LP>::TH), (Mac32Cfg<LP>::WAVES)) void dig
                     u32 x[PPT];
 #pragma unroll
                     for (int i = 0; i < PPT; i++) x[i] = tile[pr][pad16(u * C::M + j0 + i)];
-                    const u32 *__restrict__ g = a.key32 + (((u64)(pr) * a.T + (t0 + u)) * NC) * n + j0;
+                    const u32 *__restrict__ g = a.key32 + (((u64)(pr0 + pr) * a.T + (t0 + u)) * NC) * n + j0;
 #pragma unroll
                     for (int c = 0; c < NC; c++) {
                         u32 gv[PPT];
@@ -350,17 +356,17 @@ __global__ __launch_bounds__((Mac32Cfg<LP>::TH), (Mac32Cfg<LP>::WAVES)) void dig
 #pragma unroll
                 for (int c = 0; c < NC; c++)
 #pragma unroll
-                    for (int i = 0; i < PPT; i++) acc[pr][c][i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr]);
+                    for (int i = 0; i < PPT; i++) acc[pr][c][i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr0 + pr]);
             pending = 1;
         }
     }
 #pragma unroll
     for (int pr = 0; pr < NP; pr++) {
-        u32 *__restrict__ o = a.part32 + ((((b * a.parts + part) * 2 + pr) * NC) * (u64)n) + j0;
+        u32 *__restrict__ o = a.part32 + ((((b * a.parts + part) * 2 + pr0 + pr) * NC) * (u64)n) + j0;
 #pragma unroll
         for (int c = 0; c < NC; c++)
 #pragma unroll
-            for (int i = 0; i < PPT; i++) o[(u64)c * n + i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr]);
+            for (int i = 0; i < PPT; i++) o[(u64)c * n + i] = reduce64_32(acc[pr][c][i], p[pr], a.mu[pr0 + pr]);
     }
 }
 
@@ -484,7 +490,7 @@ static hipError_t launch_mac32_lp(const Ext32Args &a, hipStream_t st) {
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     if (hipError_t e = allow_big_lds((const void *)digit_mac32_kernel<LP, 4, SRC>, K::LDS_BYTES)) return e;
     KernelTimer kt("digit_mac32", LP, st);
-    hipLaunchKernelGGL((digit_mac32_kernel<LP, 4, SRC>), dim3((unsigned)grid), dim3(K::TH), K::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((digit_mac32_kernel<LP, 4, SRC>), dim3((unsigned)grid, K::ONEP ? 2u : 1u), dim3(K::TH), K::LDS_BYTES, st, a);
     return hipGetLastError();
 }
 template <int LP, int EPI>

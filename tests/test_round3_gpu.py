@@ -649,3 +649,31 @@ def test_elementwise_rows_and_keyed_rows_at_2_63(pkg, oracle, need_gpu):
                L.fhe_tr_mul_r_dev(plan.handle, dk.data_ptr(), da.data_ptr(), dk.data_ptr(), k, batch, 0, None)):
         assert rc == B.FHE_E_BAD_Q
     assert b"2^62" in L.fhe_last_error()
+
+
+@pytest.mark.gpu
+def test_device_entry_points_at_2_63_in_place_ragged_and_with_evals(pkg, oracle, need_gpu):
+    """the device entry points at the top of the range: transforms in place, a batch that ends inside a workgroup,
+    the product with the library workspace writing c over a and keeping C's evals, and the synthetic fill"""
+    import torch
+
+    q, st = Q63_TOP, torch.cuda.current_stream().cuda_stream
+    for n, batch in ((64, 37), (8192, 5), (1 << 15, 3)):
+        plan = pkg.Plan(q, n)
+        x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
+        pkg.binding.fill_synthetic_dev(q, 0x63, 0, batch * n, x.data_ptr(), st)
+        a = x.cpu().numpy().view(np.uint64)
+        assert np.array_equal(a, oracle.fill_synthetic(q, 0x63, 0, batch * n)) and int(a.max()) < q
+        y = x.clone()
+        plan.forward_dev(y.data_ptr(), y.data_ptr(), batch, st)
+        assert np.array_equal(y.cpu().numpy().view(np.uint64), oracle.ntt(q, n, a).reshape(-1)), n
+        plan.inverse_dev(y.data_ptr(), y.data_ptr(), batch, st)
+        assert torch.equal(y, x), n
+        b = torch.empty_like(x)
+        pkg.binding.fill_synthetic_dev(q, 0x64, 0, batch * n, b.data_ptr(), st)
+        ce = torch.empty_like(x)
+        c = x.clone()
+        plan.rq_mul_dev(c.data_ptr(), b.data_ptr(), c.data_ptr(), batch, d_c_evals=ce.data_ptr(), stream=st)   # c over a
+        oc, oce, _, _ = oracle.rq_mul(q, n, a, b.cpu().numpy().view(np.uint64))
+        assert np.array_equal(c.cpu().numpy().view(np.uint64), oc.reshape(-1)), n
+        assert np.array_equal(ce.cpu().numpy().view(np.uint64), oce.reshape(-1)), n

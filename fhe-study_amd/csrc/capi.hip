@@ -326,12 +326,6 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     return FHE_OK;
 }
 
-int fhe_keyed_rows_need_q62(const fhe::DevicePlan &dp, const char *who) {
-    if (dp.arith != 3) return FHE_OK;
-    return fail(FHE_E_BAD_Q, "%s: q=%llu: this row accumulates lazily and needs q < 2^62 (transforms, Rq products and the "
-                "element-wise operations cover q < 2^63)", who, (unsigned long long)dp.mod.q);
-}
-
 // FHE_PM=0 (read once): pseudo-Mersenne moduli stay on the Shoup kernels — how the A/B numbers of DESIGN.md were taken
 bool fhe_pm_enabled() {
     static const bool on = [] { const char *e = getenv("FHE_PM"); return !(e && e[0] == '0'); }();

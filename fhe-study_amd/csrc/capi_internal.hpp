@@ -54,9 +54,6 @@ namespace fhe { struct SmallQArgs; }
 bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a);
 int fhe_smallq_scratch(unsigned log_n, uint64_t rows, hipStream_t st, fhe::SmallQArgs *a);   // a->mid for n > 2^14
 bool fhe_pm_enabled();                                 // FHE_PM=0 keeps pseudo-Mersenne moduli on the Shoup kernels
-// rows N2 / N3 (fhe_tr_*, fhe_glev_*, fhe_glwe_key_switch*) accumulate products lazily and need 4q < 2^64:
-// FHE_E_BAD_Q for a plan with 2^62 <= q < 2^63 (whose transforms, products and element-wise operations run: generic63.hip)
-int fhe_keyed_rows_need_q62(const fhe::DevicePlan &dp, const char *who);
 bool fhe_ext32_enabled();                              // FHE_EXT32=0 keeps every product on the 61-bit kernels
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers
 int fhe_stage_acquire(size_t bytes, void **out, size_t *got, int *dev);

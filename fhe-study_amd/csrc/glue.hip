@@ -315,7 +315,6 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_b); REQUIRE_ALIGNED(d_c);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
-    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n, rows = batch * k;
     const bool a_ev = flags & FHE_A_IS_EVALS, b_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
@@ -328,7 +327,7 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     u64 *C = out_ev ? (u64 *)d_c : WC;
     // T = k terms, nc = 1 output row, "G" = A per batch element
     { fhe::KernelTimer kt_("mac_rows", 0, st);
-    hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, 1, n))), dim3(256), 0, st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
+    fhe::launch_mac_rows(dp.arith == 3, fhe_ew_grid(fhe::mac_rows_threads(batch, 1, n)), st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
     }
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_c, batch, st);
@@ -344,7 +343,6 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     REQUIRE_ALIGNED(d_a); REQUIRE_ALIGNED(d_p); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
-    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n, total = batch * rows;
     const bool a_ev = flags & FHE_A_IS_EVALS, p_ev = flags & FHE_B_IS_EVALS, out_ev = flags & FHE_OUT_EVALS;
@@ -357,7 +355,7 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     u64 *C = out_ev ? (u64 *)d_out : WC;
     // T = 1, nc = rows: out[b][c] = A[b][c] * P[b]
     { fhe::KernelTimer kt_("mac_rows", 0, st);
-    hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, rows, n))), dim3(256), 0, st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
+    fhe::launch_mac_rows(dp.arith == 3, fhe_ew_grid(fhe::mac_rows_threads(batch, rows, n)), st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
     }
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_out, total, st);
@@ -373,7 +371,7 @@ static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const 
     if (!key_is_evals) { if ((rc = fwd(plan, dp, d_key, WK, (u64)T * nc, st)) != FHE_OK) return rc; K = WK; }
     if (!v_is_evals) { if ((rc = fwd(plan, dp, d_v, WV, batch * T, st)) != FHE_OK) return rc; V = WV; }
     { fhe::KernelTimer kt_("mac_rows", 0, st);
-    hipLaunchKernelGGL((fhe::mac_rows_kernel<>), dim3(fhe_ew_grid(fhe::mac_rows_threads(batch, nc, n))), dim3(256), 0, st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
+    fhe::launch_mac_rows(dp.arith == 3, fhe_ew_grid(fhe::mac_rows_threads(batch, nc, n)), st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
     }
     LAUNCH_OK("mac_rows_kernel");
     return out_evals ? FHE_OK : inv(plan, dp, d_out, d_out, batch * nc, st);
@@ -390,7 +388,6 @@ extern "C" int fhe_glev_mul_dev(const fhe_ntt_plan *plan, unsigned k, unsigned l
     REQUIRE_ALIGNED(d_glev); REQUIRE_ALIGNED(d_v); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
-    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     const u64 n = plan->n;
     void *w = nullptr;
     if ((rc = fhe_workspace_get(1, ((u64)l * (k + 1) + batch * l) * n * 8, (hipStream_t)stream, &w)) != FHE_OK) return rc;
@@ -457,7 +454,6 @@ extern "C" int fhe_glwe_key_switch_dev(const fhe_ntt_plan *plan, unsigned k, uns
     REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_ksk); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
-    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 n = plan->n;
     const u32 k1 = k + 1, T = k * l;
@@ -537,7 +533,7 @@ static int ksk_args_ok(const char *fn, const fhe_ntt_plan *plan, unsigned k, uns
     return check_decompose_args(fn, plan->q, beta, l);
 }
 extern "C" size_t fhe_glwe_ksk_prepared_words(const fhe_ntt_plan *plan, unsigned k, unsigned beta, unsigned l) {
-    if (!plan || k == 0 || l == 0 || beta < 2 || (plan->q >> 62)) return 0;   // q >= 2^62: the keyed rows reject the plan
+    if (!plan || k == 0 || l == 0 || beta < 2) return 0;
     {   // the arguments fhe_glwe_ksk_prepare_dev would reject (check_decompose_args) have no prepared form: 0, and the
         // caller's fhe_last_error() is left as it was
         unsigned bad = beta == 2 ? l > 64 : 0;
@@ -558,7 +554,6 @@ extern "C" int fhe_glwe_ksk_prepare_dev(const fhe_ntt_plan *plan, unsigned k, un
     if (d_ksk == d_prepared) return fhe_fail(FHE_E_INVALID, "fhe_glwe_ksk_prepare_dev: the prepared key cannot overwrite the key");
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
-    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const u64 rows = (u64)k * l * (k + 1);
     if (!ks32_usable(plan, k, beta, l)) return fwd(plan, dp, (const u64 *)d_ksk, (u64 *)d_prepared, rows, st);
@@ -579,7 +574,6 @@ extern "C" int fhe_glwe_key_switch_prepared_dev(const fhe_ntt_plan *plan, unsign
     REQUIRE_ALIGNED(d_glwe); REQUIRE_ALIGNED(d_prepared); REQUIRE_ALIGNED(d_out);
     fhe::DevicePlan dp;
     if ((rc = fhe_device_plan(plan, &dp)) != FHE_OK) return rc;
-    if ((rc = fhe_keyed_rows_need_q62(dp, __func__)) != FHE_OK) return rc;
     return ks32_run(plan, dp, k, l, d_glwe, (const uint32_t *)d_prepared, nullptr, d_out, batch, (hipStream_t)stream);
 }
 

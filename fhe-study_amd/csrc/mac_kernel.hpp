@@ -10,13 +10,14 @@
 //
 // One thread owns coefficients (j, j+1) of output rows (c0, c0+1): every D word is loaded once,
 // as 16 bytes, for both rows; sums run in 128-bit accumulators reduced once per kMacChunk terms
-// (zq_device.hpp).  All operands must be canonical (< q).
+// (zq_device.hpp).  All operands must be canonical (< q).  Q63 (2^62 <= q < 2^63, with CHUNK = kMacChunk63 = 2): the
+// strict reduction, every partial result canonical — 4q does not fit a word there.
 #pragma once
 #include "zq_device.hpp"
 
 namespace fhe {
 
-template <int CHUNK = (int)kMacChunk>
+template <int CHUNK = (int)kMacChunk, bool Q63 = false>
 __global__ __launch_bounds__(256) void mac_rows_kernel(const u64 *__restrict__ G, const u64 *__restrict__ D,
                                                        u64 *__restrict__ out, u64 batch, u32 n, u32 T, u32 nc,
                                                        u64 gstride, Mod m) {
@@ -48,13 +49,26 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(const u64 *__restrict__ G
                     }
                 }
             }
-            a00.fold(m); a01.fold(m);
-            if (two) { a10.fold(m); a11.fold(m); }
+            if constexpr (Q63) {
+                static_assert(!Q63 || CHUNK <= (int)kMacChunk63, "q < 2^63: two terms per fold");
+                a00.fold63(m); a01.fold63(m);
+                if (two) { a10.fold63(m); a11.fold63(m); }
+            } else {
+                a00.fold(m); a01.fold(m);
+                if (two) { a10.fold(m); a11.fold(m); }
+            }
         }
         ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + (b * nc + c0) * n) + jp;
         o[0] = ulonglong2{(u64)a00.v, (u64)a01.v};          // after fold() the accumulator IS the canonical sum
         if (two) o[nh] = ulonglong2{(u64)a10.v, (u64)a11.v};
     }
+}
+
+// the launch, by the plan's modulus range
+static inline void launch_mac_rows(bool q63, unsigned grid, hipStream_t st, const u64 *G, const u64 *D, u64 *out, u64 batch, u32 n, u32 T, u32 nc,
+                                   u64 gstride, const Mod &m) {
+    if (q63) hipLaunchKernelGGL((mac_rows_kernel<(int)kMacChunk63, true>), dim3(grid), dim3(256), 0, st, G, D, out, batch, n, T, nc, gstride, m);
+    else hipLaunchKernelGGL((mac_rows_kernel<>), dim3(grid), dim3(256), 0, st, G, D, out, batch, n, T, nc, gstride, m);
 }
 
 // workgroups for mac_rows_kernel over `batch` elements of nc rows of n words

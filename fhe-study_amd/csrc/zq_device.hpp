@@ -364,7 +364,14 @@ struct MacAcc {
         v = r;
         return r;
     }
+    // 2^62 <= q < 2^63: a term is below 2^126, so TWO terms and a canonical carry-over stay below 2^128 (kMacChunk63)
+    __device__ __forceinline__ u64 fold63(const Mod &m) {
+        const u64 r = reduce128_63((u64)(v >> 64), (u64)v, m);
+        v = r;
+        return r;
+    }
 };
+constexpr unsigned kMacChunk63 = 2;
 
 __device__ __forceinline__ u64 splitmix64(u64 x) {
     x += 0x9E3779B97F4A7C15ull;

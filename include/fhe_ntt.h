@@ -64,10 +64,7 @@ extern "C" {
  * in the reference, ntt.rs:139) or n > 2^20 (engine limit). */
 #define FHE_E_BAD_N (-1)
 /* (q-1) % 2n != 0 (assert, ntt.rs:117), q < 3, or q >= 2^63 (where the
- * reference's own Zq::add overflows, zq.rs:225).  Also returned by the keyed
- * rows (fhe_tr_*, fhe_glev_*, fhe_glwe_key_switch*) for 2^62 <= q < 2^63:
- * their accumulators need 4q < 2^64; transforms, products and the element-wise
- * operations cover the whole range. */
+ * reference's own Zq::add overflows, zq.rs:225). */
 #define FHE_E_BAD_Q (-2)
 /* the k = 1,2,... search found no primitive 2n-th root (panic, ntt.rs:130). */
 #define FHE_E_NO_ROOT (-3)

@@ -10,6 +10,7 @@ import pytest
 from conftest import Q16, Q61
 
 U64 = 1 << 64
+Q63 = 9223372036844421121      # the largest prime = 1 (mod 2^17) below 2^63: the top of the reference's range (zq.rs:225)
 
 
 def _rq_mul(q, a, b):
@@ -112,7 +113,7 @@ def _host(t):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q,n", [(Q16, 64), (Q61, 1024)])
+@pytest.mark.parametrize("q,n", [(Q16, 64), (Q61, 1024), (Q63, 256)])
 def test_gpu_elementwise(pkg, oracle, q, n):
     import torch
 
@@ -152,7 +153,7 @@ def test_gpu_elementwise(pkg, oracle, q, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q,n,beta,l", [(16, 4, 4, 2), (Q16, 64, 2, 16), (Q16, 64, 2, 8), (Q16, 32, 4, 8), (Q61, 256, 2, 61)])
+@pytest.mark.parametrize("q,n,beta,l", [(16, 4, 4, 2), (Q16, 64, 2, 16), (Q16, 64, 2, 8), (Q16, 32, 4, 8), (Q61, 256, 2, 61), (Q63, 64, 2, 63), (Q63, 64, 4, 12)])
 def test_gpu_decompose(pkg, oracle, q, n, beta, l):
     import torch
 
@@ -172,7 +173,7 @@ def test_gpu_decompose(pkg, oracle, q, n, beta, l):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q,n,k,batch", [(Q16, 8, 16, 3), (Q16, 128, 16, 2), (Q61, 4096, 2, 3), (Q61, 16384, 3, 2)])
+@pytest.mark.parametrize("q,n,k,batch", [(Q16, 8, 16, 3), (Q16, 128, 16, 2), (Q61, 4096, 2, 3), (Q61, 16384, 3, 2), (Q63, 256, 5, 3), (Q63, 16384, 2, 2)])
 def test_gpu_tr_dot_and_mul_r(pkg, oracle, q, n, k, batch):
     """TR.TR and GLWE x R at the reference's test shapes (gfhe/src/glwe.rs tests: k = 16, n = 8..128)"""
     import torch
@@ -220,7 +221,9 @@ def test_gpu_tr_dot_and_mul_r(pkg, oracle, q, n, k, batch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("q,n,k,beta,l,batch", [(Q16, 128, 16, 2, 16, 2),     # gfhe/src/glwe.rs:582-594 test_key_switch
                                                (Q16, 16, 2, 4, 8, 3),
-                                               (Q61, 1024, 2, 2, 61, 2)])
+                                               (Q61, 1024, 2, 2, 61, 2),
+                                               (Q63, 512, 2, 2, 63, 2),     # strict accumulators (two terms per fold)
+                                               (Q63, 64, 1, 4, 9, 3)])
 def test_gpu_glev_mul_and_key_switch(pkg, oracle, q, n, k, beta, l, batch):
     import torch
 

@@ -349,7 +349,8 @@ def test_fused_external_product_and_prepared_key(pkg, oracle, n, k, l, batch):
                                            (Q61, 2048, 1, 64, 2),     # the same on the two-small-prime kernels (k = 1), 8 positions per thread
                                            (Q61, 512, 1, 40, 5),
                                            (Q16, 4096, 1, 16, 2),     # 512-thread workgroups with every digit saturated
-                                           (Q61, 256, 1, 7, 33)])     # more ciphertexts than a tail workgroup holds rows, odd digit count
+                                           (Q61, 256, 1, 7, 33),      # more ciphertexts than a tail workgroup holds rows, odd digit count
+                                           (9223372036844421121, 1024, 1, 63, 3)])   # just below 2^63 (round 3): plain kernels, strict accumulators
 def test_fused_key_switch(pkg, oracle, q, n, k, l, batch):
     """GLWE::key_switch (gfhe/src/glwe.rs:126-137) with base-2 decomposition through digit_mac_kernel;
     key in coefficients and key resident in the NTT domain (FHE_A_IS_EVALS) give the oracle's words."""

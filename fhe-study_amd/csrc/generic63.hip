@@ -122,8 +122,8 @@ hipError_t inv_group_r(int r, const DevicePlan &p, const u64 *in, const u64 *in2
 
 }  // namespace
 
-// the grid of a group is batch * n / 2^R / 256 workgroups: batch * n < 2^40 keeps it below 2^32
-static inline bool g63_fits(const DevicePlan &p, u64 batch) { return batch <= (1ull << 40 >> p.log_n); }
+// the grid of a group is batch * n / 2^R / 256 workgroups (R >= 1): batch * n <= 2^38 keeps it below 2^31
+static inline bool g63_fits(const DevicePlan &p, u64 batch) { return batch <= (1ull << 38 >> p.log_n); }
 
 hipError_t launch_g63_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch, hipStream_t st) {
     if (batch == 0) return hipSuccess;

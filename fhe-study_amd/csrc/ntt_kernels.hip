@@ -677,6 +677,9 @@ static hipError_t launch_strided(const PassArgs &a, hipStream_t st, unsigned ope
     return post_launch();
 }
 
+#ifndef FHE_STRIDED_CW8
+#define FHE_STRIDED_CW8 32        // columns of a strided-pass workgroup at 8 strided stages (shape experiments: 16 / 64)
+#endif
 #define CONTIG_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 
 // ar: the kernels' AR (0 / 1 = Shoup tables, 2 = pseudo-Mersenne tables: DevicePlan::arith)
@@ -719,7 +722,7 @@ static hipError_t strided_dispatch_ar(int la, const PassArgs &a, hipStream_t st,
     switch (la) {
         case 6: return launch_strided<6, 128, INV, AR>(a, st, operands);
         case 7: return launch_strided<7, 64, INV, AR>(a, st, operands);
-        case 8: return launch_strided<8, 32, INV, AR>(a, st, operands);   // 16 / 64 columns measured equal / slower
+        case 8: return launch_strided<8, FHE_STRIDED_CW8, INV, AR>(a, st, operands);   // 16 / 64 columns measured equal / slower
     }
     return hipErrorInvalidValue;
 }

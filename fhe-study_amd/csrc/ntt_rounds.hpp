@@ -420,11 +420,14 @@ __device__ __forceinline__ void st_c(u64 *ubase, u32 byte_off, T x) {
 // Workgroup = W units (unit = one M-block of one polynomial, all W units share
 // `blk`, hence the twiddles), TPB = M/16 threads per unit.
 // ---------------------------------------------------------------------------
+#ifndef FHE_CONTIG_TH8
+#define FHE_CONTIG_TH8 256        // threads of a workgroup around 256-point blocks (shape experiments: 128 / 512)
+#endif
 template <int LP>
 struct ContigCfg {
     static constexpr int M = 1 << LP;
     static constexpr int TPB = M / 16;
-    static constexpr int TH = (LP <= 12) ? 256 : 512;
+    static constexpr int TH = (LP == 8) ? FHE_CONTIG_TH8 : (LP <= 12) ? 256 : 512;
     static constexpr int W = TH / TPB;
     static constexpr int TILE = W * M;  // = 16 * TH
     static constexpr int NR = (LP + 3) / 4;

@@ -672,3 +672,48 @@ def test_device_entry_points_at_2_63_in_place_ragged_and_with_evals(pkg, oracle,
         oc, oce, _, _ = oracle.rq_mul(q, n, a, b.cpu().numpy().view(np.uint64))
         assert np.array_equal(c.cpu().numpy().view(np.uint64), oc.reshape(-1)), n
         assert np.array_equal(ce.cpu().numpy().view(np.uint64), oce.reshape(-1)), n
+
+
+# ---- differential sweep over the modulus range ----------------------------------------------------------------------------
+def _random_cases():
+    """(q, n) pairs drawn once (fixed seed): a prime = 1 (mod 2n) near a random point of every bit length from 17 to 63, plus
+    primes hugging the boundaries where the engine changes arithmetic (2^32/25, 2^30, 2^32, 2^61 and the pseudo-Mersenne
+    eligibility limit delta <= 2^(k-39), 2^62, 2^63)"""
+    rng = random.Random(20260403)
+    cases = []
+    for bits in range(17, 64):
+        n = 1 << rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14])
+        lo, hi = 1 << (bits - 1), 1 << bits
+        cases.append((_prime_below(rng.randrange(lo + (hi - lo) // 8, hi), 2 * n), n))
+    for limit in ((1 << 32) // 25, (1 << 32) // 25 + (1 << 22), 1 << 30, (1 << 30) + (1 << 24), 1 << 32, (1 << 32) + (1 << 26),
+                  1 << 61, (1 << 61) + (1 << 50), 1 << 62, (1 << 62) + (1 << 40), 1 << 63):
+        for n in (256, 4096):
+            cases.append((_prime_below(limit, 2 * n), n))
+    for k in (56, 58, 60, 61):                      # either side of the pseudo-Mersenne eligibility limit
+        for mult in (1, 3):
+            cases.append((_prime_below((1 << k) - mult * (1 << (k - 40)), 1 << 13), 4096))
+    return sorted(set(cases))
+
+
+def test_differential_cases_cover_every_arithmetic(pkg):
+    """host-side: the sweep below reaches all five arithmetic forms (fhe_ntt_plan_arithmetic)"""
+    forms = {pkg.Plan(q, n).arithmetic() for q, n in _random_cases()}
+    ext_on = os.environ.get("FHE_EXT32", "1")[:1] != "0"
+    pm_on = os.environ.get("FHE_PM", "1")[:1] != "0"
+    assert forms >= ({0, 1, 4} | ({3} if ext_on else set()) | ({2} if pm_on else set())), forms
+
+
+@pytest.mark.gpu
+def test_differential_sweep_over_the_modulus_range(pkg, oracle, need_gpu):
+    """forward, inverse, product (with its three evals) and pointwise product against the oracle for every case of
+    _random_cases(): three rows each — all q-1, alternating, pseudo-random"""
+    for q, n in _random_cases():
+        a = _extreme_rows(oracle, q, n, q % 1009)[[1, 2, 4]]
+        b = _extreme_rows(oracle, q, n, q % 1013)[[4, 1, 5]]
+        plan = pkg.Plan(q, n)
+        A = plan.forward(a)
+        assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (q, n, plan.arithmetic())
+        assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (q, n, plan.arithmetic())
+        got, want = plan.rq_mul(a, b), oracle.rq_mul(q, n, a, b)
+        assert all(np.array_equal(x.reshape(-1), y.reshape(-1)) for x, y in zip(got, want)), (q, n, plan.arithmetic())
+        assert np.array_equal(plan.pointwise_mul(a, b).reshape(-1), oracle.pointwise_mul(q, a.reshape(-1), b.reshape(-1))), (q, n)

@@ -104,7 +104,15 @@ timeout -k 10 200 python tools/smallq_bench.py > $OUT/smallq.txt 2>&1 || true
 FHE_EXT32=0 timeout -k 10 200 python tools/smallq_bench.py >> $OUT/smallq.txt 2>&1 || true
 timeout -k 10 100 python tools/abl_bfv.py > $OUT/bfv_kernels.txt 2>&1 || true
 FHE_EXT32=0 timeout -k 10 100 python tools/abl_bfv.py >> $OUT/bfv_kernels.txt 2>&1 || true
+# 2^62 <= q < 2^63 (generic63.hip) beside the headline modulus on this box
+(for ln in 16 12 10; do KBENCH_Q=9223372036844421121 timeout -k 10 120 python tools/kbench.py $ln $((1 << (28 - ln))); done; timeout -k 10 120 python tools/kbench.py 16 4096) > $OUT/q63_kbench.txt 2>&1 || true
+# VALU counters of the BFV kernels (two --pmc passes, as for the pass kernels)
+C3="bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-parity"
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc3_a -o runc --output-format csv -- python3 $C3 > $OUT/pmc3_a.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY --kernel-trace -d $OUT/pmc3_b -o runc --output-format csv -- python3 $C3 > $OUT/pmc3_b.log 2>&1 || true
+python3 tools/pmc_isa.py $OUT/pmc3_a $OUT/config3_counters_a.json > /dev/null 2>&1 || true
+python3 tools/pmc_isa.py $OUT/pmc3_b $OUT/config3_counters_b.json > /dev/null 2>&1 || true
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt
-rm -rf $OUT/pmc_isa_*/*/*.db $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc4_*/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true
+rm -rf $OUT/pmc3_*/*/*.db $OUT/pmc_isa_*/*/*.db $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc4_*/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true
 find $OUT -name "*.db" -delete 2>/dev/null || true
 date

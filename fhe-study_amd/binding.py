@@ -14,8 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")  # env: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "ntt_kernels.hip", "digit_mac.hip", "digit32.hip", "bfv32.hip", "smallq.hip", "generic63.hip", "zring.hip", "glue.hip"]
-HEADERS = ["ntt_kernels.hpp", "ntt_rounds.hpp", "digit_mac.hpp", "digit32.hpp", "bfv32.hpp", "smallq.hpp", "ntt32_rounds.hpp", "ntt32_big.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp",
+SOURCES = ["capi.hip", "ntt_kernels.hip", "ntt_persist.hip", "digit_mac.hip", "digit32.hip", "bfv32.hip", "smallq.hip", "generic63.hip", "zring.hip", "glue.hip"]
+HEADERS = ["ntt_kernels.hpp", "ntt_rounds.hpp", "ntt_persist.hpp", "persist_sched.hpp", "digit_mac.hpp", "digit32.hpp", "bfv32.hpp", "smallq.hpp", "ntt32_rounds.hpp", "ntt32_big.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp",
            os.path.join("..", "..", "include", "fhe_ntt.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
 # -ffp-contract=off: zring.hip restates the reference's f64 scale-and-round (one IEEE rounding
@@ -43,7 +43,7 @@ EXPORTS = [
     "fhe_rq_pointwise_mul", "fhe_rq_check_canonical",
     "fhe_ntt_forward_dev", "fhe_ntt_inverse_dev", "fhe_rq_mul_dev",
     "fhe_rq_mul_workspace_bytes", "fhe_rq_pointwise_mul_dev", "fhe_fill_synthetic_dev",
-    "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
+    "fhe_ntt_set_batch_tile", "fhe_ntt_set_persist", "fhe_ntt_persist_status", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
     "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace", "fhe_ntt_workspace_bytes",
@@ -175,6 +175,8 @@ def load_library():
     L.fhe_rq_pointwise_mul_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
     L.fhe_fill_synthetic_dev.argtypes = [_u64, _u64, _u64, _sz, _vp, _vp]
     L.fhe_ntt_set_batch_tile.argtypes = [_sz]
+    L.fhe_ntt_set_persist.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    L.fhe_ntt_persist_status.argtypes = []
     L.fhe_ntt_kernel_timing_enable.argtypes = [_int]
     L.fhe_ntt_kernel_timing_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), _p64, _int]
     L.fhe_ntt_kernel_timing_reset.argtypes = []
@@ -453,6 +455,16 @@ def shard_range(total, world, rank):
 
 def set_batch_tile(polys):
     _check(load_library().fhe_ntt_set_batch_tile(int(polys)))
+
+
+def set_persist(tile_polys, lag=1, ringslots=4):
+    """The one-launch n = 2^16 forward transform (csrc/ntt_persist.hip); tile_polys = 0: the two-pass kernels."""
+    _check(load_library().fhe_ntt_set_persist(int(tile_polys), int(lag), int(ringslots)))
+
+
+def persist_status():
+    """Raises FheError if a persistent launch that has finished gave up a bounded wait (call after synchronising)."""
+    _check(load_library().fhe_ntt_persist_status())
 
 
 def kernel_timing_enable(on):

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "capi_internal.hpp"
+#include "ntt_persist.hpp"
 #include "smallq.hpp"
 
 using fhe::u64;
@@ -435,6 +436,111 @@ extern "C" int fhe_ntt_set_batch_tile(size_t polys) {
     return FHE_OK;
 }
 
+// ---- the one-launch forward transform (ntt_persist.hip) ---------------------------------------------------------
+// FHE_NTT_PERSIST=T[,L[,R]] (or fhe_ntt_set_persist): n = 2^16 transforms on a pseudo-Mersenne modulus run as ONE launch of
+// persistent workgroups — tiles of T polynomials, the strided stages running L tiles ahead of the contiguous ones, the
+// intermediate in a ring of R tile slots per XCD (R = 0: in the output buffer).  Unset / T = 0: the two-pass kernels.
+static bool g_persist_set = false;
+static fhe::PersistTune g_persist{};
+static bool g_persist_on = false;
+static uint32_t *g_persist_host_err = nullptr;      // pinned, device-visible: a bounded wait that ran out lands here
+static bool persist_tune(fhe::PersistTune *t) {
+    std::lock_guard<std::mutex> lk(g_cfg_lock);
+    if (!g_persist_set) {
+        g_persist_set = true;
+        const char *e = getenv("FHE_NTT_PERSIST");
+        unsigned T = 0, L = 1, R = 4;
+        if (e && sscanf(e, "%u,%u,%u", &T, &L, &R) >= 1 && T > 0 && (T & (T - 1)) == 0 && T <= 1024 && (R == 0 || R >= L + 1)) {
+            g_persist.log_t = 0;
+            while ((1u << g_persist.log_t) < T) g_persist.log_t++;
+            g_persist.lag = L; g_persist.ringslots = R;
+            g_persist_on = true;
+        }
+    }
+    *t = g_persist;
+    return g_persist_on;
+}
+extern "C" int fhe_ntt_set_persist(unsigned tile_polys, unsigned lag, unsigned ringslots) {
+    if (tile_polys && ((tile_polys & (tile_polys - 1)) != 0 || tile_polys > 1024))
+        return fail(FHE_E_INVALID, "fhe_ntt_set_persist: tile of %u polynomials (need a power of two <= 1024, or 0)", tile_polys);
+    if (tile_polys && ringslots && ringslots < lag + 1)
+        return fail(FHE_E_INVALID, "fhe_ntt_set_persist: a ring of %u slots cannot hold a lag of %u tiles (need >= lag + 1)", ringslots, lag);
+    std::lock_guard<std::mutex> lk(g_cfg_lock);
+    g_persist_set = true;
+    g_persist_on = tile_polys != 0;
+    g_persist.log_t = 0;
+    while (tile_polys && (1u << g_persist.log_t) < tile_polys) g_persist.log_t++;
+    g_persist.lag = lag; g_persist.ringslots = ringslots;
+    return FHE_OK;
+}
+static int persist_host_err(uint32_t **dptr) {
+    std::lock_guard<std::mutex> lk(g_cfg_lock);
+    if (!g_persist_host_err) {
+        void *h = nullptr;
+        HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+        memset(h, 0, 64);
+        g_persist_host_err = (uint32_t *)h;
+    }
+    void *d = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d, g_persist_host_err, 0));
+    *dptr = (uint32_t *)d;
+    return FHE_OK;
+}
+// FHE_OK, or FHE_E_HIP when a persistent launch that has FINISHED gave up a bounded wait (its outputs are then not valid);
+// reading clears the word.  Call after synchronising the stream.
+extern "C" int fhe_ntt_persist_status(void) {
+    uint32_t v = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_cfg_lock);
+        if (g_persist_host_err) { v = *(volatile uint32_t *)g_persist_host_err; *(volatile uint32_t *)g_persist_host_err = 0; }
+    }
+    if (v) return fail(FHE_E_HIP, "persistent transform: a bounded wait ran out (bits 0x%x: 1 bind, 2 strided-done, 4 ring slot)", v);
+    return FHE_OK;
+}
+// the lane-ordered table of the last four stages, built once per (plan, device)
+static int persist_tables(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const fhe::Tw **twc, hipStream_t st) {
+    int dev = 0;
+    int rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
+    std::lock_guard<std::mutex> lk(plan->dev_lock);
+    DeviceTables &t = plan->dev[dev];
+    if (!t.twc_pm) {
+        fhe::Tw *d = nullptr;
+        HIP_TRY(hipMalloc((void **)&d, fhe::persist_twc_entries(plan->log_n) * sizeof(fhe::Tw)));
+        hipError_t e = fhe::launch_persist_twc(dp.tw_fwd_pm, d, plan->log_n, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "persist_twc_kernel"); }
+        t.twc_pm = d;
+    }
+    *twc = t.twc_pm;
+    return FHE_OK;
+}
+static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const fhe::PersistTune &tune, const void *d_in,
+                           void *d_out, size_t batch, hipStream_t st) {
+    if (g_persist_host_err && *(volatile uint32_t *)g_persist_host_err)
+        return fail(FHE_E_HIP, "an earlier persistent transform failed (fhe_ntt_persist_status())");
+    const fhe::Tw *twc = nullptr;
+    int rc = persist_tables(plan, dp, &twc, st);
+    if (rc != FHE_OK) return rc;
+    uint32_t *herr = nullptr;
+    if ((rc = persist_host_err(&herr)) != FHE_OK) return rc;
+    const size_t cb = (fhe::persist_ctl_bytes(tune, batch) + 255) & ~(size_t)255, rb = fhe::persist_ring_bytes(tune);
+    void *w = nullptr;
+    if ((rc = fhe_workspace_get(4, cb + rb, st, &w)) != FHE_OK) return rc;
+    static unsigned grid = 0;
+    if (!grid) {
+        unsigned g = 0;
+        HIP_TRY(fhe::persist_grid(&g));
+        const char *e = getenv("FHE_NTT_PERSIST_GRID");
+        if (e && atoi(e) > 0) g = (unsigned)atoi(e);
+        grid = g;
+    }
+    hipError_t e = fhe::launch_ntt_forward_persist(dp, twc, (const u64 *)d_in, (u64 *)d_out, batch, tune, (uint32_t *)w,
+                                                   rb ? (u64 *)((char *)w + cb) : nullptr, herr, grid, st);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward_persist");
+    return FHE_OK;
+}
+
 // Grow-only library workspaces, one per (slot, device, STREAM): slot 0 = fhe_rq_mul_dev(d_work = NULL)
 // and the tensor result of fhe_bfv_mul_dev, slot 1 = zring / glue intermediates.  The contents
 // belong to one call; calls on the same stream are ordered by the stream, calls on different
@@ -720,6 +826,9 @@ extern "C" int fhe_ntt_forward_dev(const fhe_ntt_plan *plan, const void *d_in, v
         hipError_t se = fhe::launch_sq_forward(sq, (int)dp.log_n, (hipStream_t)hip_stream);
         return se == hipSuccess ? FHE_OK : hip_fail(se, "sq_forward_kernel");
     }
+    fhe::PersistTune tune;
+    if (persist_tune(&tune) && fhe::persist_supported(dp))
+        return forward_persist(plan, dp, tune, d_in, d_out, batch, (hipStream_t)hip_stream);
     hipError_t e = fhe::launch_ntt_forward(dp, (const u64 *)d_in, (u64 *)d_out, batch,
                                            fhe_batch_tile_for(plan), (hipStream_t)hip_stream);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward");
@@ -1064,6 +1173,7 @@ extern "C" int fhe_ntt_shutdown(void) {
             if (t.tw32_inv) (void)hipFree(t.tw32_inv);
             if (t.tw_fwd_pm) (void)hipFree(t.tw_fwd_pm);
             if (t.tw_inv_pm) (void)hipFree(t.tw_inv_pm);
+            if (t.twc_pm) (void)hipFree(t.twc_pm);
             t = DeviceTables();
         }
     }

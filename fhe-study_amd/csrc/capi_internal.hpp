@@ -18,6 +18,7 @@ struct DeviceTables {
     fhe::u64 *digit_lut = nullptr;   // 136 words, n >= 8 (ntt_rounds.hpp: round0_bits)
     fhe::Tw32 *tw32_fwd = nullptr, *tw32_inv = nullptr;   // small moduli (smallq.hip)
     fhe::Tw *tw_fwd_pm = nullptr, *tw_inv_pm = nullptr;   // pseudo-Mersenne moduli: {w, w 2^32 mod q} (zq_device.hpp)
+    fhe::Tw *twc_pm = nullptr;   // the one-launch transform's lane-ordered table of the last four stages (ntt_persist.hip), built on first use
     bool ready = false;
 };
 

@@ -181,6 +181,14 @@ int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_index, size
  * 256 MiB Infinity Cache when the second pass reads it.  0 restores the default
  * (one launch per pass over the whole batch — measured fastest). */
 int fhe_ntt_set_batch_tile(size_t polys);
+/* The one-launch forward transform (n = 2^16, pseudo-Mersenne moduli; csrc/ntt_persist.hip): persistent workgroups
+ * run the strided and the contiguous stages of NTT::ntt (arith/src/ntt.rs:44-73) in ONE kernel, handing the
+ * intermediate over inside an XCD's L2 (a ring of `ringslots` tiles per XCD; 0 = through the output buffer) instead
+ * of through HBM.  tile_polys: power of two <= 1024, 0 = off (the two-pass kernels); lag: tiles the strided stages
+ * run ahead; ringslots >= lag + 1 or 0.  Environment: FHE_NTT_PERSIST=T[,L[,R]].  Every wait inside the kernel is
+ * bounded; fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if one ran out, and clears the flag. */
+int fhe_ntt_set_persist(unsigned tile_polys, unsigned lag, unsigned ringslots);
+int fhe_ntt_persist_status(void);
 /* When enabled, every kernel launch is bracketed by HIP events on its stream;
  * fhe_ntt_kernel_timing_read() synchronises, and returns per-kernel totals
  * since the last reset.  `names` receives up to `cap` NUL-terminated names of

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""tools/persist_bench.py — the one-launch n = 2^16 forward transform (csrc/ntt_persist.hip) against the two-pass kernels:
+word-for-word comparison on small / ragged batches, then timings over a list of (tile, lag, ring) settings.
+usage: python tools/persist_bench.py [batch] [T,L,R ...]       (diagnostic; not the contract bench)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import fhe_study_amd as pkg
+
+B = pkg.binding
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]] or [(1, 1, 4), (2, 1, 2), (16, 1, 0), (64, 1, 0)]
+q, n = pkg.Q61, 1 << 16
+plan = pkg.Plan(q, n)
+st = torch.cuda.current_stream().cuda_stream
+
+
+def run(x, y, b):
+    plan.forward_dev(x.data_ptr(), y.data_ptr(), b, st)
+
+
+# ---- parity: every setting against the two-pass kernels, batches that leave tiles, items and queues ragged ----
+bad = 0
+for b in (1, 3, 37, 300, 1030):
+    x = torch.empty(b * n, dtype=torch.int64, device="cuda:0")
+    B.fill_synthetic_dev(q, 7 + b, 0, b * n, x.data_ptr(), st)
+    ref = torch.empty_like(x)
+    B.set_persist(0)
+    run(x, ref, b)
+    torch.cuda.synchronize()
+    for (T, L, R) in cfgs:
+        y = torch.zeros_like(x)
+        B.set_persist(T, L, R)
+        t0 = time.perf_counter()
+        run(x, y, b)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        try:
+            B.persist_status()
+            err = ""
+        except Exception as e:   # noqa: BLE001
+            err = f" STATUS: {e}"
+        ok = bool(torch.equal(y, ref))
+        z = x.clone()                      # in place
+        run(z, z, b)
+        torch.cuda.synchronize()
+        ok2 = bool(torch.equal(z, ref))
+        bad += (not ok) + (not ok2) + bool(err)
+        print(f"parity batch={b:5d} T={T} L={L} R={R}: {'ok' if ok else 'MISMATCH'} / in place {'ok' if ok2 else 'MISMATCH'}"
+              f"  ({dt*1e3:.2f} ms){err}", flush=True)
+    del x, ref
+print("parity:", "ALL OK" if not bad else f"{bad} FAILURES", flush=True)
+if bad and not os.environ.get("PERSIST_BENCH_FORCE"):
+    sys.exit(1)
+
+# ---- timings ----
+x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
+y = torch.empty_like(x)
+B.fill_synthetic_dev(q, 1, 0, batch * n, x.data_ptr(), st)
+for (T, L, R) in [(0, 0, 0)] + cfgs:
+    B.set_persist(T, L, R)
+    for _ in range(2):
+        run(x, y, batch)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run(x, y, batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    B.persist_status()
+    print(f"time batch={batch} T={T} L={L} R={R}: {dt*1e3:.3f} ms  {batch/dt/1e6:.3f} M NTT/s  {batch*n*16/dt/8e12:.4f} of 8 TB/s"
+          f"  (x 65536/batch = {dt*1e3*65536/batch:.2f} ms per step)", flush=True)

@@ -50,7 +50,12 @@ __device__ __forceinline__ u64 ld_mid(const u64 *base, u32 byte_off) {
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// R stages on the 16 registers with the twiddle of (stage i, group g) supplied by `twf`
+// compiler-only fence: memory operations are not moved across it (bounds how far loads are hoisted = registers held)
+#define FHE_SCHED_FENCE() asm volatile("" ::: "memory")
+
+// R stages on the 16 registers with the twiddle of (stage i, group g) supplied by `twf`.  The workgroup keeps the NEXT
+// item's 16 coefficients in registers while this runs, so the twiddle reads must not all be hoisted to the front (60
+// registers): compiler fences keep at most four twiddles (16 registers) ahead of their use.
 template <int R, int BIN, typename F>
 __device__ __forceinline__ void round_fwd_pm_f(u64 (&v)[16], F twf, const Mod &m) {
     static_assert(pm_fwd_bound_out(R, BIN) <= kPmCap, "a stage would overflow");
@@ -60,6 +65,7 @@ __device__ __forceinline__ void round_fwd_pm_f(u64 (&v)[16], F twf, const Mod &m
         const bool red = pm_fwd_needs_red(pm_fwd_bound_out(i, BIN));
 #pragma unroll
         for (int g = 0; g < (1 << i); g++) {
+            if ((g & 3) == 0) FHE_SCHED_FENCE();           // at most four twiddles (16 registers) ahead of their use
             const Tw t = twf(i, g);
 #pragma unroll
             for (int l = 0; l < span; l++) {
@@ -71,12 +77,31 @@ __device__ __forceinline__ void round_fwd_pm_f(u64 (&v)[16], F twf, const Mod &m
     }
 }
 
-// what lane 0 hands the workgroup for one ticket: five words in LDS
-enum : int { kCtlPhase = 0, kCtlOrd = 1, kCtlR = 2, kCtlBind = 3, kCtlStatus = 4 };
+// what lane 0 hands the workgroup for a ticket: one record of eight words in LDS (two records: the current ticket when it
+// has to be resolved at the top of an iteration, and the NEXT ticket, resolved while the current item computes)
+enum : int { kCtlPhase = 0, kCtlOrd = 1, kCtlR = 2, kCtlBind = 3, kCtlStatus = 4, kCtlRes = 5, kCtlWords = 8 };
+
+struct Desc {          // a ticket as every lane knows it (wave-uniform)
+    u32 phase, ord, r;
+    u32 bind;          // global tile + 1, or kPersistInvalid
+};
 
 }  // namespace
 
-// MIDRING: the intermediate lives in a.ring (per-XCD slots, rewritten in place); otherwise in a.out
+// MIDRING: the intermediate lives in a.ring (per-XCD slots, rewritten in place); otherwise in a.out.
+//
+// One iteration = one work item, software-pipelined two tickets deep:
+//   top      lane 0 draws the ticket after next (nobody waits for it) and starts the loads of the NEXT ticket's control
+//            words (its tile binding, the counter it depends on)
+//   round 0  first four stages of the item whose coefficients arrived during the PREVIOUS item
+//            lane 0 looks at the control words that have arrived: next ticket resolved or not
+//   barrier  (the LDS exchange's) — behind it: the previous item's completion is signalled (its stores have been waited
+//            for), every lane learns the next ticket and, if it is resolved, issues its coefficient loads
+//   round 1  last four stages, stores
+// so that neither the ticket, nor the dependency check, nor the HBM latency of the next item's coefficients is waited
+// for — unless the next ticket's dependencies are not met yet: then it is resolved at the top of its own iteration by
+// polling (bounded), which is the only place a workgroup ever waits for another.  Holding tickets ahead is safe: a
+// workgroup runs its tickets in order and only ever blocks on the one it is running.
 template <bool MIDRING>
 __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) {
     using S = StridedCfg<8, 32>;
@@ -90,146 +115,296 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
     const Mod &m = a.mod;
     const u32 log_t = a.log_t, T = 1u << log_t, I = 8u << log_t;
     const u32 maxord = a.maxord;
+    const u32 log_pb = log_t < 5u ? log_t : 5u, pbm = (1u << log_pb) - 1u, bpi = kUnits >> log_pb;   // C items: polynomials x blocks
     u32 *const ctl = a.ctl;
     u32 *const head = ctl + persist_ctl_head(xq);
 
     for (u32 li = tid0; li < 256u; li += kTH) ltw[li] = a.tw[li];   // the strided stages' twiddles, once per workgroup
+
+    // ---- lane 0's side of the protocol ----
+    auto rd_desc = [&](int base, Desc &d, u32 &res, u32 &status) {
+        d.phase = __builtin_amdgcn_readfirstlane(ctrl[base + kCtlPhase]);
+        d.ord = __builtin_amdgcn_readfirstlane(ctrl[base + kCtlOrd]);
+        d.r = __builtin_amdgcn_readfirstlane(ctrl[base + kCtlR]);
+        d.bind = __builtin_amdgcn_readfirstlane(ctrl[base + kCtlBind]);
+        res = __builtin_amdgcn_readfirstlane(ctrl[base + kCtlRes]);
+        status = __builtin_amdgcn_readfirstlane(ctrl[base + kCtlStatus]);
+    };
+    auto wr_desc = [&](int base, const PersistItem &it, u32 bind, u32 res, u32 status) {
+        ctrl[base + kCtlPhase] = it.phase; ctrl[base + kCtlOrd] = it.ord; ctrl[base + kCtlR] = it.r;
+        ctrl[base + kCtlBind] = bind; ctrl[base + kCtlRes] = res; ctrl[base + kCtlStatus] = status;
+    };
+    auto dep_word = [&](const PersistItem &it) -> u32 * {     // the counter a bound ticket waits for, or nullptr
+        if (it.phase == kPersistC) return ctl + persist_ctl_sdone(xq, it.ord, maxord);
+        if (MIDRING && it.ord >= a.ringslots) return ctl + persist_ctl_cdone(xq, it.ord - a.ringslots, maxord);
+        return nullptr;
+    };
+    // bind an ordinal to the next global tile (the holder of S(j, 0), once ordinal j - 1 is bound: prev != 0)
+    auto claim = [&](const PersistItem &it, u32 prev) -> u32 {
+        u32 b = kPersistInvalid;
+        if (prev != kPersistInvalid) {
+            const u32 g = ctl_add(ctl + persist_ctl_gtile(), 1u);
+            if ((u64)g < a.ntiles) b = g + 1u;
+        }
+        ctl_store(ctl + persist_ctl_bind(xq, it.ord, maxord), b);
+        return b;
+    };
+    // resolve a ticket by polling: the only place a workgroup waits for others.  -> bind, status
+    auto resolve_blocking = [&](const PersistItem &it, u32 &bind) -> u32 {
+        bind = kPersistInvalid;
+        if (it.ord >= maxord) return 0u;      // a ticket drawn on the way out: no tile can be bound that far
+        u32 *bp = ctl + persist_ctl_bind(xq, it.ord, maxord);
+        if (it.phase == kPersistS && it.r == 0) {
+            bind = ctl_load(bp);                  // non-zero: bound while looking ahead, only its dependency was missing
+            if (bind == 0) {
+                u32 prev = 1u;
+                if (it.ord > 0 && !wait_ge(bp - 1, 1u, &prev)) return (u32)kPersistErrBind;
+                bind = claim(it, prev);
+            }
+        } else if (!wait_ge(bp, 1u, &bind)) {
+            return (u32)kPersistErrBind;
+        }
+        if (bind != kPersistInvalid) {
+            u32 got;
+            if (u32 *dw = dep_word(it))
+                if (!wait_ge(dw, I, &got)) return it.phase == kPersistC ? (u32)kPersistErrSdone : (u32)kPersistErrCdone;
+        }
+        return 0u;
+    };
+    auto fail = [&](u32 status) {
+        atomicOr(ctl + persist_ctl_err(), status);
+        __hip_atomic_fetch_or(a.host_err, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word
+    };
+
+    // ---- every lane's side ----
+    auto ring_slot = [&](u32 ord) -> u64 * { return a.ring + ((((u64)xq * a.ringslots + ord % a.ringslots) << log_t) << 16); };
+    auto unit_poly = [&](const Desc &d, u32 uu) -> u32 { return ((d.r & ((T >> log_pb) - 1u)) << log_pb) + (uu & pbm); };
+    auto unit_blk = [&](const Desc &d, u32 uu) -> u32 { return (d.r >> (log_t - log_pb)) * bpi + (uu >> log_pb); };
+    auto has_work = [&](const Desc &d) -> bool {               // false: a ticket whose polynomials lie past the batch
+        const u64 tile0 = (u64)(d.bind - 1u) << log_t;
+        return d.phase == kPersistS ? tile0 + (d.r >> 3) < a.batch : tile0 + unit_poly(d, 0u) < a.batch;
+    };
+    // coefficient loads of a resolved ticket
+    auto issue_loads = [&](const Desc &d, u32 tid, u64 (&x)[16]) {
+        const u64 tile0 = (u64)(d.bind - 1u) << log_t;
+        if (d.phase == kPersistS) {
+            const u32 pl = d.r >> 3, cg = d.r & 7u, c = tid % 32u, tf = tid / 32u;
+            const u64 *__restrict__ pin = a.in + ((tile0 + pl) << 16) + cg * 32u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = ld_at<u64>(pin, ((field_of<S::A0>(tf, k) << 8) + c) * 8u);
+        } else {
+            const u32 u = tid >> 4, tf = tid & 15u, blk = unit_blk(d, u);
+            u32 pl = unit_poly(d, u);
+            if (tile0 + pl >= a.batch) pl = unit_poly(d, 0u);      // a missing polynomial's lanes redo the item's first one
+            const u64 *__restrict__ src = (MIDRING ? ring_slot(d.ord) + ((u64)pl << 16) : a.out + ((tile0 + pl) << 16)) + blk * 256u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = ld_mid(src, field_of<4>(tf, k) * 8u);
+        }
+    };
+    // this lane's entry of a C item's stage 8..11 twiddle tile: roots[((256 + blk) << i) + g] for the item's blocks,
+    // [block][2^i - 1 + g]; lanes past the tile's 15 x blocks entries load its last one and store nothing
+    auto load_tw0 = [&](const Desc &d, u32 tid) -> Tw {
+        const u32 e = tid < bpi * 15u ? tid : bpi * 15u - 1u;
+        const u32 bl = e / 15u, j = e - bl * 15u;
+        const u32 i = 31u - (u32)__builtin_clz(j + 1u), g = j + 1u - (1u << i);
+        return a.tw[((256u + unit_blk(d, 0u) + bl) << i) + g];
+    };
+
+    // lane 0: the tickets it holds beyond the current one, the control words in flight for the next one, and the
+    // completion it still owes for the previous item
+    u32 k_nxt = 0, k_nn = 0, pf_bind = 0, pf_dep = 0, owed = 0;   // owed: 1 + index of the sdone word
+    bool owes = false;                                            // uniform: the previous item was an S item with stores
+    Desc cur{};
+    u32 cur_res = 0, cur_loaded = 0;
+    if (tid0 == 0) {
+        const u32 k0 = ctl_add(head, 1u);
+        k_nxt = ctl_add(head, 1u);
+        wr_desc(0, persist_decode(k0, log_t, a.lag), 0u, 0u, 0u);
+    }
+    __syncthreads();
+    { u32 res, st; rd_desc(0, cur, res, st); }
+
+    u64 v[16];
+    // completion of the previous item: its stores have been acknowledged in every wave, then ONE counter add
+    auto settle = [&](u32 tid) {
+        if (owes) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) ctl_add(ctl + (owed - 1u), 1u);
+            owes = false;
+        }
+    };
 
     for (;;) {
         // opaque per iteration: the lane's index arithmetic (LDS slots, byte offsets) is then redone per item, as in the
         // two-pass kernels, instead of being hoisted out of the loop into ~30 registers that spill
         u32 tid = tid0;
         asm volatile("" : "+v"(tid));
+        __syncthreads();                                   // the LDS tile is free, the twiddle tile of a prefetched C item is in place
+        PersistItem nit{};
         if (tid == 0) {
-            const u64 k = ctl_add(head, 1u);
-            const PersistItem it = persist_decode(k, log_t, a.lag);
-            u32 status = 0, b = kPersistInvalid;
-            // Ordinals at or past maxord cannot be bound to a tile (a queue binds at most ntiles of them, as a prefix): they are
-            // the tickets workgroups draw on their way out, and touch no control word.
-            if (it.ord < maxord) {
-                u32 *bp = ctl + persist_ctl_bind(xq, it.ord, maxord);
-                if (it.phase == kPersistS && it.r == 0) {
-                    // bind this ordinal to the next global tile — after the previous ordinal of this queue has been bound, so
-                    // that the bound ordinals of a queue are a PREFIX (a workgroup leaves at the first C ticket without a tile)
-                    u32 prev = 1u;
-                    if (it.ord > 0 && !wait_ge(bp - 1, 1u, &prev)) status = kPersistErrBind;
-                    if (!status) {
-                        if (prev != kPersistInvalid) {
-                            const u32 g = ctl_add(ctl + persist_ctl_gtile(), 1u);
-                            b = (u64)g < a.ntiles ? g + 1u : kPersistInvalid;
-                        }
-                        ctl_store(bp, b);
-                    }
-                } else if (!wait_ge(bp, 1u, &b)) {
-                    status = kPersistErrBind;
-                }
-                if (!status && b != kPersistInvalid) {
-                    u32 got;
-                    if (it.phase == kPersistC) {
-                        if (!wait_ge(ctl + persist_ctl_sdone(xq, it.ord, maxord), I, &got)) status = kPersistErrSdone;
-                    } else if (MIDRING && it.ord >= a.ringslots) {
-                        if (!wait_ge(ctl + persist_ctl_cdone(xq, it.ord - a.ringslots, maxord), I, &got)) status = kPersistErrCdone;
-                    }
-                }
+            k_nn = ctl_add(head, 1u);                      // the ticket after next: needed one iteration from now
+            nit = persist_decode(k_nxt, log_t, a.lag);
+            pf_bind = 0; pf_dep = I;                       // control words of the next ticket: loads in flight until round 0 is done
+            if (nit.ord < maxord) {
+                const u32 *bp = ctl + persist_ctl_bind(xq, nit.ord, maxord);
+                if (nit.phase == kPersistS && nit.r == 0) pf_bind = nit.ord ? ctl_load(bp - 1) : 1u;
+                else pf_bind = ctl_load(bp);
+                if (const u32 *dw = dep_word(nit)) pf_dep = ctl_load(dw);
             }
-            if (status) {
-                atomicOr(ctl + persist_ctl_err(), status);
-                __hip_atomic_fetch_or(a.host_err, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word
+        }
+        // lane 0, once the control words have arrived: is the next ticket ready to run?  (never waits for another workgroup)
+        auto look_ahead = [&]() {
+            if (tid == 0) {
+                u32 bind = kPersistInvalid, res = 1u;
+                if (nit.ord < maxord) {
+                    if (nit.phase == kPersistS && nit.r == 0) {
+                        if (pf_bind != 0) bind = claim(nit, pf_bind); else res = 0u;
+                    } else {
+                        bind = pf_bind;
+                        if (bind == 0) res = 0u;
+                    }
+                    if (res && bind != kPersistInvalid && pf_dep < I) res = 0u;
+                }
+                wr_desc(kCtlWords, nit, bind, res, 0u);
             }
-            ctrl[kCtlPhase] = it.phase; ctrl[kCtlOrd] = it.ord; ctrl[kCtlR] = it.r; ctrl[kCtlBind] = b; ctrl[kCtlStatus] = status;
-        }
-        __syncthreads();
-        const u32 phase = __builtin_amdgcn_readfirstlane(ctrl[kCtlPhase]), ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlOrd]),
-                  r = __builtin_amdgcn_readfirstlane(ctrl[kCtlR]), bind = __builtin_amdgcn_readfirstlane(ctrl[kCtlBind]),
-                  status = __builtin_amdgcn_readfirstlane(ctrl[kCtlStatus]);
-        if (status) return;
-        if (bind == kPersistInvalid) {
-            if (phase == kPersistC) return;     // the queue has run dry
-            __syncthreads();                    // everybody has read ctrl before lane 0 rewrites it
-            continue;
-        }
-        const u64 tile0 = (u64)(bind - 1u) << log_t;                         // first polynomial of the tile
-        u64 *const ring_slot = MIDRING ? a.ring + ((((u64)xq * a.ringslots + ord % a.ringslots) << log_t) << 16) : nullptr;
+        };
 
-        if (phase == kPersistS) {
-            // ---- strided stages 0..7 of 32 columns of one polynomial (ntt_fwd_strided_kernel<8, 32>) ----
-            const u32 pl = r >> 3, cg = r & 7u;
-            const u64 poly = tile0 + pl;
-            if (poly < a.batch) {
-                const u32 c = tid % 32u, tf = tid / 32u;
-                const u64 *__restrict__ pin = a.in + (poly << 16) + cg * 32u;
-                u64 *__restrict__ pout = (MIDRING ? ring_slot + ((u64)pl << 16) : a.out + (poly << 16)) + cg * 32u;
-                u64 v[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<S::A0>(tf, k) << 8) + c) * 8u);
-                constexpr int P0 = kPmOne, P1 = pm_fwd_bound_out(S::R0, P0);
-                round_fwd_pm<S::R0, P0, true>(v, a.tw, 1u, m);
-                exchange_strided<32, S::A0, S::a_of(1), true>(v, lds, c, tf);
-                round_fwd_pm<4, P1, false>(v, ltw, (1u << S::ls0_of(1)) + (tf >> S::a_of(1)), m);
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const u32 off = ((field_of<S::a_of(1)>(tf, k) << 8) + c) * 8u;
-                    if (MIDRING) st_c<u64>(pout, off, v[k]);     // stays in this XCD's L2 for its consumers
-                    else st_at(pout, off, v[k]);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!cur_res) {                                    // the ticket could not be resolved ahead: poll for it now
+            settle(tid);                                   // nothing this workgroup owes may be what the ticket waits for
+            if (tid == 0) {
+                const PersistItem it{cur.phase, cur.ord, cur.r};
+                u32 bind;
+                const u32 status = resolve_blocking(it, bind);
+                if (status) fail(status);
+                wr_desc(0, it, bind, 1u, status);
             }
-            __syncthreads();                                      // every wave's stores have been acknowledged
-            if (tid == 0) ctl_add(ctl + persist_ctl_sdone(xq, ord, maxord), 1u);
-        } else {
-            // ---- contiguous stages 8..15 of 32 units (256 coefficients each) of the tile ----
-            const u32 log_pb = log_t < 5u ? log_t : 5u, pbm = (1u << log_pb) - 1u;     // polynomials per item
-            const u32 pgrp = r & ((T >> log_pb) - 1u), bgrp = r >> (log_t - log_pb);
-            const u32 u = tid >> 4, tf = tid & 15u;
-            auto unit_poly = [&](u32 uu) -> u32 { return (pgrp << log_pb) + (uu & pbm); };
-            auto unit_blk = [&](u32 uu) -> u32 { return bgrp * (kUnits >> log_pb) + (uu >> log_pb); };
-            const bool any = tile0 + (pgrp << log_pb) < a.batch;     // the item's first polynomial exists
-            if (any) {
-                const u32 blk = unit_blk(u);
-                u32 pl = unit_poly(u);
-                if (tile0 + pl >= a.batch) pl = pgrp << log_pb;       // a missing polynomial's lanes redo the first one
-                const u64 *__restrict__ src = (MIDRING ? ring_slot + ((u64)pl << 16) : a.out + ((tile0 + pl) << 16)) + blk * 256u;
-                u64 v[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = ld_mid(src, field_of<4>(tf, k) * 8u);
-                // stages 8..11: twiddles roots[((256 + blk) << i) + g], the same for the 16 lanes of a unit: staged once per
-                // item ([block of the item][2^i - 1 + g]) and read back as LDS broadcasts
-                const u32 bpi = kUnits >> log_pb;
-                if (tid < bpi * 15u) {
-                    const u32 bl = tid / 15u, j = tid - bl * 15u;
-                    const u32 i = 31u - (u32)__builtin_clz(j + 1u), g = j + 1u - (1u << i);
-                    ltw0[tid] = a.tw[((256u + bgrp * bpi + bl) << i) + g];
+            __syncthreads();
+            u32 res, status;
+            rd_desc(0, cur, res, status);
+            if (status) return;
+            cur_res = 1u;
+        }
+        const bool valid = cur.bind != kPersistInvalid;
+        if (!valid && cur.phase == kPersistC) {            // the queue has run dry: everything after this ticket is void too
+            settle(tid);
+            // ... including the two tickets this workgroup holds and will not run.  If one of them is the S(j, 0) that
+            // binds ordinal j, the holders of the other S(j, .) tickets are waiting for that word: bind it (to nothing).
+            if (tid == 0) {
+                const u32 held[2] = {k_nxt, k_nn};
+                for (int h = 0; h < 2; h++) {
+                    const PersistItem it = persist_decode(held[h], log_t, a.lag);
+                    if (it.phase == kPersistS && it.r == 0 && it.ord < maxord)
+                        ctl_store(ctl + persist_ctl_bind(xq, it.ord, maxord), kPersistInvalid);
                 }
+            }
+            return;
+        }
+        const bool work = valid && has_work(cur);
+        if (work && !cur_loaded) {
+            if (cur.phase == kPersistC) {
+                const Tw t0 = load_tw0(cur, tid);
+                issue_loads(cur, tid, v);
+                if (tid < bpi * 15u) ltw0[tid] = t0;
                 __syncthreads();
+            } else {
+                issue_loads(cur, tid, v);
+            }
+        }
+
+        // ---- first half: stages 0..3 of the pass in registers, scatter into the LDS tile ----
+        const u32 c = tid % 32u, tfs = tid / 32u;          // S item: column, row group
+        const u32 u = tid >> 4, tfc = tid & 15u;           // C item: unit, lane of the unit
+        if (work) {
+            if (cur.phase == kPersistS) {
+                // (in a persistent loop the compiler cannot prove the global table unclobbered, so it would not use scalar
+                // loads for these workgroup-uniform twiddles: they come from the LDS copy, as broadcast reads)
+                round_fwd_pm_f<S::R0, kPmOne>(v, [&](int i, int g) { return ltw[(1 << i) + g]; }, m);
+#pragma unroll
+                for (int k = 0; k < 16; k++) lds[field_of<S::A0>(tfs, k) * 32u + c] = v[k];
+            } else {
                 const Tw *tw0 = ltw0 + (u >> log_pb) * 15u;
                 round_fwd_pm_f<4, kPmPassBound>(v, [&](int i, int g) { return tw0[(1 << i) - 1 + g]; }, m);
 #pragma unroll
-                for (int k = 0; k < 16; k++) lds[pad16(u * 256u + field_of<4>(tf, k))] = v[k];
+                for (int k = 0; k < 16; k++) lds[pad16(u * 256u + field_of<4>(tfc, k))] = v[k];
             }
-            __syncthreads();
-            // every lane's loads of the intermediate have landed: the ring slot may be rewritten
-            if (MIDRING && tid == 0) ctl_add(ctl + persist_ctl_cdone(xq, ord, maxord), 1u);
-            if (any) {
-                const u32 blk = unit_blk(u);
-                u64 v[16];
+        }
+        look_ahead();
+        if (owes) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous item's stores (nothing younger is in flight)
+        __syncthreads();
+        if (tid == 0) {
+            if (owes) ctl_add(ctl + (owed - 1u), 1u);
+            // every lane's loads of the intermediate have landed (they were scattered): the ring slot may be rewritten
+            if (MIDRING && valid && cur.phase == kPersistC) ctl_add(ctl + persist_ctl_cdone(xq, cur.ord, maxord), 1u);
+        }
+        owes = false;
+        Desc nxt;
+        u32 nxt_res, nst;
+        rd_desc(kCtlWords, nxt, nxt_res, nst);
+        // The next item's coefficient loads are issued as soon as this item's registers are free (after its stores / its
+        // last scatter) and land across the hand-over.  (Issuing them here, into a second set of 32 registers, so that
+        // they land while the second half computes, does not fit 128 registers: the compiler spills the whole set.)
+        const bool pre = nxt_res && nxt.bind != kPersistInvalid && has_work(nxt);
+        const bool pre_c = pre && nxt.phase == kPersistC;
+        Tw t0n = ltw[0];                                   // (placeholder; the next C item's twiddle entry when pre_c)
+        if (pre_c) t0n = load_tw0(nxt, tid);               // issued first: it is waited for first (hand-over)
+
+        // ---- second half: gather, stages 4..7 of the pass, stores ----
+        if (work) {
+            const u64 tile0 = (u64)(cur.bind - 1u) << log_t;
+            if (cur.phase == kPersistS) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = lds[pad16(u * 256u + field_of<0>(tf, k))];
+                for (int k = 0; k < 16; k++) v[k] = lds[field_of<S::a_of(1)>(tfs, k) * 32u + c];
+                constexpr int P1 = pm_fwd_bound_out(S::R0, kPmOne);
+                const u32 T1 = (1u << S::ls0_of(1)) + (tfs >> S::a_of(1));
+                round_fwd_pm_f<4, P1>(v, [&](int i, int g) { return ltw[(T1 << i) + g]; }, m);
+                const u32 pl = cur.r >> 3, cg = cur.r & 7u;
+                u64 *__restrict__ pout = (MIDRING ? ring_slot(cur.ord) + ((u64)pl << 16) : a.out + ((tile0 + pl) << 16)) + cg * 32u;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const u32 off = ((field_of<S::a_of(1)>(tfs, k) << 8) + c) * 8u;
+                    if (MIDRING) st_c<u64>(pout, off, v[k]);     // stays in this XCD's L2 for its consumers
+                    else st_at(pout, off, v[k]);
+                    if ((k & 3) == 3) FHE_SCHED_FENCE();
+                }
+                if (pre) issue_loads(nxt, tid, v);
+            } else {
+                const u32 blk = unit_blk(cur, u);
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = lds[pad16(u * 256u + field_of<0>(tfc, k))];
                 // stages 12..15: roots[((4096 + 16 blk + tf) << i) + g], laid out [blk][2^i - 1 + g][tf] (twc)
-                const Tw *__restrict__ tc = a.twc + (size_t)blk * 240u + tf;
+                const Tw *__restrict__ tc = a.twc + (size_t)blk * 240u + tfc;
                 constexpr int B1 = pm_fwd_bound_out(4, kPmPassBound);
                 round_fwd_pm_f<4, B1>(v, [&](int i, int g) { return tc[((1 << i) - 1 + g) * 16]; }, m);
                 // a thread rewrites exactly the slots it has just gathered: no barrier before the scatter
 #pragma unroll
-                for (int k = 0; k < 16; k++) lds[pad16(u * 256u + field_of<0>(tf, k))] = pm_canon(v[k], m);
+                for (int k = 0; k < 16; k++) {
+                    lds[pad16(u * 256u + field_of<0>(tfc, k))] = pm_canon(v[k], m);
+                    if ((k & 3) == 3) FHE_SCHED_FENCE();
+                }
+                if (pre) issue_loads(nxt, tid, v);
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const u32 e = i * kTH + tid, wu = e >> 8, f = e & 255u;
-                    const u64 poly = tile0 + unit_poly(wu);
-                    if (poly < a.batch) st_at(a.out + (poly << 16) + unit_blk(wu) * 256u, f * 8u, lds[pad16(e)]);
+                    const u64 poly = tile0 + unit_poly(cur, wu);
+                    if (poly < a.batch) st_at(a.out + (poly << 16) + unit_blk(cur, wu) * 256u, f * 8u, lds[pad16(e)]);
+                    if ((i & 3) == 3) FHE_SCHED_FENCE();
                 }
             }
         }
+        // an S ticket owes its completion even when its polynomial lies past the batch (its consumers count to 8T)
+        if (valid && cur.phase == kPersistS) {
+            owes = true;
+            if (tid == 0) owed = 1u + (u32)persist_ctl_sdone(xq, cur.ord, maxord);
+        }
+        // ---- hand over ----
+        if (pre && !work) issue_loads(nxt, tid, v);        // (an item without work did not reach the places above)
+        if (pre_c && tid < bpi * 15u) ltw0[tid] = t0n;     // read after the barrier at the top
+        cur = nxt;
+        cur_res = nxt_res;
+        cur_loaded = pre ? 1u : 0u;
+        if (tid == 0) k_nxt = k_nn;
     }
 }
 

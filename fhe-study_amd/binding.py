@@ -43,7 +43,7 @@ EXPORTS = [
     "fhe_rq_pointwise_mul", "fhe_rq_check_canonical",
     "fhe_ntt_forward_dev", "fhe_ntt_inverse_dev", "fhe_rq_mul_dev",
     "fhe_rq_mul_workspace_bytes", "fhe_rq_pointwise_mul_dev", "fhe_fill_synthetic_dev",
-    "fhe_ntt_set_batch_tile", "fhe_ntt_set_persist", "fhe_ntt_persist_status", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
+    "fhe_ntt_set_batch_tile", "fhe_ntt_set_persist", "fhe_ntt_persist_status", "fhe_ntt_persist_profile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
     "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace", "fhe_ntt_workspace_bytes",
@@ -177,6 +177,7 @@ def load_library():
     L.fhe_ntt_set_batch_tile.argtypes = [_sz]
     L.fhe_ntt_set_persist.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
     L.fhe_ntt_persist_status.argtypes = []
+    L.fhe_ntt_persist_profile.argtypes = [_vp]
     L.fhe_ntt_kernel_timing_enable.argtypes = [_int]
     L.fhe_ntt_kernel_timing_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), _p64, _int]
     L.fhe_ntt_kernel_timing_reset.argtypes = []

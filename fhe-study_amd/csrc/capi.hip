@@ -473,6 +473,14 @@ extern "C" int fhe_ntt_set_persist(unsigned tile_polys, unsigned lag, unsigned r
     g_persist.lag = lag; g_persist.ringslots = ringslots;
     return FHE_OK;
 }
+// Diagnostic: with a device buffer of 26 u64 words registered here, lane 0 of every persistent workgroup adds the shader-
+// clock ticks it spent in each part of its iterations (by item kind: 12 + 12 words), and the items it ran (2 words).
+static void *g_persist_prof = nullptr;
+extern "C" int fhe_ntt_persist_profile(void *d_words26) {
+    std::lock_guard<std::mutex> lk(g_cfg_lock);
+    g_persist_prof = d_words26;
+    return FHE_OK;
+}
 static int persist_host_err(uint32_t **dptr) {
     std::lock_guard<std::mutex> lk(g_cfg_lock);
     if (!g_persist_host_err) {
@@ -536,7 +544,7 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
         grid = g;
     }
     hipError_t e = fhe::launch_ntt_forward_persist(dp, twc, (const u64 *)d_in, (u64 *)d_out, batch, tune, (uint32_t *)w,
-                                                   rb ? (u64 *)((char *)w + cb) : nullptr, herr, grid, st);
+                                                   rb ? (u64 *)((char *)w + cb) : nullptr, herr, (u64 *)g_persist_prof, grid, st);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward_persist");
     return FHE_OK;
 }

@@ -25,7 +25,8 @@ constexpr int kUnits = 32;                     // 256-coefficient units of a C i
 constexpr u32 kSpinCap = 1u << 21;             // polls before a wait gives up (seconds)
 constexpr size_t kTileBytes = (size_t)(kUnits * 256 + kUnits * 16) * 8;   // padded C tile (>= the 64 KiB S tile)
 constexpr size_t kTw0Bytes = (size_t)kUnits * 15 * sizeof(Tw);             // stages 8..11 of a C item: 15 twiddles per block
-constexpr size_t kLdsBytes = kTileBytes + 256 * sizeof(Tw) + kTw0Bytes + 64;   // + the strided stages' twiddles + control words
+constexpr size_t kProfWords = 27;                                           // profile accumulators of lane 0 (u64): 2 phases x 12 + items x 2 + last
+constexpr size_t kLdsBytes = kTileBytes + 256 * sizeof(Tw) + kTw0Bytes + 64 + kProfWords * 8;   // + the strided stages' twiddles + control words
 
 __device__ __forceinline__ u32 xcc_id() {
     u32 v;
@@ -53,10 +54,9 @@ __device__ __forceinline__ u64 ld_mid(const u64 *base, u32 byte_off) {
 // compiler-only fence: memory operations are not moved across it (bounds how far loads are hoisted = registers held)
 #define FHE_SCHED_FENCE() asm volatile("" ::: "memory")
 
-// R stages on the 16 registers with the twiddle of (stage i, group g) supplied by `twf`.  The workgroup keeps the NEXT
-// item's 16 coefficients in registers while this runs, so the twiddle reads must not all be hoisted to the front (60
-// registers): compiler fences keep at most four twiddles (16 registers) ahead of their use.
-template <int R, int BIN, typename F>
+// R stages on the 16 registers with the twiddle of (stage i, group g) supplied by `twf`.  FENCE > 0: a compiler fence
+// every FENCE twiddles, so that twiddles READ FROM LDS are not all hoisted to the front of the round (60 registers).
+template <int R, int BIN, int FENCE, typename F>
 __device__ __forceinline__ void round_fwd_pm_f(u64 (&v)[16], F twf, const Mod &m) {
     static_assert(pm_fwd_bound_out(R, BIN) <= kPmCap, "a stage would overflow");
 #pragma unroll
@@ -65,7 +65,7 @@ __device__ __forceinline__ void round_fwd_pm_f(u64 (&v)[16], F twf, const Mod &m
         const bool red = pm_fwd_needs_red(pm_fwd_bound_out(i, BIN));
 #pragma unroll
         for (int g = 0; g < (1 << i); g++) {
-            if ((g & 3) == 0) FHE_SCHED_FENCE();           // at most four twiddles (16 registers) ahead of their use
+            if (FENCE > 0 && (g % (FENCE > 0 ? FENCE : 1)) == 0) FHE_SCHED_FENCE();
             const Tw t = twf(i, g);
 #pragma unroll
             for (int l = 0; l < span; l++) {
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + kTileBytes);
     Tw *ltw0 = ltw + 256;                                                   // a C item's stage 8..11 twiddles [block][15]
     u32 *ctrl = reinterpret_cast<u32 *>(smem_raw + kTileBytes + 256 * sizeof(Tw) + kTw0Bytes);
+    u64 *prof = reinterpret_cast<u64 *>(smem_raw + kTileBytes + 256 * sizeof(Tw) + kTw0Bytes + 64);
     const u32 tid0 = threadIdx.x;
     const u32 xq = xcc_id();
     const Mod &m = a.mod;
@@ -120,6 +121,23 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
     u32 *const head = ctl + persist_ctl_head(xq);
 
     for (u32 li = tid0; li < 256u; li += kTH) ltw[li] = a.tw[li];   // the strided stages' twiddles, once per workgroup
+    // optional profile (a.prof != nullptr): lane 0 accumulates shader-clock ticks per part of an iteration, by item kind
+    const bool profiling = a.prof != nullptr;
+    if (profiling && tid0 == 0) {
+        for (u32 i = 0; i < kProfWords; i++) prof[i] = 0;
+        prof[kProfWords - 1] = (u64)clock64();
+    }
+    auto tick = [&](u32 tid, u32 phase, u32 part) {           // time since the last tick goes to (phase, part)
+        if (profiling && tid == 0) {
+            const u64 now = (u64)clock64();
+            prof[phase * 12u + part] += now - prof[kProfWords - 1];
+            prof[kProfWords - 1] = now;
+        }
+    };
+    auto prof_flush = [&](u32 tid) {
+        if (profiling && tid == 0)
+            for (u32 i = 0; i < kProfWords - 1; i++) atomicAdd((unsigned long long *)a.prof + i, (unsigned long long)prof[i]);
+    };
 
     // ---- lane 0's side of the protocol ----
     auto rd_desc = [&](int base, Desc &d, u32 &res, u32 &status) {
@@ -240,7 +258,9 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
         // two-pass kernels, instead of being hoisted out of the loop into ~30 registers that spill
         u32 tid = tid0;
         asm volatile("" : "+v"(tid));
+        tick(tid, cur.phase, 6u);                          // hand-over of the previous iteration (charged to the new item's kind)
         __syncthreads();                                   // the LDS tile is free, the twiddle tile of a prefetched C item is in place
+        tick(tid, cur.phase, 0u);                          // wait at the top barrier
         PersistItem nit{};
         if (tid == 0) {
             k_nn = ctl_add(head, 1u);                      // the ticket after next: needed one iteration from now
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
         const bool valid = cur.bind != kPersistInvalid;
         if (!valid && cur.phase == kPersistC) {            // the queue has run dry: everything after this ticket is void too
             settle(tid);
+            prof_flush(tid);
             // ... including the two tickets this workgroup holds and will not run.  If one of them is the S(j, 0) that
             // binds ordinal j, the holders of the other S(j, .) tickets are waiting for that word: bind it (to nothing).
             if (tid == 0) {
@@ -312,6 +333,8 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
             }
         }
 
+        tick(tid, cur.phase, 1u);                          // resolving by polling / loads that could not be issued ahead
+        if (profiling && tid == 0 && work) prof[24 + cur.phase] += 1;
         // ---- first half: stages 0..3 of the pass in registers, scatter into the LDS tile ----
         const u32 c = tid % 32u, tfs = tid / 32u;          // S item: column, row group
         const u32 u = tid >> 4, tfc = tid & 15u;           // C item: unit, lane of the unit
@@ -319,19 +342,22 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
             if (cur.phase == kPersistS) {
                 // (in a persistent loop the compiler cannot prove the global table unclobbered, so it would not use scalar
                 // loads for these workgroup-uniform twiddles: they come from the LDS copy, as broadcast reads)
-                round_fwd_pm_f<S::R0, kPmOne>(v, [&](int i, int g) { return ltw[(1 << i) + g]; }, m);
+                round_fwd_pm_f<S::R0, kPmOne, 4>(v, [&](int i, int g) { return ltw[(1 << i) + g]; }, m);
 #pragma unroll
                 for (int k = 0; k < 16; k++) lds[field_of<S::A0>(tfs, k) * 32u + c] = v[k];
             } else {
                 const Tw *tw0 = ltw0 + (u >> log_pb) * 15u;
-                round_fwd_pm_f<4, kPmPassBound>(v, [&](int i, int g) { return tw0[(1 << i) - 1 + g]; }, m);
+                round_fwd_pm_f<4, kPmPassBound, 4>(v, [&](int i, int g) { return tw0[(1 << i) - 1 + g]; }, m);
 #pragma unroll
                 for (int k = 0; k < 16; k++) lds[pad16(u * 256u + field_of<4>(tfc, k))] = v[k];
             }
         }
+        tick(tid, cur.phase, 2u);                          // first half (waits for the coefficients)
         look_ahead();
         if (owes) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous item's stores (nothing younger is in flight)
+        tick(tid, cur.phase, 3u);                          // looking ahead + the previous item's store acknowledgements
         __syncthreads();
+        tick(tid, cur.phase, 4u);                          // wait at the exchange barrier
         if (tid == 0) {
             if (owes) ctl_add(ctl + (owed - 1u), 1u);
             // every lane's loads of the intermediate have landed (they were scattered): the ring slot may be rewritten
@@ -356,8 +382,10 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
 #pragma unroll
                 for (int k = 0; k < 16; k++) v[k] = lds[field_of<S::a_of(1)>(tfs, k) * 32u + c];
                 constexpr int P1 = pm_fwd_bound_out(S::R0, kPmOne);
+                tick(tid, 0u, 7u);                         // S: descriptor read + gather
                 const u32 T1 = (1u << S::ls0_of(1)) + (tfs >> S::a_of(1));
-                round_fwd_pm_f<4, P1>(v, [&](int i, int g) { return ltw[(T1 << i) + g]; }, m);
+                round_fwd_pm_f<4, P1, 4>(v, [&](int i, int g) { return ltw[(T1 << i) + g]; }, m);
+                tick(tid, 0u, 8u);                         // S: stages 4..7
                 const u32 pl = cur.r >> 3, cg = cur.r & 7u;
                 u64 *__restrict__ pout = (MIDRING ? ring_slot(cur.ord) + ((u64)pl << 16) : a.out + ((tile0 + pl) << 16)) + cg * 32u;
 #pragma unroll
@@ -367,23 +395,31 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
                     else st_at(pout, off, v[k]);
                     if ((k & 3) == 3) FHE_SCHED_FENCE();
                 }
+                tick(tid, 0u, 9u);                         // S: stores
                 if (pre) issue_loads(nxt, tid, v);
+                tick(tid, 0u, 10u);                        // S: issuing the next item's loads
             } else {
                 const u32 blk = unit_blk(cur, u);
 #pragma unroll
                 for (int k = 0; k < 16; k++) v[k] = lds[pad16(u * 256u + field_of<0>(tfc, k))];
+                tick(tid, 1u, 7u);                         // C: descriptor read + gather
                 // stages 12..15: roots[((4096 + 16 blk + tf) << i) + g], laid out [blk][2^i - 1 + g][tf] (twc)
+                // (global loads, not fenced: the compiler issues all 15 up front and their L2 latency is paid once)
                 const Tw *__restrict__ tc = a.twc + (size_t)blk * 240u + tfc;
                 constexpr int B1 = pm_fwd_bound_out(4, kPmPassBound);
-                round_fwd_pm_f<4, B1>(v, [&](int i, int g) { return tc[((1 << i) - 1 + g) * 16]; }, m);
+                round_fwd_pm_f<4, B1, 0>(v, [&](int i, int g) { return tc[((1 << i) - 1 + g) * 16]; }, m);
+                tick(tid, 1u, 8u);                         // C: stages 12..15
                 // a thread rewrites exactly the slots it has just gathered: no barrier before the scatter
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     lds[pad16(u * 256u + field_of<0>(tfc, k))] = pm_canon(v[k], m);
                     if ((k & 3) == 3) FHE_SCHED_FENCE();
                 }
+                tick(tid, 1u, 9u);                         // C: canonical + scatter
                 if (pre) issue_loads(nxt, tid, v);
+                tick(tid, 1u, 10u);                        // C: issuing the next item's loads
                 __syncthreads();
+                tick(tid, 1u, 11u);                        // C: wait at the store barrier
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const u32 e = i * kTH + tid, wu = e >> 8, f = e & 255u;
@@ -393,6 +429,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
                 }
             }
         }
+        tick(tid, cur.phase, 5u);                          // second half
         // an S ticket owes its completion even when its polynomial lies past the batch (its consumers count to 8T)
         if (valid && cur.phase == kPersistS) {
             owes = true;
@@ -439,7 +476,7 @@ size_t persist_ring_bytes(const PersistTune &t) {
 }
 
 hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const u64 *in, u64 *out, u64 batch,
-                                      const PersistTune &t, u32 *ctl, u64 *ring, u32 *host_err, unsigned grid, hipStream_t st) {
+                                      const PersistTune &t, u32 *ctl, u64 *ring, u32 *host_err, u64 *prof, unsigned grid, hipStream_t st) {
     if (!persist_supported(p)) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     if (t.log_t > 10 || (t.ringslots && t.ringslots < t.lag + 1)) return hipErrorInvalidValue;
@@ -450,7 +487,7 @@ hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const 
     a.ntiles = (batch + ((1ull << t.log_t) - 1)) >> t.log_t;
     a.log_t = t.log_t; a.lag = t.lag; a.ringslots = t.ringslots;
     a.maxord = persist_maxord(a.ntiles, t.lag);
-    a.ctl = ctl; a.host_err = host_err;
+    a.ctl = ctl; a.host_err = host_err; a.prof = prof;
     hipError_t e = hipMemsetAsync(ctl, 0, persist_ctl_words(a.maxord) * sizeof(u32), st);
     if (e != hipSuccess) return e;
     const void *fn = t.ringslots ? (const void *)ntt_fwd_persist_kernel<true> : (const void *)ntt_fwd_persist_kernel<false>;

@@ -23,6 +23,7 @@ struct PersistArgs {
     uint32_t log_t, lag, ringslots, maxord;
     uint32_t *ctl;    // control block, zeroed before the launch (persist_sched.hpp)
     uint32_t *host_err;   // pinned host word (device pointer): error bits are OR-ed in here too, where the host can see them
+    u64 *prof;            // nullptr, or 26 words: lane 0's shader-clock ticks per part of an iteration (fhe_ntt_persist_profile)
 };
 
 bool persist_supported(const DevicePlan &p);
@@ -34,6 +35,6 @@ hipError_t persist_grid(unsigned *grid);
 // ctl: persist_ctl_bytes(t, batch) bytes; ring: persist_ring_bytes(t) bytes (nullptr when t.ringslots == 0).
 // The error word is ctl[persist_ctl_err()], mirrored into *host_err: non-zero once the launch has finished = a bounded wait ran out.
 hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const u64 *in, u64 *out, u64 batch,
-                                      const PersistTune &t, uint32_t *ctl, u64 *ring, uint32_t *host_err, unsigned grid, hipStream_t st);
+                                      const PersistTune &t, uint32_t *ctl, u64 *ring, uint32_t *host_err, u64 *prof, unsigned grid, hipStream_t st);
 
 }  // namespace fhe

@@ -167,7 +167,7 @@ __device__ __forceinline__ u64 canon8(u64 x, const Mod &m) { return canon4(csub_
 // conditional subtraction that only halves).  Measured in registers (tools/ubench_bfly.hip v17 against v8,
 // profiles/r03_ubench_bfly.txt): 59.9 against 87.6 cycles per butterfly-wave.
 //
-// The 14 instructions of a butterfly are ONE asm statement: between two dependent asm statements the compiler inserts an
+// The 13 instructions of a butterfly (14 until round 4: see ct_bfly_pm) are ONE asm statement: between two dependent asm statements the compiler inserts an
 // s_nop (it must assume a dst-forwarding hazard inside any inline asm), five per butterfly when each instruction is its
 // own statement.  Sub-registers of a 64-bit asm operand cannot be named, so the temporaries are the physical registers
 // v[2:7], listed as clobbers (the compiler keeps nothing there across a butterfly; inputs and outputs are its own).
@@ -237,59 +237,66 @@ __device__ __forceinline__ u64 pm_below_2k(u64 x, const Mod &m) { return pm_redu
 __device__ __forceinline__ u64 mul_var_pm(u64 a, u64 b, const Mod &m) { return mul_pm<false>(a, b, pm_shift32(b, m), m); }
 
 // Forward butterfly (ntt.rs:57-62): x' = u + r, y' = u - r + 3q  (r = y w < 2q + q/16), u = x < B q  ->  both below
-// (B + 3) q; the caller reduces x first when B + 3 would pass 8.
+// (B + 3) q; the caller reduces x first when B + 3 would pass 8.  13 instructions: the subtraction is a borrow chain
+// (v_sub_co_u32 / v_subb_co_u32 on the halves: one instruction fewer than "+ ~r + 1", tools/ubench_bfly.hip v18: 55.4
+// against 59.8 cycles per butterfly-wave); the halves of a 64-bit asm operand cannot be named, so u + 3q is formed in the
+// physical pair v[4:5] and y' leaves as two 32-bit outputs, which the compiler joins into a register pair without moves.
+// Outputs written by the LAST instructions only (y', the inverse butterfly's product) are not early-clobber: every compiler-
+// allocated input has been read by then, so they may take over y's registers.
 template <bool SGPR_TW>
 __device__ __forceinline__ void ct_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, const Mod &m) {
     const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
     const u32 a0 = (u32)w, a1 = (u32)(w >> 32), b0 = (u32)w2, b1 = (u32)(w2 >> 32);
-    u64 yo;
+    const u64 k3 = m.q3p1 - 1ull;                                 // 3q
+    u32 yl, yh;
 #define FHE_PM_CT_BODY                                                                                 \
-    "v_lshl_add_u64 %[yo], %[x], 0, %[k3]\n\t"                   /* u + 3q + 1 */                      \
+    "v_lshl_add_u64 v[4:5], %[x], 0, %[k3]\n\t"                   /* u + 3q */                          \
     FHE_PM_PRODUCT("%[y0]", "%[y1]", "v[2:3]")                                                         \
     "v_lshl_add_u64 %[x], %[x], 0, v[2:3]\n\t"                   /* x' = u + r */                      \
-    "v_not_b32 v2, v2\n\t"                                                                             \
-    "v_not_b32 v3, v3\n\t"                                                                             \
-    "v_lshl_add_u64 %[yo], %[yo], 0, v[2:3]"                     /* y' = u + 3q + 1 + ~r */
+    "v_sub_co_u32 %[yl], vcc, v4, v2\n\t"                                                              \
+    "v_subb_co_u32 %[yh], vcc, v5, v3, vcc"                      /* y' = u + 3q - r */
     if constexpr (SGPR_TW)
         asm(FHE_PM_CT_BODY
-            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [x] "+&v"(x), [yl] "=v"(yl), [yh] "=v"(yh)
             : [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1),
-              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [k3] "s"(m.q3p1)
-            : "vcc", "v2", "v3", "v6", "v7");
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [k3] "s"(k3)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
     else
         asm(FHE_PM_CT_BODY
-            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [x] "+&v"(x), [yl] "=v"(yl), [yh] "=v"(yh)
             : [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
-              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [k3] "s"(m.q3p1)
-            : "vcc", "v2", "v3", "v6", "v7");
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [k3] "s"(k3)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
 #undef FHE_PM_CT_BODY
-    y = yo;
+    y = ((u64)yh << 32) | yl;
 }
 
 // Inverse butterfly (ntt.rs:91-96): x' = x + y, y' = (x - y + K q) w.  kq1 = K q + 1 with K q >= the bound of y.
+// x - y + K q is the same borrow chain (12 instructions in all); x is written before the product reads its operands,
+// hence early-clobber.
 template <bool SGPR_TW>
 __device__ __forceinline__ void gs_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, u64 kq1, const Mod &m) {
     const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
     const u32 a0 = (u32)w, a1 = (u32)(w >> 32), b0 = (u32)w2, b1 = (u32)(w2 >> 32);
+    const u64 kq = kq1 - 1ull;
     u64 yo;
 #define FHE_PM_GS_BODY                                                                                 \
-    "v_not_b32 v2, %[y0]\n\t"                                                                          \
-    "v_not_b32 v3, %[y1]\n\t"                                                                          \
-    "v_lshl_add_u64 v[4:5], %[x], 0, %[kq1]\n\t"                                                       \
-    "v_lshl_add_u64 v[4:5], v[4:5], 0, v[2:3]\n\t"               /* d = x - y + K q */                 \
+    "v_lshl_add_u64 v[4:5], %[x], 0, %[kq]\n\t"                                                        \
+    "v_sub_co_u32 v4, vcc, v4, %[y0]\n\t"                                                              \
+    "v_subb_co_u32 v5, vcc, v5, %[y1], vcc\n\t"                  /* d = x + K q - y */                 \
     "v_lshl_add_u64 %[x], %[x], 0, %[y]\n\t"                     /* x' = x + y */                      \
     FHE_PM_PRODUCT("v4", "v5", "%[yo]")
     if constexpr (SGPR_TW)
         asm(FHE_PM_GS_BODY
-            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [x] "+&v"(x), [yo] "=v"(yo)
             : [y] "v"(y), [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1),
-              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [kq1] "s"(kq1)
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [kq] "s"(kq)
             : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
     else
         asm(FHE_PM_GS_BODY
-            : [x] "+v"(x), [yo] "=&v"(yo)
+            : [x] "+&v"(x), [yo] "=v"(yo)
             : [y] "v"(y), [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
-              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [kq1] "s"(kq1)
+              [c2] "s"(m.pm_c2), [mask] "s"(m.pm_mask), [sh] "s"(m.pm_sh), [kq] "s"(kq)
             : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
 #undef FHE_PM_GS_BODY
     y = yo;

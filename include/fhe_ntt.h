@@ -189,6 +189,8 @@ int fhe_ntt_set_batch_tile(size_t polys);
  * bounded; fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if one ran out, and clears the flag. */
 int fhe_ntt_set_persist(unsigned tile_polys, unsigned lag, unsigned ringslots);
 int fhe_ntt_persist_status(void);
+/* diagnostic: d_words26 = device buffer of 26 uint64_t (zeroed by the caller), or NULL to stop; see tools/persist_bench.py */
+int fhe_ntt_persist_profile(void *d_words26);
 /* When enabled, every kernel launch is bracketed by HIP events on its stream;
  * fhe_ntt_kernel_timing_read() synchronises, and returns per-kernel totals
  * since the last reset.  `names` receives up to `cap` NUL-terminated names of

@@ -69,5 +69,18 @@ for (T, L, R) in [(0, 0, 0)] + cfgs:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     B.persist_status()
+    prof = ""
+    if T and os.environ.get("PERSIST_PROFILE"):
+        pw = torch.zeros(26, dtype=torch.int64, device="cuda:0")
+        B.load_library().fhe_ntt_persist_profile(pw.data_ptr())
+        run(x, y, batch)
+        torch.cuda.synchronize()
+        B.load_library().fhe_ntt_persist_profile(None)
+        w = pw.cpu().tolist()
+        names = ["top-barrier", "poll/late-loads", "half1", "look-ahead", "xchg-barrier", "half2-rest", "hand-over", "gather", "round1", "epi-a", "next-loads", "store-barrier"]
+        for ph, nm in ((0, "S"), (1, "C")):
+            items = max(w[24 + ph], 1)
+            tot = sum(w[ph * 12:ph * 12 + 12])
+            prof += f"\n      {nm}: {items} items, {tot / items:.0f} ticks/item: " + ", ".join(f"{n} {w[ph * 12 + i] / items:.0f}" for i, n in enumerate(names))
     print(f"time batch={batch} T={T} L={L} R={R}: {dt*1e3:.3f} ms  {batch/dt/1e6:.3f} M NTT/s  {batch*n*16/dt/8e12:.4f} of 8 TB/s"
-          f"  (x 65536/batch = {dt*1e3*65536/batch:.2f} ms per step)", flush=True)
+          f"  (x 65536/batch = {dt*1e3*65536/batch:.2f} ms per step){prof}", flush=True)

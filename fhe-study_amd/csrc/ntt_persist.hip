@@ -20,13 +20,15 @@ namespace fhe {
 
 namespace {
 
-constexpr int kTH = 512;                       // threads of a persistent workgroup
-constexpr int kUnits = 32;                     // 256-coefficient units of a C item (16 threads each)
+constexpr int kTH = 256;                       // threads of a persistent workgroup: four per CU, as independent instruction streams
+constexpr int kUnits = 16;                     // 256-coefficient units of a C item (16 threads each)
+constexpr int kCW = 16;                        // columns of an S item
+constexpr int kSRow = 17;                      // its row stride in the LDS tile: odd, so that the two row groups a half-wave gathers from hit different banks
 constexpr u32 kSpinCap = 1u << 21;             // polls before a wait gives up (seconds)
-constexpr size_t kTileBytes = (size_t)(kUnits * 256 + kUnits * 16) * 8;   // padded C tile (>= the 64 KiB S tile)
-constexpr size_t kTw0Bytes = (size_t)kUnits * 15 * sizeof(Tw);             // stages 8..11 of a C item: 15 twiddles per block
-constexpr size_t kProfWords = 27;                                           // profile accumulators of lane 0 (u64): 2 phases x 12 + items x 2 + last
-constexpr size_t kLdsBytes = kTileBytes + 256 * sizeof(Tw) + kTw0Bytes + 64 + kProfWords * 8;   // + the strided stages' twiddles + control words
+constexpr size_t kTileBytes = (size_t)(kUnits * 256 + kUnits * 16) * 8;   // padded C tile (>= the 32 KiB S tile)
+constexpr size_t kProfWords = 27;              // profile accumulators of lane 0 (u64): 2 phases x 12 + items x 2 + last
+// tile + ONE 256-entry twiddle tile (whatever the current item needs) + control words + profile
+constexpr size_t kLdsBytes = kTileBytes + 256 * sizeof(Tw) + 64 + kProfWords * 8;
 
 __device__ __forceinline__ u32 xcc_id() {
     u32 v;
@@ -36,7 +38,7 @@ __device__ __forceinline__ u32 xcc_id() {
 __device__ __forceinline__ u32 ctl_add(u32 *p, u32 x) { return __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 ctl_load(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctl_store(u32 *p, u32 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// one lane: poll until *p >= target (or != 0 when target == 0 means "any"); false when the spin ran out
+// one lane: poll until *p >= target; false when the spin ran out
 __device__ __forceinline__ bool wait_ge(const u32 *p, u32 target, u32 *got) {
     for (u32 it = 0; it < kSpinCap; it++) {
         const u32 v = ctl_load(p);
@@ -90,37 +92,44 @@ struct Desc {          // a ticket as every lane knows it (wave-uniform)
 
 // MIDRING: the intermediate lives in a.ring (per-XCD slots, rewritten in place); otherwise in a.out.
 //
-// One iteration = one work item, software-pipelined two tickets deep:
+// Work items (persist_sched.hpp) are 4096 coefficients: an S item = stages 0..7 of 16 columns of a polynomial, a C item =
+// stages 8..15 of 16 units of 256 coefficients — 16 polynomials x one block when the tile has 16 polynomials or more (WIDE:
+// all 16 units share their twiddles, as in the two-pass contiguous kernel), fewer polynomials x more blocks otherwise.
+// The twiddles an item needs are ONE tile of <= 256 entries in LDS, one entry per lane: the 255 of the strided stages; a
+// block's 255 (wide C item); or 15 per block for stages 8..11, with stages 12..15 read from the lane-ordered global table.
+//
+// One iteration = one work item, with the control two tickets deep:
 //   top      lane 0 draws the ticket after next (nobody waits for it) and starts the loads of the NEXT ticket's control
 //            words (its tile binding, the counter it depends on)
-//   round 0  first four stages of the item whose coefficients arrived during the PREVIOUS item
-//            lane 0 looks at the control words that have arrived: next ticket resolved or not
-//   barrier  (the LDS exchange's) — behind it: the previous item's completion is signalled (its stores have been waited
-//            for), every lane learns the next ticket and, if it is resolved, issues its coefficient loads
-//   round 1  last four stages, stores
-// so that neither the ticket, nor the dependency check, nor the HBM latency of the next item's coefficients is waited
-// for — unless the next ticket's dependencies are not met yet: then it is resolved at the top of its own iteration by
-// polling (bounded), which is the only place a workgroup ever waits for another.  Holding tickets ahead is safe: a
-// workgroup runs its tickets in order and only ever blocks on the one it is running.
+//   half 1   first four stages of the item; lane 0 then looks at the control words that have arrived: next ticket
+//            resolved or not
+//   barrier  (the LDS exchange's) — behind it the previous item's completion is signalled (its stores have been waited
+//            for) and every lane learns the next ticket
+//   half 2   last four stages, stores; then, as the registers free up, the next item's coefficient loads and its twiddle
+//            entry are issued, to land across the hand-over
+// so that neither the ticket nor the dependency check is waited for — unless the next ticket's dependencies are not met
+// yet: then it is resolved at the top of its own iteration by polling (bounded), which is the only place a workgroup ever
+// waits for another.  Holding tickets ahead is safe: a workgroup runs its tickets in order and only ever blocks on the
+// one it is running.
 template <bool MIDRING>
 __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) {
-    using S = StridedCfg<8, 32>;
+    using S = StridedCfg<8, kCW>;
+    static_assert(S::TH == kTH && S::NR == 2 && S::R0 == 4, "S items: 16 columns x 256 rows on 256 threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
-    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + kTileBytes);
-    Tw *ltw0 = ltw + 256;                                                   // a C item's stage 8..11 twiddles [block][15]
-    u32 *ctrl = reinterpret_cast<u32 *>(smem_raw + kTileBytes + 256 * sizeof(Tw) + kTw0Bytes);
-    u64 *prof = reinterpret_cast<u64 *>(smem_raw + kTileBytes + 256 * sizeof(Tw) + kTw0Bytes + 64);
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + kTileBytes);                // the current item's twiddle tile
+    u32 *ctrl = reinterpret_cast<u32 *>(smem_raw + kTileBytes + 256 * sizeof(Tw));
+    u64 *prof = reinterpret_cast<u64 *>(smem_raw + kTileBytes + 256 * sizeof(Tw) + 64);
     const u32 tid0 = threadIdx.x;
     const u32 xq = xcc_id();
     const Mod &m = a.mod;
-    const u32 log_t = a.log_t, T = 1u << log_t, I = 8u << log_t;
+    const u32 log_t = a.log_t, T = 1u << log_t, I = 16u << log_t;
     const u32 maxord = a.maxord;
-    const u32 log_pb = log_t < 5u ? log_t : 5u, pbm = (1u << log_pb) - 1u, bpi = kUnits >> log_pb;   // C items: polynomials x blocks
+    const u32 log_pb = log_t < 4u ? log_t : 4u, pbm = (1u << log_pb) - 1u, bpi = kUnits >> log_pb;   // C items: polynomials x blocks
+    const bool wide = log_pb == 4u;
     u32 *const ctl = a.ctl;
     u32 *const head = ctl + persist_ctl_head(xq);
 
-    for (u32 li = tid0; li < 256u; li += kTH) ltw[li] = a.tw[li];   // the strided stages' twiddles, once per workgroup
     // optional profile (a.prof != nullptr): lane 0 accumulates shader-clock ticks per part of an iteration, by item kind
     const bool profiling = a.prof != nullptr;
     if (profiling && tid0 == 0) {
@@ -200,14 +209,34 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
     auto unit_blk = [&](const Desc &d, u32 uu) -> u32 { return (d.r >> (log_t - log_pb)) * bpi + (uu >> log_pb); };
     auto has_work = [&](const Desc &d) -> bool {               // false: a ticket whose polynomials lie past the batch
         const u64 tile0 = (u64)(d.bind - 1u) << log_t;
-        return d.phase == kPersistS ? tile0 + (d.r >> 3) < a.batch : tile0 + unit_poly(d, 0u) < a.batch;
+        return d.phase == kPersistS ? tile0 + (d.r >> 4) < a.batch : tile0 + unit_poly(d, 0u) < a.batch;
+    };
+    // which twiddle tile an item needs (two items with the same key share it)
+    auto tw_key = [&](const Desc &d) -> u32 { return d.phase == kPersistS ? 0u : 1u + (d.r >> (log_t - log_pb)); };
+    // this lane's entry of that tile
+    auto load_twe = [&](const Desc &d, u32 tid) -> Tw {
+        u32 idx;
+        if (d.phase == kPersistS) {
+            idx = tid;                                         // roots[1 .. 255]: stages 0..7 (entry 0 unused)
+        } else if (wide) {
+            // one block for all 16 units: local index li -> roots[(1 << (8 + ls)) + (blk << ls) + (li - 2^ls)], ls = floor(log2 li)
+            const u32 blk = unit_blk(d, 0u), l1 = tid | (tid == 0), ls = 31u - (u32)__builtin_clz(l1);
+            idx = (1u << (8u + ls)) + (blk << ls) + (l1 - (1u << ls));
+        } else {
+            // stages 8..11 only, [block of the item][2^i - 1 + g] = roots[((256 + blk) << i) + g]; lanes past the tile load its last entry
+            const u32 e = tid < bpi * 15u ? tid : bpi * 15u - 1u;
+            const u32 bl = e / 15u, j = e - bl * 15u;
+            const u32 i = 31u - (u32)__builtin_clz(j + 1u), g = j + 1u - (1u << i);
+            idx = ((256u + unit_blk(d, 0u) + bl) << i) + g;
+        }
+        return a.tw[idx];
     };
     // coefficient loads of a resolved ticket
     auto issue_loads = [&](const Desc &d, u32 tid, u64 (&x)[16]) {
         const u64 tile0 = (u64)(d.bind - 1u) << log_t;
         if (d.phase == kPersistS) {
-            const u32 pl = d.r >> 3, cg = d.r & 7u, c = tid % 32u, tf = tid / 32u;
-            const u64 *__restrict__ pin = a.in + ((tile0 + pl) << 16) + cg * 32u;
+            const u32 pl = d.r >> 4, cg = d.r & 15u, c = tid % kCW, tf = tid / kCW;
+            const u64 *__restrict__ pin = a.in + ((tile0 + pl) << 16) + cg * kCW;
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = ld_at<u64>(pin, ((field_of<S::A0>(tf, k) << 8) + c) * 8u);
         } else {
@@ -219,14 +248,6 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
             for (int k = 0; k < 16; k++) x[k] = ld_mid(src, field_of<4>(tf, k) * 8u);
         }
     };
-    // this lane's entry of a C item's stage 8..11 twiddle tile: roots[((256 + blk) << i) + g] for the item's blocks,
-    // [block][2^i - 1 + g]; lanes past the tile's 15 x blocks entries load its last one and store nothing
-    auto load_tw0 = [&](const Desc &d, u32 tid) -> Tw {
-        const u32 e = tid < bpi * 15u ? tid : bpi * 15u - 1u;
-        const u32 bl = e / 15u, j = e - bl * 15u;
-        const u32 i = 31u - (u32)__builtin_clz(j + 1u), g = j + 1u - (1u << i);
-        return a.tw[((256u + unit_blk(d, 0u) + bl) << i) + g];
-    };
 
     // lane 0: the tickets it holds beyond the current one, the control words in flight for the next one, and the
     // completion it still owes for the previous item
@@ -234,6 +255,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
     bool owes = false;                                            // uniform: the previous item was an S item with stores
     Desc cur{};
     u32 cur_res = 0, cur_loaded = 0;
+    u32 staged = 0xffffffffu;                                     // key of the twiddle tile in LDS
     if (tid0 == 0) {
         const u32 k0 = ctl_add(head, 1u);
         k_nxt = ctl_add(head, 1u);
@@ -259,13 +281,13 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
         u32 tid = tid0;
         asm volatile("" : "+v"(tid));
         tick(tid, cur.phase, 6u);                          // hand-over of the previous iteration (charged to the new item's kind)
-        __syncthreads();                                   // the LDS tile is free, the twiddle tile of a prefetched C item is in place
+        __syncthreads();                                   // the LDS tile is free, a prefetched item's twiddle tile is in place
         tick(tid, cur.phase, 0u);                          // wait at the top barrier
         PersistItem nit{};
         if (tid == 0) {
             k_nn = ctl_add(head, 1u);                      // the ticket after next: needed one iteration from now
             nit = persist_decode(k_nxt, log_t, a.lag);
-            pf_bind = 0; pf_dep = I;                       // control words of the next ticket: loads in flight until round 0 is done
+            pf_bind = 0; pf_dep = I;                       // control words of the next ticket: loads in flight until half 1 is done
             if (nit.ord < maxord) {
                 const u32 *bp = ctl + persist_ctl_bind(xq, nit.ord, maxord);
                 if (nit.phase == kPersistS && nit.r == 0) pf_bind = nit.ord ? ctl_load(bp - 1) : 1u;
@@ -322,31 +344,33 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
             return;
         }
         const bool work = valid && has_work(cur);
-        if (work && !cur_loaded) {
-            if (cur.phase == kPersistC) {
-                const Tw t0 = load_tw0(cur, tid);
-                issue_loads(cur, tid, v);
-                if (tid < bpi * 15u) ltw0[tid] = t0;
+        if (work && !cur_loaded) {                         // nothing could be issued ahead for this item
+            const u32 key = tw_key(cur);
+            const Tw te = load_twe(cur, tid);
+            issue_loads(cur, tid, v);
+            if (key != staged) {
+                __syncthreads();                           // (the tile may still be read: a previous S item's second half)
+                ltw[tid] = te;
+                staged = key;
                 __syncthreads();
-            } else {
-                issue_loads(cur, tid, v);
             }
         }
-
         tick(tid, cur.phase, 1u);                          // resolving by polling / loads that could not be issued ahead
         if (profiling && tid == 0 && work) prof[24 + cur.phase] += 1;
+
         // ---- first half: stages 0..3 of the pass in registers, scatter into the LDS tile ----
-        const u32 c = tid % 32u, tfs = tid / 32u;          // S item: column, row group
+        const u32 c = tid % kCW, tfs = tid / kCW;          // S item: column, row group
         const u32 u = tid >> 4, tfc = tid & 15u;           // C item: unit, lane of the unit
         if (work) {
             if (cur.phase == kPersistS) {
                 // (in a persistent loop the compiler cannot prove the global table unclobbered, so it would not use scalar
-                // loads for these workgroup-uniform twiddles: they come from the LDS copy, as broadcast reads)
+                // loads for these workgroup-uniform twiddles: they come from the LDS tile, as broadcast reads)
                 round_fwd_pm_f<S::R0, kPmOne, 4>(v, [&](int i, int g) { return ltw[(1 << i) + g]; }, m);
 #pragma unroll
-                for (int k = 0; k < 16; k++) lds[field_of<S::A0>(tfs, k) * 32u + c] = v[k];
+                for (int k = 0; k < 16; k++) lds[field_of<S::A0>(tfs, k) * kSRow + c] = v[k];
             } else {
-                const Tw *tw0 = ltw0 + (u >> log_pb) * 15u;
+                // stages 8..11: the same twiddles for the 16 lanes of a unit (wide: for the whole workgroup)
+                const Tw *tw0 = wide ? ltw + 1 : ltw + (u >> log_pb) * 15u;
                 round_fwd_pm_f<4, kPmPassBound, 4>(v, [&](int i, int g) { return tw0[(1 << i) - 1 + g]; }, m);
 #pragma unroll
                 for (int k = 0; k < 16; k++) lds[pad16(u * 256u + field_of<4>(tfc, k))] = v[k];
@@ -368,26 +392,27 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
         u32 nxt_res, nst;
         rd_desc(kCtlWords, nxt, nxt_res, nst);
         // The next item's coefficient loads are issued as soon as this item's registers are free (after its stores / its
-        // last scatter) and land across the hand-over.  (Issuing them here, into a second set of 32 registers, so that
-        // they land while the second half computes, does not fit 128 registers: the compiler spills the whole set.)
+        // last scatter) and land across the hand-over.  (Issued here, into a second set of 32 registers, they would land
+        // while the second half computes — but that does not fit 128 registers: the compiler spills the whole set.)
         const bool pre = nxt_res && nxt.bind != kPersistInvalid && has_work(nxt);
-        const bool pre_c = pre && nxt.phase == kPersistC;
-        Tw t0n = ltw[0];                                   // (placeholder; the next C item's twiddle entry when pre_c)
-        if (pre_c) t0n = load_tw0(nxt, tid);               // issued first: it is waited for first (hand-over)
+        const u32 nkey = pre ? tw_key(nxt) : staged;
+        const bool restage = nkey != staged;
+        Tw ten = ltw[0];                                   // (placeholder; the next item's twiddle entry when restage)
+        if (restage) ten = load_twe(nxt, tid);             // issued first: it is waited for first (hand-over)
 
         // ---- second half: gather, stages 4..7 of the pass, stores ----
         if (work) {
             const u64 tile0 = (u64)(cur.bind - 1u) << log_t;
             if (cur.phase == kPersistS) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = lds[field_of<S::a_of(1)>(tfs, k) * 32u + c];
-                constexpr int P1 = pm_fwd_bound_out(S::R0, kPmOne);
+                for (int k = 0; k < 16; k++) v[k] = lds[field_of<S::a_of(1)>(tfs, k) * kSRow + c];
                 tick(tid, 0u, 7u);                         // S: descriptor read + gather
                 const u32 T1 = (1u << S::ls0_of(1)) + (tfs >> S::a_of(1));
+                constexpr int P1 = pm_fwd_bound_out(S::R0, kPmOne);
                 round_fwd_pm_f<4, P1, 4>(v, [&](int i, int g) { return ltw[(T1 << i) + g]; }, m);
                 tick(tid, 0u, 8u);                         // S: stages 4..7
-                const u32 pl = cur.r >> 3, cg = cur.r & 7u;
-                u64 *__restrict__ pout = (MIDRING ? ring_slot(cur.ord) + ((u64)pl << 16) : a.out + ((tile0 + pl) << 16)) + cg * 32u;
+                const u32 pl = cur.r >> 4, cg = cur.r & 15u;
+                u64 *__restrict__ pout = (MIDRING ? ring_slot(cur.ord) + ((u64)pl << 16) : a.out + ((tile0 + pl) << 16)) + cg * kCW;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const u32 off = ((field_of<S::a_of(1)>(tfs, k) << 8) + c) * 8u;
@@ -403,11 +428,17 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
 #pragma unroll
                 for (int k = 0; k < 16; k++) v[k] = lds[pad16(u * 256u + field_of<0>(tfc, k))];
                 tick(tid, 1u, 7u);                         // C: descriptor read + gather
-                // stages 12..15: roots[((4096 + 16 blk + tf) << i) + g], laid out [blk][2^i - 1 + g][tf] (twc)
-                // (global loads, not fenced: the compiler issues all 15 up front and their L2 latency is paid once)
-                const Tw *__restrict__ tc = a.twc + (size_t)blk * 240u + tfc;
                 constexpr int B1 = pm_fwd_bound_out(4, kPmPassBound);
-                round_fwd_pm_f<4, B1, 0>(v, [&](int i, int g) { return tc[((1 << i) - 1 + g) * 16]; }, m);
+                if (wide) {
+                    // stages 12..15 from the block's tile: local index ((16 + tf) << i) + g
+                    const u32 T1 = 16u + tfc;
+                    round_fwd_pm_f<4, B1, 4>(v, [&](int i, int g) { return ltw[(T1 << i) + g]; }, m);
+                } else {
+                    // stages 12..15: roots[((4096 + 16 blk + tf) << i) + g], laid out [blk][2^i - 1 + g][tf] (twc): global
+                    // loads, not fenced — the compiler issues all 15 up front and their latency is paid once
+                    const Tw *__restrict__ tc = a.twc + (size_t)blk * 240u + tfc;
+                    round_fwd_pm_f<4, B1, 0>(v, [&](int i, int g) { return tc[((1 << i) - 1 + g) * 16]; }, m);
+                }
                 tick(tid, 1u, 8u);                         // C: stages 12..15
                 // a thread rewrites exactly the slots it has just gathered: no barrier before the scatter
 #pragma unroll
@@ -430,14 +461,19 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
             }
         }
         tick(tid, cur.phase, 5u);                          // second half
-        // an S ticket owes its completion even when its polynomial lies past the batch (its consumers count to 8T)
+        // an S ticket owes its completion even when its polynomial lies past the batch (its consumers count to 16T)
         if (valid && cur.phase == kPersistS) {
             owes = true;
             if (tid == 0) owed = 1u + (u32)persist_ctl_sdone(xq, cur.ord, maxord);
         }
-        // ---- hand over ----
+        // ---- hand-over ----
         if (pre && !work) issue_loads(nxt, tid, v);        // (an item without work did not reach the places above)
-        if (pre_c && tid < bpi * 15u) ltw0[tid] = t0n;     // read after the barrier at the top
+        if (restage) {
+            // the tile is read in second halves: behind a C item's store barrier everybody is past that; an S item has none
+            if (!(work && cur.phase == kPersistC)) __syncthreads();
+            ltw[tid] = ten;                                // read after the barrier at the top
+            staged = nkey;
+        }
         cur = nxt;
         cur_res = nxt_res;
         cur_loaded = pre ? 1u : 0u;
@@ -498,7 +534,7 @@ hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const 
     return hipGetLastError();
 }
 
-// workgroups the chip holds at once: 2 per CU (LDS: 2 x 74 KiB of 160)
+// workgroups the chip holds at once: 4 per CU (LDS: 4 x 38.3 KiB of 160)
 hipError_t persist_grid(unsigned *grid) {
     int dev = 0, cus = 0, per = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -6,12 +6,12 @@
 // as two launches: the intermediate makes a round trip through HBM.  Here ONE launch runs both: persistent workgroups
 // draw TICKETS from a queue — one queue per XCD, chosen by the hardware XCC id, so that everything a queue exchanges
 // stays behind ONE L2 — and a ticket names a work item:
-//     S(j, r)   strided stages of 32 columns of one polynomial of tile j        (r in [0, 8T): polynomial r / 8, columns r % 8)
-//     C(j, r)   contiguous stages of 32 rows ("units" of 256 coefficients) of tile j
+//     S(j, r)   strided stages of 16 columns of one polynomial of tile j        (r in [0, 16T): polynomial r / 16, columns r % 16)
+//     C(j, r)   contiguous stages of 16 rows ("units" of 256 coefficients) of tile j
 // A TILE is T = 2^log_t polynomials; tile ordinals j = 0, 1, ... are per queue and are BOUND to global tiles on first
 // touch (the ticket S(j, 0) takes the next global tile, once ordinal j - 1 has been bound: the bound ordinals of a queue
 // are a prefix), so queues that run faster simply take more tiles.
-// Order of the chunks of I = 8T tickets in a queue, for a lag L:   S(0) .. S(L),  C(0), S(L+1), C(1), S(L+2), ...
+// Order of the chunks of I = 16T tickets in a queue, for a lag L:   S(0) .. S(L),  C(0), S(L+1), C(1), S(L+2), ...
 // Dependencies, all on EARLIER tickets of the same queue (so the holder of the smallest unfinished ticket can always
 // finish: no co-residency is assumed, and no workgroup ever waits for a later ticket):
 //     every ticket of ordinal j   waits for  bind[j]        (written by the holder of S(j, 0) before it does anything else)
@@ -37,12 +37,12 @@ constexpr uint32_t kPersistLineWords = 32;      // control words that are hammer
 struct PersistItem {
     uint32_t phase;   // kPersistS / kPersistC
     uint32_t ord;     // tile ordinal within the queue
-    uint32_t r;       // item within the tile, [0, 8T)
+    uint32_t r;       // item within the tile, [0, 16T)
 };
 
 // ticket k of a queue -> work item
 FHE_HD inline PersistItem persist_decode(uint64_t k, uint32_t log_t, uint32_t lag) {
-    const uint32_t log_i = log_t + 3;                       // I = 8T tickets per chunk
+    const uint32_t log_i = log_t + 4;                       // I = 16T tickets per chunk
     const uint64_t chunk = k >> log_i;
     PersistItem it;
     it.r = (uint32_t)(k & ((1ull << log_i) - 1ull));

@@ -9,7 +9,7 @@ import fhe_study_amd as pkg
 
 B = pkg.binding
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]] or [(1, 1, 4), (2, 1, 2), (16, 1, 0), (64, 1, 0)]
+cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]] or [(1, 4, 6), (4, 2, 4), (16, 1, 0), (64, 1, 0)]
 q, n = pkg.Q61, 1 << 16
 plan = pkg.Plan(q, n)
 st = torch.cuda.current_stream().cuda_stream

@@ -43,7 +43,7 @@ EXPORTS = [
     "fhe_rq_pointwise_mul", "fhe_rq_check_canonical",
     "fhe_ntt_forward_dev", "fhe_ntt_inverse_dev", "fhe_rq_mul_dev",
     "fhe_rq_mul_workspace_bytes", "fhe_rq_pointwise_mul_dev", "fhe_fill_synthetic_dev",
-    "fhe_ntt_set_batch_tile", "fhe_ntt_set_persist", "fhe_ntt_persist_status", "fhe_ntt_persist_profile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
+    "fhe_ntt_set_batch_tile", "fhe_ntt_set_persist", "fhe_ntt_persist_status", "fhe_ntt_persist_profile", "fhe_ntt_set_persist_grid", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
     "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace", "fhe_ntt_workspace_bytes",
@@ -175,9 +175,10 @@ def load_library():
     L.fhe_rq_pointwise_mul_dev.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
     L.fhe_fill_synthetic_dev.argtypes = [_u64, _u64, _u64, _sz, _vp, _vp]
     L.fhe_ntt_set_batch_tile.argtypes = [_sz]
-    L.fhe_ntt_set_persist.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    L.fhe_ntt_set_persist.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
     L.fhe_ntt_persist_status.argtypes = []
     L.fhe_ntt_persist_profile.argtypes = [_vp]
+    L.fhe_ntt_set_persist_grid.argtypes = [_int]
     L.fhe_ntt_kernel_timing_enable.argtypes = [_int]
     L.fhe_ntt_kernel_timing_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), _p64, _int]
     L.fhe_ntt_kernel_timing_reset.argtypes = []
@@ -458,9 +459,16 @@ def set_batch_tile(polys):
     _check(load_library().fhe_ntt_set_batch_tile(int(polys)))
 
 
-def set_persist(tile_polys, lag=1, ringslots=4):
-    """The one-launch n = 2^16 forward transform (csrc/ntt_persist.hip); tile_polys = 0: the two-pass kernels."""
-    _check(load_library().fhe_ntt_set_persist(int(tile_polys), int(lag), int(ringslots)))
+def set_persist(mode, tile_polys=1, lag=1, ringslots=4):
+    """The one-launch n = 2^16 forward transform (csrc/ntt_persist.hip): mode 0 off (two-pass kernels), "A" / 1 lagged
+    tiles (tile_polys, lag, ringslots; ringslots 0 = through the output buffer), "B" / 2 teams (ringslots)."""
+    mode = {"A": 1, "B": 2, "a": 1, "b": 2}.get(mode, mode)
+    _check(load_library().fhe_ntt_set_persist(int(mode), int(tile_polys), int(lag), int(ringslots)))
+
+
+def set_persist_grid(workgroups):
+    """Workgroups of a persistent launch (0: as many as the chip holds)."""
+    _check(load_library().fhe_ntt_set_persist_grid(int(workgroups)))
 
 
 def persist_status():

@@ -437,21 +437,29 @@ extern "C" int fhe_ntt_set_batch_tile(size_t polys) {
 }
 
 // ---- the one-launch forward transform (ntt_persist.hip) ---------------------------------------------------------
-// FHE_NTT_PERSIST=T[,L[,R]] (or fhe_ntt_set_persist): n = 2^16 transforms on a pseudo-Mersenne modulus run as ONE launch of
-// persistent workgroups — tiles of T polynomials, the strided stages running L tiles ahead of the contiguous ones, the
-// intermediate in a ring of R tile slots per XCD (R = 0: in the output buffer).  Unset / T = 0: the two-pass kernels.
+// FHE_NTT_PERSIST (or fhe_ntt_set_persist): n = 2^16 transforms on a pseudo-Mersenne modulus run as ONE launch of
+// persistent workgroups.  "A:T,L,R" — tiles of T polynomials, the strided stages running L tiles ahead of the contiguous
+// ones, the intermediate in a ring of R tile slots per XCD (R = 0: in the output buffer).  "B:R" — teams: sixteen
+// workgroups of one XCD take one polynomial through both halves, the intermediate in a ring of R polynomial slots per
+// XCD, read back out of the L2.  Unset: the two-pass kernels.
 static bool g_persist_set = false;
 static fhe::PersistTune g_persist{};
 static bool g_persist_on = false;
+static int g_persist_grid = -1;                      // > 0: workgroups to launch instead of what the chip holds; -1: not read yet
 static uint32_t *g_persist_host_err = nullptr;      // pinned, device-visible: a bounded wait that ran out lands here
 static bool persist_tune(fhe::PersistTune *t) {
     std::lock_guard<std::mutex> lk(g_cfg_lock);
     if (!g_persist_set) {
         g_persist_set = true;
-        const char *e = getenv("FHE_NTT_PERSIST");
+        const char *e = getenv("FHE_NTT_PERSIST");       // "A:T,L,R" (tiles, lagged) or "B:R" (teams)
         unsigned T = 0, L = 1, R = 4;
-        if (e && sscanf(e, "%u,%u,%u", &T, &L, &R) >= 1 && T > 0 && (T & (T - 1)) == 0 && T <= 1024 && (R == 0 || R >= L + 1)) {
-            g_persist.log_t = 0;
+        if (e && (e[0] == 'B' || e[0] == 'b') && e[1] == ':' && sscanf(e + 2, "%u", &R) == 1 && R >= 1) {
+            g_persist = fhe::PersistTune{};
+            g_persist.log_t = 0; g_persist.lag = 0; g_persist.ringslots = R; g_persist.teams = true;
+            g_persist_on = true;
+        } else if (e && (e[0] == 'A' || e[0] == 'a') && e[1] == ':' && sscanf(e + 2, "%u,%u,%u", &T, &L, &R) >= 1 && T > 0 &&
+                   (T & (T - 1)) == 0 && T <= 1024 && (R == 0 || R >= L + 1)) {
+            g_persist = fhe::PersistTune{};
             while ((1u << g_persist.log_t) < T) g_persist.log_t++;
             g_persist.lag = L; g_persist.ringslots = R;
             g_persist_on = true;
@@ -460,17 +468,23 @@ static bool persist_tune(fhe::PersistTune *t) {
     *t = g_persist;
     return g_persist_on;
 }
-extern "C" int fhe_ntt_set_persist(unsigned tile_polys, unsigned lag, unsigned ringslots) {
-    if (tile_polys && ((tile_polys & (tile_polys - 1)) != 0 || tile_polys > 1024))
-        return fail(FHE_E_INVALID, "fhe_ntt_set_persist: tile of %u polynomials (need a power of two <= 1024, or 0)", tile_polys);
-    if (tile_polys && ringslots && ringslots < lag + 1)
+extern "C" int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned lag, unsigned ringslots) {
+    if (mode > 2) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: mode %u (0 off, 1 = A: lagged tiles, 2 = B: teams)", mode);
+    if (mode == 1 && (tile_polys == 0 || (tile_polys & (tile_polys - 1)) != 0 || tile_polys > 1024))
+        return fail(FHE_E_INVALID, "fhe_ntt_set_persist: tile of %u polynomials (need a power of two <= 1024)", tile_polys);
+    if (mode == 1 && ringslots && ringslots < lag + 1)
         return fail(FHE_E_INVALID, "fhe_ntt_set_persist: a ring of %u slots cannot hold a lag of %u tiles (need >= lag + 1)", ringslots, lag);
+    if (mode == 2 && ringslots == 0) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: teams need a ring (ringslots >= 1)");
     std::lock_guard<std::mutex> lk(g_cfg_lock);
     g_persist_set = true;
-    g_persist_on = tile_polys != 0;
-    g_persist.log_t = 0;
-    while (tile_polys && (1u << g_persist.log_t) < tile_polys) g_persist.log_t++;
-    g_persist.lag = lag; g_persist.ringslots = ringslots;
+    g_persist_on = mode != 0;
+    g_persist = fhe::PersistTune{};
+    if (mode == 1) {
+        while ((1u << g_persist.log_t) < tile_polys) g_persist.log_t++;
+        g_persist.lag = lag; g_persist.ringslots = ringslots;
+    } else if (mode == 2) {
+        g_persist.log_t = 0; g_persist.lag = 0; g_persist.ringslots = ringslots; g_persist.teams = true;
+    }
     return FHE_OK;
 }
 // Diagnostic: with a device buffer of 26 u64 words registered here, lane 0 of every persistent workgroup adds the shader-
@@ -479,6 +493,11 @@ static void *g_persist_prof = nullptr;
 extern "C" int fhe_ntt_persist_profile(void *d_words26) {
     std::lock_guard<std::mutex> lk(g_cfg_lock);
     g_persist_prof = d_words26;
+    return FHE_OK;
+}
+extern "C" int fhe_ntt_set_persist_grid(int workgroups) {
+    std::lock_guard<std::mutex> lk(g_cfg_lock);
+    g_persist_grid = workgroups > 0 ? workgroups : 0;
     return FHE_OK;
 }
 static int persist_host_err(uint32_t **dptr) {
@@ -502,25 +521,28 @@ extern "C" int fhe_ntt_persist_status(void) {
         std::lock_guard<std::mutex> lk(g_cfg_lock);
         if (g_persist_host_err) { v = *(volatile uint32_t *)g_persist_host_err; *(volatile uint32_t *)g_persist_host_err = 0; }
     }
-    if (v) return fail(FHE_E_HIP, "persistent transform: a bounded wait ran out (bits 0x%x: 1 bind, 2 strided-done, 4 ring slot)", v);
+    if (v) return fail(FHE_E_HIP, "persistent transform: a bounded wait ran out (bits 0x%x: 1 bind, 2 strided-done, 4 ring slot; 8: an XCD's queue was never served)", v);
     return FHE_OK;
 }
 // the lane-ordered table of the last four stages, built once per (plan, device)
-static int persist_tables(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const fhe::Tw **twc, hipStream_t st) {
+static int persist_tables(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const fhe::Tw **twc, const u64 **twc8, hipStream_t st) {
     int dev = 0;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
     std::lock_guard<std::mutex> lk(plan->dev_lock);
     DeviceTables &t = plan->dev[dev];
     if (!t.twc_pm) {
+        const size_t n = fhe::persist_twc_entries(plan->log_n);
         fhe::Tw *d = nullptr;
-        HIP_TRY(hipMalloc((void **)&d, fhe::persist_twc_entries(plan->log_n) * sizeof(fhe::Tw)));
-        hipError_t e = fhe::launch_persist_twc(dp.tw_fwd_pm, d, plan->log_n, st);
+        HIP_TRY(hipMalloc((void **)&d, n * (sizeof(fhe::Tw) + sizeof(u64))));      // [Tw x n][u64 x n]
+        u64 *d8 = (u64 *)(d + n);
+        hipError_t e = fhe::launch_persist_twc(dp.tw_fwd_pm, d, d8, plan->log_n, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "persist_twc_kernel"); }
         t.twc_pm = d;
     }
     *twc = t.twc_pm;
+    *twc8 = (const u64 *)(t.twc_pm + fhe::persist_twc_entries(plan->log_n));
     return FHE_OK;
 }
 static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const fhe::PersistTune &tune, const void *d_in,
@@ -528,23 +550,28 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
     if (g_persist_host_err && *(volatile uint32_t *)g_persist_host_err)
         return fail(FHE_E_HIP, "an earlier persistent transform failed (fhe_ntt_persist_status())");
     const fhe::Tw *twc = nullptr;
-    int rc = persist_tables(plan, dp, &twc, st);
+    const u64 *twc8 = nullptr;
+    int rc = persist_tables(plan, dp, &twc, &twc8, st);
     if (rc != FHE_OK) return rc;
     uint32_t *herr = nullptr;
     if ((rc = persist_host_err(&herr)) != FHE_OK) return rc;
     const size_t cb = (fhe::persist_ctl_bytes(tune, batch) + 255) & ~(size_t)255, rb = fhe::persist_ring_bytes(tune);
     void *w = nullptr;
     if ((rc = fhe_workspace_get(4, cb + rb, st, &w)) != FHE_OK) return rc;
-    static unsigned grid = 0;
+    static unsigned grids[2] = {0, 0};
+    unsigned &grid = grids[tune.teams ? 1 : 0];
     if (!grid) {
         unsigned g = 0;
-        HIP_TRY(fhe::persist_grid(&g));
-        const char *e = getenv("FHE_NTT_PERSIST_GRID");
-        if (e && atoi(e) > 0) g = (unsigned)atoi(e);
+        HIP_TRY(fhe::persist_grid(tune.teams, &g));
         grid = g;
     }
-    hipError_t e = fhe::launch_ntt_forward_persist(dp, twc, (const u64 *)d_in, (u64 *)d_out, batch, tune, (uint32_t *)w,
-                                                   rb ? (u64 *)((char *)w + cb) : nullptr, herr, (u64 *)g_persist_prof, grid, st);
+    {   // FHE_NTT_PERSIST_GRID / fhe_ntt_set_persist_grid: another number of workgroups (tests: fewer than the chip holds)
+        std::lock_guard<std::mutex> lk(g_cfg_lock);
+        if (g_persist_grid < 0) { const char *e = getenv("FHE_NTT_PERSIST_GRID"); g_persist_grid = e ? atoi(e) : 0; }
+    }
+    const unsigned use_grid = g_persist_grid > 0 ? (unsigned)g_persist_grid : grid;
+    hipError_t e = fhe::launch_ntt_forward_persist(dp, twc, twc8, (const u64 *)d_in, (u64 *)d_out, batch, tune, (uint32_t *)w,
+                                                   rb ? (u64 *)((char *)w + cb) : nullptr, herr, (u64 *)g_persist_prof, use_grid, st);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward_persist");
     return FHE_OK;
 }

@@ -481,6 +481,312 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_persist_kernel(PersistArgs a) 
     }
 }
 
+// =====================================================================================================================
+// TEAMS (variant B): the unit of exchange is ONE polynomial and the exchange stays inside the L2.
+//
+// A ticket of a queue is (j, r): part r of 16 of the queue's j-th polynomial — polynomial 8 j + x of the batch for queue
+// x: the queues share the batch out statically, so nothing is bound and nobody waits for a binding.  Its holder runs the
+// strided stages of 16 columns of that polynomial, S(j, r), stores them into slot j mod R of the XCD's ring, adds to
+// sdone[j] — and then WAITS for sdone[j] == 16: the other fifteen parts were drawn in the same breath by workgroups of
+// the same XCD that are running them right now, so the wait is the skew between sixteen workgroups that started within
+// microseconds of each other.  Then it runs the contiguous stages of 16 rows of the SAME polynomial, C(j, r), reading the
+// ring slot a few microseconds after it was written — from the L2 — and writes the result.  The slot's lines die in the
+// cache (or are written back once, unread, when the cache needs room): the transform reads 8 bytes and writes 8 to 16
+// bytes per coefficient of HBM instead of 16 + 16.  While a workgroup waits for its team, the three other workgroups of
+// its CU — members of other teams, in other phases — have the CU.
+//
+// No co-residency is assumed.  A workgroup holds NO undone ticket while it waits (the next one is drawn after the team has
+// met), and a wait that lasts (kHelpPolls) turns into work: the waiter draws the next ticket itself — if that is another
+// part of its own team (it was never drawn: the queue has fewer than sixteen workgroups at the moment) it runs that S
+// part too, and later the C part of every part it owns; if it is a later ticket, every part of the team HAS a holder that
+// is running it, and the waiter keeps the ticket for later and goes on waiting.  So a queue served by a single workgroup
+// still finishes (sixteen S parts, then sixteen C parts, per polynomial), and every wait is bounded on top of that.
+// A queue served by NO workgroup leaves its eighth of the batch untouched: the last workgroup out checks that every
+// queue's tickets were all drawn and raises the error word otherwise.
+// =====================================================================================================================
+constexpr u32 kHelpPolls = 1024;                // polls of the team counter before a waiter starts drawing tickets itself
+enum : u32 { kTeamDone = 0, kTeamHelp = 1, kTeamFail = 2 };
+
+// Twiddles: ONE 256-entry tile in LDS that holds the strided stages' roots[1..255] while an S part runs and the 240
+// entries of stages 8..11 of the part's rows while a C part runs (re-staged at the two hand-overs, one entry per lane);
+// stages 12..15 of a C part are 15 words per lane of the lane-ordered table twc8 — only w, 8 bytes: the second table word
+// w 2^32 mod q is recomputed (pm_shift32, three instructions) — fetched into 30 registers when the S part has stored, so
+// that they arrive while the team meets.  Four workgroups per CU.
+__global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
+    using S = StridedCfg<8, kCW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + kTileBytes);               // the twiddle tile (see above)
+    u32 *ctrl = reinterpret_cast<u32 *>(smem_raw + kTileBytes + 256 * sizeof(Tw));
+    u64 *prof = reinterpret_cast<u64 *>(smem_raw + kTileBytes + 256 * sizeof(Tw) + 64);
+    const u32 tid0 = threadIdx.x;
+    const u32 xq = xcc_id();
+    const Mod &m = a.mod;
+    const u32 maxord = a.maxord, R = a.ringslots;
+    constexpr u32 kParts = 16u;
+    u32 *const ctl = a.ctl;
+    u32 *const head = ctl + persist_ctl_head(xq);
+
+    const bool profiling = a.prof != nullptr;
+    if (profiling && tid0 == 0) {
+        for (u32 i = 0; i < kProfWords; i++) prof[i] = 0;
+        prof[kProfWords - 1] = (u64)clock64();
+    }
+    auto tick = [&](u32 tid, u32 phase, u32 part) {
+        if (profiling && tid == 0) {
+            const u64 now = (u64)clock64();
+            prof[phase * 12u + part] += now - prof[kProfWords - 1];
+            prof[kProfWords - 1] = now;
+        }
+    };
+    auto fail = [&](u32 status) {
+        atomicOr(ctl + persist_ctl_err(), status);
+        __hip_atomic_fetch_or(a.host_err, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    auto poly_of = [&](u32 ord) -> u64 { return (u64)ord * kPersistQueues + xq; };
+    auto slot_of = [&](u32 ord) -> u64 * { return a.ring + (((u64)xq * R + ord % R) << 16); };
+    auto issue_s_loads = [&](u32 ord, u32 r, u32 tid, u64 (&x)[16]) {
+        const u32 c = tid % kCW, tf = tid / kCW;
+        const u64 *__restrict__ pin = a.in + (poly_of(ord) << 16) + r * kCW;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = ld_at<u64>(pin, ((field_of<S::A0>(tf, k) << 8) + c) * 8u);
+    };
+    // this lane's entry of the C part's twiddle tile: roots[((256 + 16 r + row) << i) + g] at [row][2^i - 1 + g]
+    auto load_te_c = [&](u32 r, u32 tid) -> Tw {
+        const u32 e = tid < 240u ? tid : 239u;
+        const u32 bl = e / 15u, j = e - bl * 15u;
+        const u32 i = 31u - (u32)__builtin_clz(j + 1u), g = j + 1u - (1u << i);
+        return a.tw[((256u + r * kUnits + bl) << i) + g];
+    };
+
+    ltw[tid0] = a.tw[tid0];
+    u32 cur_ord = 0, cur_r = 0, cur_loaded = 0;
+    u32 pf_dep = 0;                             // lane 0: cdone of the current ticket's ring slot's previous tenant, as loaded ahead
+    if (tid0 == 0) {
+        const u32 k0 = ctl_add(head, 1u);
+        ctrl[kCtlOrd] = k0 >> 4; ctrl[kCtlR] = k0 & 15u;
+    }
+    __syncthreads();
+    cur_ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlOrd]);
+    cur_r = __builtin_amdgcn_readfirstlane(ctrl[kCtlR]);
+
+    u64 v[16];
+    u32 own = 0;                                           // parts of the current polynomial this workgroup has run the S part of
+    u32 held = 0, have_held = 0, k_h = 0;                  // the ticket drawn for afterwards (k_h: lane 0, in flight)
+    u32 guard_ahead = 1;                                   // lane 0's pf_dep belongs to the current ticket
+    u32 nxt_ord = 0, nxt_r = 0;
+    bool pre = false;
+
+    // C(team, r): stages 8..15 of rows [16 r, 16 r + 16), twiddles of the last four stages in tcx; `last`: the workgroup's last
+    // part of this polynomial — the ticket for afterwards is published and its coefficient loads are issued on the way
+    auto c_part = [&](u32 tid, u32 team, u32 r, const u64 (&tcx)[15], bool last) __attribute__((always_inline)) {
+        u64 *const slot = slot_of(team);
+        const u32 u = tid >> 4, tfc = tid & 15u;
+        const u32 blk = r * kUnits + u;                    // the unit's row of the 256 x 256 view
+        tick(tid, 1u, 0u);
+        {
+            const u64 *__restrict__ src = slot + blk * 256u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = ld_mid(src, field_of<4>(tfc, k) * 8u);
+        }
+        if (profiling && tid == 0) prof[25] += 1;
+        {
+            const Tw *tw0 = ltw + u * 15u;
+            round_fwd_pm_f<4, kPmPassBound, 4>(v, [&](int i, int g) { return tw0[(1 << i) - 1 + g]; }, m);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[pad16(u * 256u + field_of<4>(tfc, k))] = v[k];
+        tick(tid, 1u, 2u);
+        if (last && tid == 0) {                            // the ticket for afterwards, and its ring slot's state
+            const u32 t = have_held ? held : k_h;
+            const u32 nord = t >> 4;
+            pf_dep = kParts;
+            if (poly_of(nord) < a.batch && nord >= R) pf_dep = ctl_load(ctl + persist_ctl_cdone(xq, nord - R, maxord));
+            ctrl[kCtlWords + kCtlOrd] = nord; ctrl[kCtlWords + kCtlR] = t & 15u;
+        }
+        tick(tid, 1u, 3u);
+        __syncthreads();
+        tick(tid, 1u, 4u);
+        if (tid == 0) ctl_add(ctl + persist_ctl_cdone(xq, team, maxord), 1u);   // this part has read the slot
+        if (last) {
+            nxt_ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlWords + kCtlOrd]);
+            nxt_r = __builtin_amdgcn_readfirstlane(ctrl[kCtlWords + kCtlR]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[pad16(u * 256u + field_of<0>(tfc, k))];
+        tick(tid, 1u, 7u);
+        {
+            constexpr int B1 = pm_fwd_bound_out(4, kPmPassBound);
+            round_fwd_pm_f<4, B1, 0>(v, [&](int i, int g) { const u64 w = tcx[(1 << i) - 1 + g]; return Tw{w, pm_shift32(w, m)}; }, m);
+        }
+        tick(tid, 1u, 8u);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            lds[pad16(u * 256u + field_of<0>(tfc, k))] = pm_canon(v[k], m);
+            if ((k & 3) == 3) FHE_SCHED_FENCE();
+        }
+        tick(tid, 1u, 9u);
+        if (last) {
+            pre = poly_of(nxt_ord) < a.batch;
+            if (pre) issue_s_loads(nxt_ord, nxt_r, tid, v);        // the next item's coefficients: land across the hand-over
+        }
+        tick(tid, 1u, 10u);
+        __syncthreads();
+        tick(tid, 1u, 11u);
+        if (last) ltw[tid] = a.tw[tid];                    // the strided stages' tile again (read after the barrier at the top)
+        {
+            u64 *__restrict__ pout = a.out + (poly_of(team) << 16) + (u64)r * kUnits * 256u;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const u32 e = i * kTH + tid;
+                st_at(pout, e * 8u, lds[pad16(e)]);        // rows 16 r .. 16 r + 15 are contiguous: 32 KiB
+                if ((i & 3) == 3) FHE_SCHED_FENCE();
+            }
+        }
+        tick(tid, 1u, 5u);
+    };
+
+    for (;;) {                                             // one S part; then, once the team has met, this workgroup's C part(s)
+        u32 tid = tid0;
+        asm volatile("" : "+v"(tid));
+        tick(tid, 0u, 6u);
+        __syncthreads();                                   // the LDS tile is free
+        tick(tid, 0u, 0u);
+        if (poly_of(cur_ord) >= a.batch) {                 // past the last polynomial: so is every later ticket of this queue
+            if (profiling && tid == 0)
+                for (u32 i = 0; i < kProfWords - 1; i++) atomicAdd((unsigned long long *)a.prof + i, (unsigned long long)prof[i]);
+            if (tid == 0 && ctl_add(ctl + persist_ctl_gtile(), 1u) + 1u == gridDim.x) {
+                // the last workgroup out: were all tickets of all eight queues drawn?  (a queue nobody served leaves its
+                // polynomials untouched: that must be an error, never a silent hole in the output)
+                u32 bad = 0;
+                for (u32 q = 0; q < kPersistQueues; q++) {
+                    const u64 polys = a.batch > q ? (a.batch - q + kPersistQueues - 1u) / kPersistQueues : 0u;
+                    if ((u64)ctl_load(ctl + persist_ctl_head(q)) < polys * kParts) bad = 1;
+                }
+                if (bad) fail(kPersistErrQueue);
+            }
+            return;
+        }
+        const u32 team = cur_ord;
+        // ================= S(team, cur_r) =================
+        {
+            const u32 c = tid % kCW, tfs = tid / kCW;
+            if (!cur_loaded) issue_s_loads(team, cur_r, tid, v);
+            tick(tid, 0u, 1u);
+            if (profiling && tid == 0) prof[24] += 1;
+            round_fwd_pm_f<S::R0, kPmOne, 4>(v, [&](int i, int g) { return ltw[(1 << i) + g]; }, m);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[field_of<S::A0>(tfs, k) * kSRow + c] = v[k];
+            tick(tid, 0u, 2u);
+            if (tid == 0) {                                // the ring slot's previous tenant must have been read (normally: long ago)
+                u32 status = 0u, got;
+                if (team >= R && !(guard_ahead && pf_dep >= kParts) &&
+                    !wait_ge(ctl + persist_ctl_cdone(xq, team - R, maxord), kParts, &got)) { status = kPersistErrCdone; fail(status); }
+                ctrl[kCtlStatus] = status;
+            }
+            __syncthreads();
+            tick(tid, 0u, 4u);
+            if (__builtin_amdgcn_readfirstlane(ctrl[kCtlStatus])) return;
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[field_of<S::a_of(1)>(tfs, k) * kSRow + c];
+            {
+                constexpr int P1 = pm_fwd_bound_out(S::R0, kPmOne);
+                const u32 T1 = 16u + tfs;
+                round_fwd_pm_f<4, P1, 4>(v, [&](int i, int g) { return ltw[(T1 << i) + g]; }, m);
+            }
+            tick(tid, 0u, 8u);
+            u64 *__restrict__ pout = slot_of(team) + cur_r * kCW;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                st_c<u64>(pout, ((field_of<S::a_of(1)>(tfs, k) << 8) + c) * 8u, v[k]);     // plain: stays in this XCD's L2
+                if ((k & 3) == 3) FHE_SCHED_FENCE();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been acknowledged by the L2
+            tick(tid, 0u, 9u);
+        }
+        __syncthreads();                                   // ... every wave's
+        own |= 1u << cur_r;
+        const bool single = own == (1u << cur_r);
+        // the C part's twiddles start their way now: this lane's entry of the stage 8..11 tile, and stages 12..15 into registers
+        // (only for a workgroup's first part of a polynomial — the normal case; a helper fetches them per part, below)
+        u64 tc[15];
+        if (single) {
+            const Tw te_c = load_te_c(cur_r, tid);
+            const u64 *__restrict__ tcp = a.twc8 + (size_t)(cur_r * kUnits + (tid >> 4)) * 240u + (tid & 15u);
+#pragma unroll
+            for (int j = 0; j < 15; j++) tc[j] = tcp[j * 16];
+            ltw[tid] = te_c;                               // (every wave is past its S part: the barrier above; entries 240..255 unused)
+        }
+        // ================= the team meets =================
+        if (tid == 0) {
+            u32 *const sd = ctl + persist_ctl_sdone(xq, team, maxord);
+            ctl_add(sd, 1u);
+            u32 res = kTeamFail;
+            const u32 cap = have_held ? kSpinCap : kHelpPolls;   // holding a later ticket: every part has a holder, just wait
+            for (u32 it = 0; it < cap; it++) {
+                if (ctl_load(sd) >= kParts) { res = kTeamDone; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (res != kTeamDone && !have_held) res = kTeamHelp;
+            if (res == kTeamFail) fail(kPersistErrSdone);
+            if (res == kTeamDone && !have_held) k_h = ctl_add(head, 1u);   // the next ticket: a whole C part ahead of its use
+            ctrl[kCtlStatus] = res;
+        }
+        tick(tid, 0u, 3u);                                 // waiting for the team (lane 0)
+        __syncthreads();
+        tick(tid, 0u, 5u);
+        u32 res = __builtin_amdgcn_readfirstlane(ctrl[kCtlStatus]);
+        if (res == kTeamFail) return;
+        if (res == kTeamHelp) {
+            // ---- a long wait: draw the next ticket here and now ----
+            if (tid == 0) {
+                const u32 t = ctl_add(head, 1u);
+                ctrl[kCtlOrd] = t >> 4; ctrl[kCtlR] = t & 15u;
+            }
+            __syncthreads();
+            const u32 t_ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlOrd]), t_r = __builtin_amdgcn_readfirstlane(ctrl[kCtlR]);
+            if (t_ord == team) {                           // a part of this very polynomial that nobody had drawn: run its S part too
+                cur_r = t_r;
+                cur_loaded = 0;
+                guard_ahead = 0;
+                ltw[tid] = a.tw[tid];                      // the strided stages' tile again (nobody reads the tile now)
+                continue;
+            }
+            held = (t_ord << 4) | t_r;                     // a later ticket: every part of this polynomial has a holder
+            have_held = 1;
+            if (tid == 0) {
+                u32 got, status = kTeamDone;
+                if (!wait_ge(ctl + persist_ctl_sdone(xq, team, maxord), kParts, &got)) { status = kTeamFail; fail(kPersistErrSdone); }
+                ctrl[kCtlStatus] = status;
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(ctrl[kCtlStatus]) == kTeamFail) return;
+        }
+        // ================= C part(s) =================
+        if (single) {
+            c_part(tid, team, cur_r, tc, true);
+        } else {
+            for (u32 todo = own; todo;) {                  // (rare) every part this workgroup ran the S part of
+                const u32 r = (u32)__builtin_ctz(todo);
+                todo &= todo - 1u;
+                u32 tid2 = tid0;                           // opaque per iteration (see the top of the outer loop)
+                asm volatile("" : "+v"(tid2));
+                u64 tc2[15];
+                const Tw te = load_te_c(r, tid2);
+                const u64 *__restrict__ tcp = a.twc8 + (size_t)(r * kUnits + (tid2 >> 4)) * 240u + (tid2 & 15u);
+#pragma unroll
+                for (int j = 0; j < 15; j++) tc2[j] = tcp[j * 16];
+                __syncthreads();                           // the previous part's store loop / stage 8..11 reads are over
+                ltw[tid2] = te;
+                __syncthreads();
+                c_part(tid2, team, r, tc2, todo == 0);
+            }
+        }
+        own = 0; have_held = 0; guard_ahead = 1;
+        cur_ord = nxt_ord; cur_r = nxt_r; cur_loaded = pre ? 1u : 0u;
+    }
+}
+
 // twc[blk][2^i - 1 + g][tf] = tw[((2^(s0+4) + 16 blk + tf) << i) + g]  (the last four stages' twiddles of 256-blocks, in
 // the order the lanes of a unit read them: 16 lanes = 256 contiguous bytes)
 __global__ __launch_bounds__(256) void persist_twc_kernel(const Tw *__restrict__ tw, Tw *__restrict__ twc, u32 s0) {
@@ -494,53 +800,67 @@ __global__ __launch_bounds__(256) void persist_twc_kernel(const Tw *__restrict__
 
 size_t persist_twc_entries(unsigned log_n) { return ((size_t)1 << (log_n - 8)) * 240u; }
 
-hipError_t launch_persist_twc(const Tw *tw, Tw *twc, unsigned log_n, hipStream_t st) {
+// twc8: the same entries, first table word only (the team kernel recomputes the second)
+__global__ __launch_bounds__(256) void persist_twc8_kernel(const Tw *__restrict__ twc, u64 *__restrict__ twc8, u32 total) {
+    const u32 e = blockIdx.x * 256u + threadIdx.x;
+    if (e < total) twc8[e] = twc[e].w;
+}
+
+hipError_t launch_persist_twc(const Tw *tw, Tw *twc, u64 *twc8, unsigned log_n, hipStream_t st) {
     const u32 s0 = log_n - 8;
     const u32 total = (1u << s0) * 240u;
     hipLaunchKernelGGL(persist_twc_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, tw, twc, s0);
+    hipLaunchKernelGGL(persist_twc8_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, twc, twc8, total);
     return hipGetLastError();
 }
 
 bool persist_supported(const DevicePlan &p) { return p.log_n == 16 && p.arith == 2; }
 
-size_t persist_ctl_bytes(const PersistTune &t, u64 batch) {
-    const u64 ntiles = (batch + ((1ull << t.log_t) - 1)) >> t.log_t;
-    return persist_ctl_words(persist_maxord(ntiles, t.lag)) * sizeof(u32);
+// ordinals a queue can touch: lagged tiles — every tile could land on one queue; teams — its static eighth of the batch
+static u32 maxord_for(const PersistTune &t, u64 batch) {
+    if (t.teams) return (u32)(batch / kPersistQueues + 4);
+    return persist_maxord((batch + ((1ull << t.log_t) - 1)) >> t.log_t, t.lag);
 }
+size_t persist_ctl_bytes(const PersistTune &t, u64 batch) { return persist_ctl_words(maxord_for(t, batch)) * sizeof(u32); }
 size_t persist_ring_bytes(const PersistTune &t) {
     return t.ringslots ? ((size_t)kPersistQueues * t.ringslots << t.log_t) << 19 : 0;   // 512 KiB per polynomial
 }
 
-hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const u64 *in, u64 *out, u64 batch,
+hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const u64 *twc8, const u64 *in, u64 *out, u64 batch,
                                       const PersistTune &t, u32 *ctl, u64 *ring, u32 *host_err, u64 *prof, unsigned grid, hipStream_t st) {
     if (!persist_supported(p)) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     if (t.log_t > 10 || (t.ringslots && t.ringslots < t.lag + 1)) return hipErrorInvalidValue;
     PersistArgs a{};
     a.in = in; a.out = out; a.ring = ring;
-    a.tw = p.tw_fwd_pm; a.twc = twc; a.mod = p.mod;
+    a.tw = p.tw_fwd_pm; a.twc = twc; a.twc8 = twc8; a.mod = p.mod;
     a.batch = batch;
     a.ntiles = (batch + ((1ull << t.log_t) - 1)) >> t.log_t;
     a.log_t = t.log_t; a.lag = t.lag; a.ringslots = t.ringslots;
-    a.maxord = persist_maxord(a.ntiles, t.lag);
+    a.maxord = maxord_for(t, batch);
     a.ctl = ctl; a.host_err = host_err; a.prof = prof;
     hipError_t e = hipMemsetAsync(ctl, 0, persist_ctl_words(a.maxord) * sizeof(u32), st);
     if (e != hipSuccess) return e;
-    const void *fn = t.ringslots ? (const void *)ntt_fwd_persist_kernel<true> : (const void *)ntt_fwd_persist_kernel<false>;
-    if ((e = allow_big_lds(fn, kLdsBytes)) != hipSuccess) return e;
+    if (t.teams) {
+        if (t.log_t != 0 || t.ringslots == 0) return hipErrorInvalidValue;
+        KernelTimer kt("ntt_fwd_team", (int)t.ringslots, st);
+        hipLaunchKernelGGL(ntt_fwd_team_kernel, dim3(grid), dim3(kTH), kLdsBytes, st, a);
+        return hipGetLastError();
+    }
     KernelTimer kt("ntt_fwd_persist", (int)t.log_t, st);
     if (t.ringslots) hipLaunchKernelGGL(ntt_fwd_persist_kernel<true>, dim3(grid), dim3(kTH), kLdsBytes, st, a);
     else hipLaunchKernelGGL(ntt_fwd_persist_kernel<false>, dim3(grid), dim3(kTH), kLdsBytes, st, a);
     return hipGetLastError();
 }
 
-// workgroups the chip holds at once: 4 per CU (LDS: 4 x 38.3 KiB of 160)
-hipError_t persist_grid(unsigned *grid) {
+// workgroups the chip holds at once: 4 per CU (38.3 KiB of LDS each)
+hipError_t persist_grid(bool teams, unsigned *grid) {
     int dev = 0, cus = 0, per = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess) e = allow_big_lds((const void *)ntt_fwd_persist_kernel<true>, kLdsBytes);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_persist_kernel<true>, kTH, kLdsBytes);
+    if (e == hipSuccess)
+        e = teams ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_team_kernel, kTH, kLdsBytes)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_persist_kernel<true>, kTH, kLdsBytes);
     if (e != hipSuccess) return e;
     if (per < 1) per = 1;
     *grid = (unsigned)(cus * per);

@@ -76,6 +76,6 @@ FHE_HD inline uint64_t persist_ctl_words(uint32_t maxord) { return persist_ctl_b
 FHE_HD inline uint32_t persist_maxord(uint64_t ntiles, uint32_t lag) { return (uint32_t)(ntiles + lag + 2); }
 
 // error word bits
-enum : uint32_t { kPersistErrBind = 1u, kPersistErrSdone = 2u, kPersistErrCdone = 4u };
+enum : uint32_t { kPersistErrBind = 1u, kPersistErrSdone = 2u, kPersistErrCdone = 4u, kPersistErrQueue = 8u };
 
 }  // namespace fhe

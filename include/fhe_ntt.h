@@ -182,13 +182,21 @@ int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_index, size
  * (one launch per pass over the whole batch — measured fastest). */
 int fhe_ntt_set_batch_tile(size_t polys);
 /* The one-launch forward transform (n = 2^16, pseudo-Mersenne moduli; csrc/ntt_persist.hip): persistent workgroups
- * run the strided and the contiguous stages of NTT::ntt (arith/src/ntt.rs:44-73) in ONE kernel, handing the
- * intermediate over inside an XCD's L2 (a ring of `ringslots` tiles per XCD; 0 = through the output buffer) instead
- * of through HBM.  tile_polys: power of two <= 1024, 0 = off (the two-pass kernels); lag: tiles the strided stages
- * run ahead; ringslots >= lag + 1 or 0.  Environment: FHE_NTT_PERSIST=T[,L[,R]].  Every wait inside the kernel is
- * bounded; fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if one ran out, and clears the flag. */
-int fhe_ntt_set_persist(unsigned tile_polys, unsigned lag, unsigned ringslots);
+ * run the strided and the contiguous stages of NTT::ntt (arith/src/ntt.rs:44-73) in ONE kernel, drawing tickets from
+ * one queue per XCD, every wait inside the kernel bounded.
+ *   mode 0  off: the two-pass kernels.
+ *   mode 1  "A": tiles of tile_polys polynomials (power of two <= 1024); the strided stages run `lag` tiles ahead of
+ *           the contiguous ones; the intermediate lives in a ring of `ringslots` (>= lag + 1) tile slots per XCD, or in
+ *           the output buffer (ringslots = 0).
+ *   mode 2  "B": teams — sixteen workgroups of one XCD take ONE polynomial through both halves and meet in between; the
+ *           intermediate lives in a ring of `ringslots` (>= 1) polynomial slots per XCD and is read back out of the L2.
+ * Environment: FHE_NTT_PERSIST=A:T,L,R or B:R.  fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if a
+ * bounded wait ran out, and clears the flag. */
+int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned lag, unsigned ringslots);
 int fhe_ntt_persist_status(void);
+/* workgroups a persistent launch uses (default 0: as many as the chip holds).  Any number >= 1 gives the same words:
+ * nothing in the kernels assumes that workgroups are resident together (tests run 1, 8, 20, ...). */
+int fhe_ntt_set_persist_grid(int workgroups);
 /* diagnostic: d_words26 = device buffer of 26 uint64_t (zeroed by the caller), or NULL to stop; see tools/persist_bench.py */
 int fhe_ntt_persist_profile(void *d_words26);
 /* When enabled, every kernel launch is bracketed by HIP events on its stream;

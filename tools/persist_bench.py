@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/persist_bench.py — the one-launch n = 2^16 forward transform (csrc/ntt_persist.hip) against the two-pass kernels:
 word-for-word comparison on small / ragged batches, then timings over a list of (tile, lag, ring) settings.
-usage: python tools/persist_bench.py [batch] [T,L,R ...]       (diagnostic; not the contract bench)"""
+usage: python tools/persist_bench.py [batch] [A:T,L,R | B:R ...]       (diagnostic; not the contract bench)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,14 @@ import fhe_study_amd as pkg
 
 B = pkg.binding
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]] or [(1, 4, 6), (4, 2, 4), (16, 1, 0), (64, 1, 0)]
+def parse(a):
+    kind, rest = a.split(":")
+    vals = [int(v) for v in rest.split(",")]
+    return (1, vals[0], vals[1], vals[2]) if kind.upper() == "A" else (2, 1, 0, vals[0])
+
+
+cfgs = [parse(a) for a in sys.argv[2:]] or [parse("B:8"), parse("B:16"), parse("A:16,1,0"), parse("A:64,1,0")]
+name = lambda c: f"A:{c[1]},{c[2]},{c[3]}" if c[0] == 1 else f"B:{c[3]}" if c[0] == 2 else "two-pass"
 q, n = pkg.Q61, 1 << 16
 plan = pkg.Plan(q, n)
 st = torch.cuda.current_stream().cuda_stream
@@ -28,9 +35,9 @@ for b in (1, 3, 37, 300, 1030):
     B.set_persist(0)
     run(x, ref, b)
     torch.cuda.synchronize()
-    for (T, L, R) in cfgs:
+    for cfg in cfgs:
         y = torch.zeros_like(x)
-        B.set_persist(T, L, R)
+        B.set_persist(*cfg)
         t0 = time.perf_counter()
         run(x, y, b)
         torch.cuda.synchronize()
@@ -46,9 +53,38 @@ for b in (1, 3, 37, 300, 1030):
         torch.cuda.synchronize()
         ok2 = bool(torch.equal(z, ref))
         bad += (not ok) + (not ok2) + bool(err)
-        print(f"parity batch={b:5d} T={T} L={L} R={R}: {'ok' if ok else 'MISMATCH'} / in place {'ok' if ok2 else 'MISMATCH'}"
+        print(f"parity batch={b:5d} {name(cfg)}: {'ok' if ok else 'MISMATCH'} / in place {'ok' if ok2 else 'MISMATCH'}"
               f"  ({dt*1e3:.2f} ms){err}", flush=True)
     del x, ref
+# ---- no co-residency is assumed: the same words from 1, 7, 20 and 100 workgroups ----
+for grid in (1, 7, 20, 100):
+    B.set_persist_grid(grid)
+    b = 21
+    x = torch.empty(b * n, dtype=torch.int64, device="cuda:0")
+    B.fill_synthetic_dev(q, 99, 0, b * n, x.data_ptr(), st)
+    ref = torch.empty_like(x)
+    B.set_persist(0)
+    run(x, ref, b)
+    torch.cuda.synchronize()
+    for cfg in cfgs:
+        y = torch.zeros_like(x)
+        B.set_persist(*cfg)
+        t0 = time.perf_counter()
+        run(x, y, b)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        try:
+            B.persist_status()
+            err = ""
+        except Exception as e:   # noqa: BLE001
+            err = f" STATUS: {e}"
+        ok = bool(torch.equal(y, ref))
+        # a queue nobody serves (fewer workgroups than XCDs) must be REPORTED by the teams, never a silent hole
+        expected_err = cfg[0] == 2 and grid < 8
+        good = (ok and not err) or (expected_err and "never served" in err)
+        bad += not good
+        print(f"grid={grid:4d} batch={b} {name(cfg)}: {'ok' if ok else 'MISMATCH'} ({dt*1e3:.2f} ms){err}{'' if good else '  <-- FAILURE'}", flush=True)
+B.set_persist_grid(0)
 print("parity:", "ALL OK" if not bad else f"{bad} FAILURES", flush=True)
 if bad and not os.environ.get("PERSIST_BENCH_FORCE"):
     sys.exit(1)
@@ -57,8 +93,9 @@ if bad and not os.environ.get("PERSIST_BENCH_FORCE"):
 x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
 y = torch.empty_like(x)
 B.fill_synthetic_dev(q, 1, 0, batch * n, x.data_ptr(), st)
-for (T, L, R) in [(0, 0, 0)] + cfgs:
-    B.set_persist(T, L, R)
+for cfg in [(0, 0, 0, 0)] + cfgs:
+    T = cfg[0]
+    B.set_persist(*cfg)
     for _ in range(2):
         run(x, y, batch)
     torch.cuda.synchronize()
@@ -82,5 +119,5 @@ for (T, L, R) in [(0, 0, 0)] + cfgs:
             items = max(w[24 + ph], 1)
             tot = sum(w[ph * 12:ph * 12 + 12])
             prof += f"\n      {nm}: {items} items, {tot / items:.0f} ticks/item: " + ", ".join(f"{n} {w[ph * 12 + i] / items:.0f}" for i, n in enumerate(names))
-    print(f"time batch={batch} T={T} L={L} R={R}: {dt*1e3:.3f} ms  {batch/dt/1e6:.3f} M NTT/s  {batch*n*16/dt/8e12:.4f} of 8 TB/s"
+    print(f"time batch={batch} {name(cfg)}: {dt*1e3:.3f} ms  {batch/dt/1e6:.3f} M NTT/s  {batch*n*16/dt/8e12:.4f} of 8 TB/s"
           f"  (x 65536/batch = {dt*1e3*65536/batch:.2f} ms per step){prof}", flush=True)

@@ -453,9 +453,10 @@ static bool persist_tune(fhe::PersistTune *t) {
         g_persist_set = true;
         const char *e = getenv("FHE_NTT_PERSIST");       // "A:T,L,R" (tiles, lagged) or "B:R" (teams)
         unsigned T = 0, L = 1, R = 4;
-        if (e && (e[0] == 'B' || e[0] == 'b') && e[1] == ':' && sscanf(e + 2, "%u", &R) == 1 && R >= 1) {
+        unsigned stagger = 0;
+        if (e && (e[0] == 'B' || e[0] == 'b') && e[1] == ':' && sscanf(e + 2, "%u,%u", &R, &stagger) >= 1 && R >= 1) {
             g_persist = fhe::PersistTune{};
-            g_persist.log_t = 0; g_persist.lag = 0; g_persist.ringslots = R; g_persist.teams = true;
+            g_persist.log_t = 0; g_persist.lag = stagger; g_persist.ringslots = R; g_persist.teams = true;
             g_persist_on = true;
         } else if (e && (e[0] == 'A' || e[0] == 'a') && e[1] == ':' && sscanf(e + 2, "%u,%u,%u", &T, &L, &R) >= 1 && T > 0 &&
                    (T & (T - 1)) == 0 && T <= 1024 && (R == 0 || R >= L + 1)) {
@@ -483,7 +484,7 @@ extern "C" int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned 
         while ((1u << g_persist.log_t) < tile_polys) g_persist.log_t++;
         g_persist.lag = lag; g_persist.ringslots = ringslots;
     } else if (mode == 2) {
-        g_persist.log_t = 0; g_persist.lag = 0; g_persist.ringslots = ringslots; g_persist.teams = true;
+        g_persist.log_t = 0; g_persist.lag = lag; g_persist.ringslots = ringslots; g_persist.teams = true;   // lag: start-up stagger
     }
     return FHE_OK;
 }
@@ -555,9 +556,6 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
     if (rc != FHE_OK) return rc;
     uint32_t *herr = nullptr;
     if ((rc = persist_host_err(&herr)) != FHE_OK) return rc;
-    const size_t cb = (fhe::persist_ctl_bytes(tune, batch) + 255) & ~(size_t)255, rb = fhe::persist_ring_bytes(tune);
-    void *w = nullptr;
-    if ((rc = fhe_workspace_get(4, cb + rb, st, &w)) != FHE_OK) return rc;
     static unsigned grids[2] = {0, 0};
     unsigned &grid = grids[tune.teams ? 1 : 0];
     if (!grid) {
@@ -570,6 +568,9 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
         if (g_persist_grid < 0) { const char *e = getenv("FHE_NTT_PERSIST_GRID"); g_persist_grid = e ? atoi(e) : 0; }
     }
     const unsigned use_grid = g_persist_grid > 0 ? (unsigned)g_persist_grid : grid;
+    const size_t cb = (fhe::persist_ctl_bytes(tune, batch, use_grid) + 255) & ~(size_t)255, rb = fhe::persist_ring_bytes(tune, use_grid);
+    void *w = nullptr;
+    if ((rc = fhe_workspace_get(4, cb + rb, st, &w)) != FHE_OK) return rc;
     hipError_t e = fhe::launch_ntt_forward_persist(dp, twc, twc8, (const u64 *)d_in, (u64 *)d_out, batch, tune, (uint32_t *)w,
                                                    rb ? (u64 *)((char *)w + cb) : nullptr, herr, (u64 *)g_persist_prof, use_grid, st);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward_persist");
@@ -1066,6 +1067,8 @@ static int host_transform(const fhe_ntt_plan *plan, const uint64_t *in, uint64_t
     HIP_TRY(hipMemcpyAsync(out, d.p, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     d.clean = true;
+    // a persistent launch (FHE_NTT_PERSIST) that gave up a bounded wait left words that are not the transform
+    if (!inverse && (rc = fhe_ntt_persist_status()) != FHE_OK) return rc;
     return FHE_OK;
 }
 

@@ -522,10 +522,9 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
     const u32 tid0 = threadIdx.x;
     const u32 xq = xcc_id();
     const Mod &m = a.mod;
-    const u32 maxord = a.maxord, R = a.ringslots;
+    const u32 maxord = a.maxord, R = a.ringslots, G = a.groups, nq = kPersistQueues * G;
     constexpr u32 kParts = 16u;
     u32 *const ctl = a.ctl;
-    u32 *const head = ctl + persist_ctl_head(xq);
 
     const bool profiling = a.prof != nullptr;
     if (profiling && tid0 == 0) {
@@ -540,11 +539,32 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
         }
     };
     auto fail = [&](u32 status) {
-        atomicOr(ctl + persist_ctl_err(), status);
+        atomicOr(ctl + team_ctl_err(nq), status);
         __hip_atomic_fetch_or(a.host_err, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
-    auto poly_of = [&](u32 ord) -> u64 { return (u64)ord * kPersistQueues + xq; };
-    auto slot_of = [&](u32 ord) -> u64 * { return a.ring + (((u64)xq * R + ord % R) << 16); };
+    // Stable GROUPS: the workgroups of an XCD sort themselves into groups of sixteen as they arrive (member number / 16), and
+    // a group has its own queue, its own share of the batch and its own ring slots.  Without them every team is a fresh
+    // mixture of the XCD's workgroups, each wait couples its sixteen members to the slowest, and within a few polynomials
+    // the whole XCD runs in lockstep — everybody loading, everybody waiting — which is the opposite of what the four
+    // workgroups of a CU are for.  Groups drift apart (and start staggered), so a CU's workgroups are in different phases.
+    // Nothing depends on a group being complete: waiters help (below), and a workgroup whose group's queue has run dry
+    // moves on to the next group's of its XCD.
+    u32 grp = 0;
+    if (tid0 == 0) {
+        const u32 mnum = ctl_add(ctl + team_ctl_members(nq, xq), 1u);
+        ctrl[kCtlBind] = (mnum / kParts) % G;
+    }
+    __syncthreads();
+    grp = __builtin_amdgcn_readfirstlane(ctrl[kCtlBind]);
+    if (tid0 == 0)
+        for (u32 i = 0; i < grp * a.lag; i++) __builtin_amdgcn_s_sleep(127);   // stagger: a.lag x ~8k cycles per group
+    u32 qx = xq * G + grp;                                 // this workgroup's queue
+    u32 dry = 0;                                           // queues of this XCD found empty so far
+    auto poly_of = [&](u32 ord) -> u64 { return team_poly(ord, xq, grp, G); };
+    auto slot_of = [&](u32 ord) -> u64 * { return a.ring + (((u64)qx * R + ord % R) << 16); };
+    auto sdone_of = [&](u32 ord) -> u32 * { return ctl + team_ctl_sdone(nq, qx, ord, maxord); };
+    auto cdone_of = [&](u32 ord) -> u32 * { return ctl + team_ctl_cdone(nq, qx, ord, maxord); };
+    auto head_of = [&]() -> u32 * { return ctl + team_ctl_head(qx); };
     auto issue_s_loads = [&](u32 ord, u32 r, u32 tid, u64 (&x)[16]) {
         const u32 c = tid % kCW, tf = tid / kCW;
         const u64 *__restrict__ pin = a.in + (poly_of(ord) << 16) + r * kCW;
@@ -563,7 +583,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
     u32 cur_ord = 0, cur_r = 0, cur_loaded = 0;
     u32 pf_dep = 0;                             // lane 0: cdone of the current ticket's ring slot's previous tenant, as loaded ahead
     if (tid0 == 0) {
-        const u32 k0 = ctl_add(head, 1u);
+        const u32 k0 = ctl_add(head_of(), 1u);
         ctrl[kCtlOrd] = k0 >> 4; ctrl[kCtlR] = k0 & 15u;
     }
     __syncthreads();
@@ -601,13 +621,13 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             const u32 t = have_held ? held : k_h;
             const u32 nord = t >> 4;
             pf_dep = kParts;
-            if (poly_of(nord) < a.batch && nord >= R) pf_dep = ctl_load(ctl + persist_ctl_cdone(xq, nord - R, maxord));
+            if (poly_of(nord) < a.batch && nord >= R) pf_dep = ctl_load(cdone_of(nord - R));
             ctrl[kCtlWords + kCtlOrd] = nord; ctrl[kCtlWords + kCtlR] = t & 15u;
         }
         tick(tid, 1u, 3u);
         __syncthreads();
         tick(tid, 1u, 4u);
-        if (tid == 0) ctl_add(ctl + persist_ctl_cdone(xq, team, maxord), 1u);   // this part has read the slot
+        if (tid == 0) ctl_add(cdone_of(team), 1u);   // this part has read the slot
         if (last) {
             nxt_ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlWords + kCtlOrd]);
             nxt_r = __builtin_amdgcn_readfirstlane(ctrl[kCtlWords + kCtlR]);
@@ -652,17 +672,29 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
         tick(tid, 0u, 6u);
         __syncthreads();                                   // the LDS tile is free
         tick(tid, 0u, 0u);
-        if (poly_of(cur_ord) >= a.batch) {                 // past the last polynomial: so is every later ticket of this queue
+        if (poly_of(cur_ord) >= a.batch) {                 // past this queue's last polynomial: so is every later ticket of it
+            if (++dry < G) {                               // on to the next group's queue of this XCD (same L2), as one more member
+                grp = grp + 1u == G ? 0u : grp + 1u;
+                qx = xq * G + grp;
+                if (tid == 0) {
+                    const u32 t = ctl_add(head_of(), 1u);
+                    ctrl[kCtlOrd] = t >> 4; ctrl[kCtlR] = t & 15u;
+                }
+                __syncthreads();
+                cur_ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlOrd]);
+                cur_r = __builtin_amdgcn_readfirstlane(ctrl[kCtlR]);
+                cur_loaded = 0;
+                guard_ahead = 0;
+                continue;
+            }
             if (profiling && tid == 0)
                 for (u32 i = 0; i < kProfWords - 1; i++) atomicAdd((unsigned long long *)a.prof + i, (unsigned long long)prof[i]);
-            if (tid == 0 && ctl_add(ctl + persist_ctl_gtile(), 1u) + 1u == gridDim.x) {
-                // the last workgroup out: were all tickets of all eight queues drawn?  (a queue nobody served leaves its
-                // polynomials untouched: that must be an error, never a silent hole in the output)
+            if (tid == 0 && ctl_add(ctl + team_ctl_left(nq), 1u) + 1u == gridDim.x) {
+                // the last workgroup out: were all tickets of all queues drawn?  (an XCD nobody ran on leaves its polynomials
+                // untouched: that must be an error, never a silent hole in the output)
                 u32 bad = 0;
-                for (u32 q = 0; q < kPersistQueues; q++) {
-                    const u64 polys = a.batch > q ? (a.batch - q + kPersistQueues - 1u) / kPersistQueues : 0u;
-                    if ((u64)ctl_load(ctl + persist_ctl_head(q)) < polys * kParts) bad = 1;
-                }
+                for (u32 q = 0; q < nq; q++)
+                    if ((u64)ctl_load(ctl + team_ctl_head(q)) < team_queue_polys(a.batch, q / G, q % G, G) * kParts) bad = 1;
                 if (bad) fail(kPersistErrQueue);
             }
             return;
@@ -681,7 +713,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             if (tid == 0) {                                // the ring slot's previous tenant must have been read (normally: long ago)
                 u32 status = 0u, got;
                 if (team >= R && !(guard_ahead && pf_dep >= kParts) &&
-                    !wait_ge(ctl + persist_ctl_cdone(xq, team - R, maxord), kParts, &got)) { status = kPersistErrCdone; fail(status); }
+                    !wait_ge(cdone_of(team - R), kParts, &got)) { status = kPersistErrCdone; fail(status); }
                 ctrl[kCtlStatus] = status;
             }
             __syncthreads();
@@ -719,7 +751,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
         }
         // ================= the team meets =================
         if (tid == 0) {
-            u32 *const sd = ctl + persist_ctl_sdone(xq, team, maxord);
+            u32 *const sd = sdone_of(team);
             ctl_add(sd, 1u);
             u32 res = kTeamFail;
             const u32 cap = have_held ? kSpinCap : kHelpPolls;   // holding a later ticket: every part has a holder, just wait
@@ -729,7 +761,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             }
             if (res != kTeamDone && !have_held) res = kTeamHelp;
             if (res == kTeamFail) fail(kPersistErrSdone);
-            if (res == kTeamDone && !have_held) k_h = ctl_add(head, 1u);   // the next ticket: a whole C part ahead of its use
+            if (res == kTeamDone && !have_held) k_h = ctl_add(head_of(), 1u);   // the next ticket: a whole C part ahead of its use
             ctrl[kCtlStatus] = res;
         }
         tick(tid, 0u, 3u);                                 // waiting for the team (lane 0)
@@ -740,7 +772,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
         if (res == kTeamHelp) {
             // ---- a long wait: draw the next ticket here and now ----
             if (tid == 0) {
-                const u32 t = ctl_add(head, 1u);
+                const u32 t = ctl_add(head_of(), 1u);
                 ctrl[kCtlOrd] = t >> 4; ctrl[kCtlR] = t & 15u;
             }
             __syncthreads();
@@ -756,7 +788,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             have_held = 1;
             if (tid == 0) {
                 u32 got, status = kTeamDone;
-                if (!wait_ge(ctl + persist_ctl_sdone(xq, team, maxord), kParts, &got)) { status = kTeamFail; fail(kPersistErrSdone); }
+                if (!wait_ge(sdone_of(team), kParts, &got)) { status = kTeamFail; fail(kPersistErrSdone); }
                 ctrl[kCtlStatus] = status;
             }
             __syncthreads();
@@ -816,30 +848,37 @@ hipError_t launch_persist_twc(const Tw *tw, Tw *twc, u64 *twc8, unsigned log_n, 
 
 bool persist_supported(const DevicePlan &p) { return p.log_n == 16 && p.arith == 2; }
 
-// ordinals a queue can touch: lagged tiles — every tile could land on one queue; teams — its static eighth of the batch
-static u32 maxord_for(const PersistTune &t, u64 batch) {
-    if (t.teams) return (u32)(batch / kPersistQueues + 4);
+// teams: stable groups of sixteen workgroups per XCD
+static u32 groups_for(unsigned grid) { const u32 g = grid / (kPersistQueues * 16u); return g ? g : 1u; }
+// ordinals a queue can touch: lagged tiles — every tile could land on one queue; teams — its static share of the batch
+static u32 maxord_for(const PersistTune &t, u64 batch, unsigned grid) {
+    if (t.teams) return (u32)(batch / (kPersistQueues * groups_for(grid)) + 4);
     return persist_maxord((batch + ((1ull << t.log_t) - 1)) >> t.log_t, t.lag);
 }
-size_t persist_ctl_bytes(const PersistTune &t, u64 batch) { return persist_ctl_words(maxord_for(t, batch)) * sizeof(u32); }
-size_t persist_ring_bytes(const PersistTune &t) {
-    return t.ringslots ? ((size_t)kPersistQueues * t.ringslots << t.log_t) << 19 : 0;   // 512 KiB per polynomial
+size_t persist_ctl_bytes(const PersistTune &t, u64 batch, unsigned grid) {
+    if (t.teams) return team_ctl_words(kPersistQueues * groups_for(grid), maxord_for(t, batch, grid)) * sizeof(u32);
+    return persist_ctl_words(maxord_for(t, batch, grid)) * sizeof(u32);
+}
+size_t persist_ring_bytes(const PersistTune &t, unsigned grid) {
+    if (t.teams) return ((size_t)kPersistQueues * groups_for(grid) * t.ringslots) << 19;   // 512 KiB per polynomial
+    return t.ringslots ? ((size_t)kPersistQueues * t.ringslots << t.log_t) << 19 : 0;
 }
 
 hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const u64 *twc8, const u64 *in, u64 *out, u64 batch,
                                       const PersistTune &t, u32 *ctl, u64 *ring, u32 *host_err, u64 *prof, unsigned grid, hipStream_t st) {
     if (!persist_supported(p)) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
-    if (t.log_t > 10 || (t.ringslots && t.ringslots < t.lag + 1)) return hipErrorInvalidValue;
+    if (t.log_t > 10 || (!t.teams && t.ringslots && t.ringslots < t.lag + 1)) return hipErrorInvalidValue;
     PersistArgs a{};
     a.in = in; a.out = out; a.ring = ring;
     a.tw = p.tw_fwd_pm; a.twc = twc; a.twc8 = twc8; a.mod = p.mod;
     a.batch = batch;
     a.ntiles = (batch + ((1ull << t.log_t) - 1)) >> t.log_t;
     a.log_t = t.log_t; a.lag = t.lag; a.ringslots = t.ringslots;
-    a.maxord = maxord_for(t, batch);
+    a.maxord = maxord_for(t, batch, grid);
+    a.groups = groups_for(grid);
     a.ctl = ctl; a.host_err = host_err; a.prof = prof;
-    hipError_t e = hipMemsetAsync(ctl, 0, persist_ctl_words(a.maxord) * sizeof(u32), st);
+    hipError_t e = hipMemsetAsync(ctl, 0, persist_ctl_bytes(t, batch, grid), st);
     if (e != hipSuccess) return e;
     if (t.teams) {
         if (t.log_t != 0 || t.ringslots == 0) return hipErrorInvalidValue;

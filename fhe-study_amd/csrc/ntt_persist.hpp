@@ -8,7 +8,7 @@ namespace fhe {
 
 struct PersistTune {
     uint32_t log_t = 0;       // tile = 2^log_t polynomials
-    uint32_t lag = 1;         // chunks of S work a queue runs ahead of its C work
+    uint32_t lag = 1;         // chunks of S work a queue runs ahead of its C work (teams: start-up stagger between groups, x ~8k cycles)
     uint32_t ringslots = 4;   // tile-sized slots of the per-XCD ring holding the intermediate; 0: it lives in `out`
     bool teams = false;       // variant B: one ticket = both halves of 1/16 of ONE polynomial, the sixteen holders meet in between (log_t = 0, lag unused)
 };
@@ -23,6 +23,7 @@ struct PersistArgs {
     Mod mod;
     u64 batch, ntiles;
     uint32_t log_t, lag, ringslots, maxord;
+    uint32_t groups;  // teams: stable groups of sixteen workgroups per XCD, each with its own queue and ring slots
     uint32_t *ctl;    // control block, zeroed before the launch (persist_sched.hpp)
     uint32_t *host_err;   // pinned host word (device pointer): error bits are OR-ed in here too, where the host can see them
     u64 *prof;            // nullptr, or 26 words: lane 0's shader-clock ticks per part of an iteration (fhe_ntt_persist_profile)
@@ -31,8 +32,8 @@ struct PersistArgs {
 bool persist_supported(const DevicePlan &p);
 size_t persist_twc_entries(unsigned log_n);
 hipError_t launch_persist_twc(const Tw *tw, Tw *twc, u64 *twc8, unsigned log_n, hipStream_t st);
-size_t persist_ctl_bytes(const PersistTune &t, u64 batch);
-size_t persist_ring_bytes(const PersistTune &t);
+size_t persist_ctl_bytes(const PersistTune &t, u64 batch, unsigned grid);
+size_t persist_ring_bytes(const PersistTune &t, unsigned grid);
 hipError_t persist_grid(bool teams, unsigned *grid);
 // ctl: persist_ctl_bytes(t, batch) bytes; ring: persist_ring_bytes(t) bytes (nullptr when t.ringslots == 0).
 // The error word is ctl[persist_ctl_err()], mirrored into *host_err: non-zero once the launch has finished = a bounded wait ran out.

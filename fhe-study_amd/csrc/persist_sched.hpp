@@ -75,6 +75,30 @@ FHE_HD inline uint64_t persist_ctl_words(uint32_t maxord) { return persist_ctl_b
 // ordinals a queue can touch: every tile could land on one queue, plus the lag + 1 ordinals past the end it looks at
 FHE_HD inline uint32_t persist_maxord(uint64_t ntiles, uint32_t lag) { return (uint32_t)(ntiles + lag + 2); }
 
+// ---- teams (variant B): queues are (XCD, group) pairs, q = xcd * groups + group, nq = 8 * groups of them ----
+// control block: [queue heads: nq lines][workgroups that have left: 1 line][error word: 1 line][members per XCD: 8 lines]
+//                [sdone: nq x maxord][cdone: nq x maxord]
+FHE_HD inline uint64_t team_ctl_head(uint32_t q) { return (uint64_t)q * kPersistLineWords; }
+FHE_HD inline uint64_t team_ctl_left(uint32_t nq) { return (uint64_t)nq * kPersistLineWords; }
+FHE_HD inline uint64_t team_ctl_err(uint32_t nq) { return (uint64_t)(nq + 1) * kPersistLineWords; }
+FHE_HD inline uint64_t team_ctl_members(uint32_t nq, uint32_t xcd) { return (uint64_t)(nq + 2 + xcd) * kPersistLineWords; }
+FHE_HD inline uint64_t team_ctl_sdone(uint32_t nq, uint32_t q, uint32_t ord, uint32_t maxord) {
+    return (uint64_t)(nq + 2 + kPersistQueues) * kPersistLineWords + (uint64_t)q * maxord + ord;
+}
+FHE_HD inline uint64_t team_ctl_cdone(uint32_t nq, uint32_t q, uint32_t ord, uint32_t maxord) {
+    return team_ctl_sdone(nq, 0, 0, maxord) + (uint64_t)(nq + q) * maxord + ord;
+}
+FHE_HD inline uint64_t team_ctl_words(uint32_t nq, uint32_t maxord) { return team_ctl_sdone(nq, 0, 0, maxord) + 2ull * nq * maxord; }
+// polynomial of ordinal `ord` of queue (xcd, group): the batch is dealt out statically, 8 * groups polynomials per round
+FHE_HD inline uint64_t team_poly(uint32_t ord, uint32_t xcd, uint32_t group, uint32_t groups) {
+    return ((uint64_t)ord * groups + group) * kPersistQueues + xcd;
+}
+// polynomials of the batch that queue (xcd, group) owns
+FHE_HD inline uint64_t team_queue_polys(uint64_t batch, uint32_t xcd, uint32_t group, uint32_t groups) {
+    const uint64_t first = (uint64_t)group * kPersistQueues + xcd, step = (uint64_t)groups * kPersistQueues;
+    return batch > first ? (batch - first + step - 1) / step : 0;
+}
+
 // error word bits
 enum : uint32_t { kPersistErrBind = 1u, kPersistErrSdone = 2u, kPersistErrCdone = 4u, kPersistErrQueue = 8u };
 

@@ -82,3 +82,13 @@ def test_tfhe_mirror_reference_tests(pkg):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all host C++ tfhe tests passed" in r.stdout
+
+
+def test_persistent_transform_protocols_simulated(pkg):
+    """csrc/persist_sched.hpp (the ticket arithmetic the kernels compile) driven by CPU models of the two persistent
+    kernels' workgroup state machines under a random scheduler: no deadlock from ONE workgroup per queue upwards, every
+    part run exactly once, ring slots never rewritten before they were read (fhe-study_amd/host/test_persist_sched.cpp)."""
+    exe = _build(pkg, "test_persist_sched")
+    r = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all persist schedule tests passed" in r.stdout

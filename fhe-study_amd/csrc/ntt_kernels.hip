@@ -26,6 +26,17 @@
 
 #include <cstdlib>
 
+// A/B switches of round 4 (defaults = what was measured faster on one box; tools/abl_build.sh builds the others)
+#ifndef FHE_MID_ONE_TILE
+#define FHE_MID_ONE_TILE 1        // rq_mul_mid_kernel: one twiddle tile that changes hands (4 workgroups per CU) / two tiles (3)
+#endif
+#ifndef FHE_MID_EARLY_FETCH
+#define FHE_MID_EARLY_FETCH 1     // rq_mul_mid_kernel: both operands' loads issued up front
+#endif
+#ifndef FHE_INV_TLOAD
+#define FHE_INV_TLOAD 1           // ntt_inv_contig_kernel (first pass of a two-pass inverse): whole-line loads transposed through LDS
+#endif
+
 namespace fhe {
 // SRC_DIGITS (single-pass sizes only): the input is `batch / digit_l` rows of 64-bit words and
 // output polynomial p is the transform of bit digit_l-1-(p % digit_l) of row p / digit_l — the
@@ -156,12 +167,37 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     Tw *ltw = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
     stage_twiddles<C::LTW_N, C::TH>(ltw, a.tw, s0, blk, tid);  // published by the barrier below
 
-    // first window = field bits [0,4): a thread's 16 coefficients are 128 contiguous bytes,
-    // fetched as 8 x 16 B straight into registers (no staging through LDS)
+    // first window = field bits [0,4): a thread's 16 coefficients are 128 contiguous bytes.
     constexpr int ALAST = C::a_of(C::NR - 1);
     static_assert(ALAST == 0, "first inverse window is the low 4 bits");
+    // TLOAD (round 4; the first pass of a two-pass inverse on the pseudo-Mersenne tables, which runs at the memory system's
+    // rate): the tile is loaded the way the forward kernel stores it — element e = i TH + tid, a wave instruction = 512
+    // contiguous bytes, whole lines, so the non-temporal hint applies — and transposed through LDS into the register window;
+    // the pointwise product of a fused multiply is formed (and its evals stored) in that layout, position by position.
+    // Otherwise: 8 x 16 B per lane straight into registers (a line arrives in pieces; the cache merges them).
+    constexpr bool TLOAD = FHE_INV_TLOAD && !FINAL && AR == 2;
     u64 v[16];
-    {
+    if constexpr (TLOAD) {
+        const u64 *__restrict__ pin = a.in + ubase;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32 e = i * C::TH + tid, wu = e >> LP, f = e & (C::M - 1);
+            const u32 o = (((wu < live ? wu : 0u) << a.log_n) + f) * 8u;
+            u64 x = ld_at<u64>(pin, o);
+            if constexpr (MUL_IN) {
+                const u64 y = ld_at<u64>(a.in2 + ubase, o);
+                x = mul_var_pm(x, y, a.mod);                     // both canonical: five multiplies
+                if (a.out2) {
+                    x = pm_canon(x, a.mod);                      // canonical only if the product is an output
+                    if (wu < live) st_at(a.out2 + ubase, o, x);
+                }
+            }
+            lds[pad16(e)] = x;
+        }
+        __syncthreads();                                         // (also publishes the twiddle tile)
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * C::M + field_of<ALAST>(tf, k))];
+    } else {
         const u32 g0 = off + tf * 128u;
         const u64 *__restrict__ pin = a.in + ubase;
 #pragma unroll
@@ -190,11 +226,11 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
                 if (a.out2 && active) st_c<ulonglong2>(pout2, g0 + j * 16u, p);
             }
         }
+        __syncthreads();
     }
 
-    __syncthreads();
     // inputs are canonical (evals, or their product); a non-FINAL pass hands values below 4q (WIDE) / 2q on
-    if constexpr (AR == 2) inv_rounds_contig_pm<LP, FINAL, true, (MUL_IN ? kPmMul : kPmOne)>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2) inv_rounds_contig_pm<LP, FINAL, !TLOAD, (MUL_IN ? kPmMul : kPmOne)>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_contig<LP, WIDE, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
 
     if (active) {
@@ -361,8 +397,12 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    // ONE twiddle tile (round 4): the forward table's while the operands are transformed, the inverse table's afterwards —
+    // each lane holds its entry of the second in registers from the start and swaps it in between two barriers around the
+    // pointwise product.  38 KiB instead of 42 KiB of LDS: FOUR workgroups per CU instead of three.
     Tw *ltw_f = reinterpret_cast<Tw *>(smem_raw + C::DATA_BYTES);
-    Tw *ltw_i = ltw_f + C::LTW_N;
+    Tw *ltw_i = FHE_MID_ONE_TILE ? ltw_f : ltw_f + C::LTW_N;
+    static_assert(C::LTW_N == C::TH, "one tile entry per lane");
     const u32 tid = threadIdx.x, w = tid / C::TPB, tf = tid % C::TPB;
     const u32 s0 = a.log_n - LP;
     const u32 blk = blockIdx.x & ((1u << s0) - 1u);
@@ -373,13 +413,16 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     const u64 ubase = pg * C::W * n + (u64)blk * C::M;
     const u32 off = ((active ? w : 0u) << a.log_n) * 8u;
     const Mod &m = a.mod;
-    stage_twiddles<C::LTW_N, C::TH>(ltw_f, a.tw, s0, blk, tid);       // both published by the barrier(s)
-    stage_twiddles<C::LTW_N, C::TH>(ltw_i, a.tw_inv, s0, blk, tid);   // that precede their first LDS use
+    stage_twiddles<C::LTW_N, C::TH>(ltw_f, a.tw, s0, blk, tid);       // published by the barrier that precedes its first LDS use
+    // this lane's entry of the inverse tile (stage_twiddles' formula), in registers until the tile changes hands
+    const u32 tw_i_ls = 31u - (u32)__builtin_clz(tid | 1u), tw_i_l1 = tid | (tid == 0);
+    const Tw tw_i_entry = a.tw_inv[(1u << (s0 + tw_i_ls)) + (blk << tw_i_ls) + (tw_i_l1 - (1u << tw_i_ls))];
     static_assert(C::NR >= 2, "two-pass sizes have LP >= 8");
 
     // keep: the operand's evals are an output, so they must be canonical; otherwise they stay as the last
     // stage left them (< 4q < 2^63): the variable x variable product reduces any 128-bit value
-    auto operand = [&](const u64 *__restrict__ src, bool is_evals, bool keep, u64 (&v)[16], auto fresh) {
+    // both operands' loads are issued before anything is computed: the second operand's latency hides behind the first's stages
+    auto fetch = [&](const u64 *__restrict__ src, bool is_evals, u64 (&v)[16]) {
         const u64 *__restrict__ p = src + ubase;
         if (is_evals) {
 #pragma unroll
@@ -391,6 +434,10 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
+        }
+    };
+    auto operand = [&](bool is_evals, bool keep, u64 (&v)[16], auto fresh) {
+        if (!is_evals) {
             if constexpr (AR == 2) fwd_rounds_contig_pm<LP, kPmPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
             else fwd_rounds_contig<LP, WIDE, true, kPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
             if (keep) {
@@ -407,10 +454,15 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     };
 
     u64 va[16], vb[16];
-    operand(a.in, a.flags & 1u, a.out3 != nullptr, va, std::true_type{});
+    fetch(a.in, a.flags & 1u, va);
+    if (FHE_MID_EARLY_FETCH) fetch(a.in2, a.flags & 2u, vb);
+    operand(a.flags & 1u, a.out3 != nullptr, va, std::true_type{});
     store_evals(a.out3, va);
-    operand(a.in2, a.flags & 2u, a.out4 != nullptr, vb, std::false_type{});   // the tile may have been used by the first operand
+    if (!FHE_MID_EARLY_FETCH) fetch(a.in2, a.flags & 2u, vb);
+    operand(a.flags & 2u, a.out4 != nullptr, vb, std::false_type{});   // the tile may have been used by the first operand
     store_evals(a.out4, vb);
+    if (FHE_MID_ONE_TILE) __syncthreads();   // every wave is past the forward rounds: the twiddle tile changes hands
+    ltw_i[tid] = tw_i_entry;
     if constexpr (AR == 2) {   // as in rq_mul_fused_kernel
 #pragma unroll
         for (int k = 0; k < 16; k++) va[k] = mul_var_pm(va[k], pm_below_2k(vb[k], m), m);
@@ -423,9 +475,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
         for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
     }
     store_evals(a.out2, va);
-    // the inverse rounds' first exchange follows a forward exchange's gather unless both operands were
-    // evals; its leading barrier (FRESH = false) also publishes the inverse twiddle tile in that case
-    if (a.flags == 3u) __syncthreads();   // no forward exchange ran: publish the twiddle tiles here
+    __syncthreads();                     // the inverse tile is in place (the first inverse round reads it before any exchange)
     if constexpr (AR == 2) inv_rounds_contig_pm<LP, false, false, kPmMul>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_contig<LP, WIDE, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
@@ -818,7 +868,7 @@ static hipError_t launch_rq_mul_mid_lp(const PassArgs &a, hipStream_t st) {
     const u64 grid = nb * ((a.batch + C::W - 1) / C::W);
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    constexpr size_t lds_bytes = C::LDS_BYTES + (size_t)C::LTW_N * sizeof(Tw);   // a second twiddle tile
+    constexpr size_t lds_bytes = C::LDS_BYTES + (FHE_MID_ONE_TILE ? 0 : (size_t)C::LTW_N * sizeof(Tw));   // ONE twiddle tile: four workgroups per CU
     if (hipError_t e = allow_big_lds((const void *)rq_mul_mid_kernel<LP, AR>, lds_bytes)) return e;
     KernelTimer kt("rq_mul_mid", LP, st);
     hipLaunchKernelGGL((rq_mul_mid_kernel<LP, AR>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);

@@ -92,3 +92,14 @@ def test_persistent_transform_protocols_simulated(pkg):
     r = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all persist schedule tests passed" in r.stdout
+
+
+def test_c_abi_without_a_device_or_with_one(pkg):
+    """every path of include/fhe_ntt.h that needs no device — plan construction and cache (16 threads), the reference's
+    argument checks in the reference's order, shard arithmetic, switches — and the compute entry points, which must return
+    FHE_E_NO_DEVICE here and the right words on the GPU box (fhe-study_amd/host/test_nodevice.cpp; `make san` runs the same
+    program under ASan + UBSan against a host-only build: profiles/r04_host_sanitizers.txt)"""
+    exe = _build(pkg, "test_nodevice")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all no-device tests passed" in r.stdout

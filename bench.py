@@ -47,14 +47,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # tools/ubench_bfly.hip v8 (the production form) at 8 waves per SIMD, profiles/r01_ubench_bfly.txt.
 VALU_PEAK_GBFLY = 2018.7
 # the five-multiply butterfly of pseudo-Mersenne moduli (zq_device.hpp: ct_bfly_pm), which the headline modulus runs:
-# tools/ubench_bfly.hip v17 at 8 waves per SIMD, profiles/r03_ubench_bfly.txt
-VALU_PEAK_GBFLY_PM = 2627.1
+# tools/ubench_bfly.hip v18 (13 instructions, round 4) at 8 waves per SIMD, profiles/r04_ubench_bfly.txt
+VALU_PEAK_GBFLY_PM = 2837.2
 # the 32-bit butterfly of the small-prime kernels (digit32.hip / bfv32.hip): tools/ubench_bfly.hip v13, registers only
 VALU_PEAK_GBFLY32 = 5730.0
 # HBM traffic per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
 # WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Counters cannot be read from inside this process.
-PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def parse():
@@ -196,7 +196,7 @@ def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
 
     transforms = 2 if inverse_too else 1
     arith = plan.arithmetic()                              # which exact Zq::mul the kernels run (fhe_ntt_plan_arithmetic)
-    small_q = arith == 3                                   # smallq.hip: 32-bit words (NOT the BASELINE modulus: --q given)
+    small_q = arith == 3                                   # FHE_ARITH_WORD32 of include/fhe_ntt.h (the PUBLIC numbering): smallq.hip, 32-bit words (NOT the BASELINE modulus: --q given)
     if inverse_too:
         name = (f"batched forward+inverse negacyclic NTT, N={n}, q={q}, {batch} polynomials per GPU "
                 "(BASELINE.json configs[1] shape), device-resident")
@@ -440,10 +440,10 @@ def main():
                      "frac": per_gpu * W["bfly_per_unit"] / 1e9 / valu_peak,
                      "butterflies_per_unit": W["bfly_per_unit"],
                      "butterfly": ("32-bit words modulo 27-bit primes (6 instructions)" if small else
-                                   "64-bit words modulo a pseudo-Mersenne q = 2^k - delta (split multiplicand, 5 multiplies, 14 instructions)" if pm else
+                                   "64-bit words modulo a pseudo-Mersenne q = 2^k - delta (split multiplicand, 5 multiplies, 13 instructions)" if pm else
                                    "64-bit words modulo q < 2^61 (Shoup, 10 multiplies)"),
                      "peak_source": ("tools/ubench_bfly.hip v13 (registers only), profiles/r02_ubench_bfly.txt" if small else
-                                     "tools/ubench_bfly.hip v17 (production butterfly, registers only), profiles/r03_ubench_bfly.txt" if pm else
+                                     "tools/ubench_bfly.hip v18 (production butterfly, registers only), profiles/r04_ubench_bfly.txt" if pm else
                                      "tools/ubench_bfly.hip v8 (production butterfly, registers only), profiles/r01_ubench_bfly.txt")},
         }
         if dom and W["pass_bytes_per_launch_per_unit"]:
@@ -461,7 +461,8 @@ def main():
                     with open(f) as fh:
                         pmc = json.load(fh)
                     traffic = pmc["kernels"][dom]["hbm_bytes_per_polynomial"] * units_per_launch
-                    traffic_src = pmc["source"]
+                    # the counters come from a file an EARLIER profiling run wrote (rocprofv3 cannot run inside this process)
+                    traffic_src = "prior run (" + os.path.relpath(f, ROOT) + "), not measured in this process: " + pmc["source"]
                     if all(k in pmc["kernels"] for k in kernels):   # every pass kernel touches each polynomial once per step
                         step_traffic = sum(pmc["kernels"][k]["hbm_bytes_per_polynomial"] for k in kernels) * W["batch"]
                     break

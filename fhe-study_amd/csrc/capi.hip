@@ -323,7 +323,7 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     dp->tw_inv_pm = t.tw_inv_pm;
     dp->ninv_pm = plan->ninv_pm;
     dp->s_ninv_pm = plan->s_ninv_pm;
-    dp->arith = (plan->q >> 62) ? 3 : (t.tw_fwd_pm && fhe_pm_enabled()) ? 2 : dp->wide ? 1 : 0;
+    dp->arith = (plan->q >> 62) ? fhe::kArStrict63 : (t.tw_fwd_pm && fhe_pm_enabled()) ? fhe::kArPMersenne : dp->wide ? fhe::kArWide61 : fhe::kArShoup62;
     return FHE_OK;
 }
 
@@ -577,13 +577,12 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
     return FHE_OK;
 }
 
-// Grow-only library workspaces, one per (slot, device, STREAM): slot 0 = fhe_rq_mul_dev(d_work = NULL)
-// and the tensor result of fhe_bfv_mul_dev, slot 1 = zring / glue intermediates.  The contents
-// belong to one call; calls on the same stream are ordered by the stream, calls on different
-// streams get different buffers, so the *_dev entry points may be issued concurrently from any
-// number of streams and threads (tests/test_parity_gpu.py::test_two_streams_share_no_workspace).
-// hipStreamPerThread is ONE handle that names a different stream in every thread, so for it
-// the key also carries the calling thread.  Growing never frees a buffer that enqueued work may
+// Grow-only library workspaces, one per (slot, device, STREAM, calling THREAD): slot 0 = fhe_rq_mul_dev(d_work = NULL)
+// and the tensor result of fhe_bfv_mul_dev, slot 1 = zring / glue intermediates, slot 3 = small-modulus scratch,
+// slot 4 = the persistent transform's control block and ring.  The contents belong to one call; a thread's calls on a
+// stream are ordered by the stream, and no two threads or streams share a buffer, so the *_dev entry points may be issued
+// concurrently from any number of streams and threads — on the same stream too
+// (tests/test_parity_gpu.py::test_two_streams_share_no_workspace, test_two_threads_on_the_default_stream).  Growing never frees a buffer that enqueued work may
 // still be using: the old buffer is retired and released at fhe_ntt_shutdown().
 struct Workspace {
     void *ptr = nullptr;
@@ -608,7 +607,10 @@ int fhe_workspace_get(int slot, size_t bytes, hipStream_t st, void **out) {
     int dev = 0;
     int rc = fhe_current_device(&dev);
     if (rc != FHE_OK) return rc;
-    const size_t tid = st == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0;
+    // keyed by the calling THREAD for every stream (round 4): two host threads that enqueue on the same stream — the NULL
+    // default stream is the common case for a shim whose Rq operations are freely shareable — get different buffers, so
+    // their kernel sequences may interleave on the stream without sharing an intermediate
+    const size_t tid = std::hash<std::thread::id>()(std::this_thread::get_id());
     std::lock_guard<std::mutex> lk(g_ws_lock);
     Workspace &w = g_ws[WsKey{slot, dev, st, tid}];
     if (w.bytes < bytes) {
@@ -703,10 +705,13 @@ extern "C" int fhe_ntt_release_stream_workspace(void *hip_stream) {
     if (rc != FHE_OK) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipStreamSynchronize(st));
-    const size_t tid = st == hipStreamPerThread ? std::hash<std::thread::id>()(std::this_thread::get_id()) : 0;
+    // hipStreamPerThread names a different stream in every thread: only the caller's buffers; an explicit stream is
+    // about to be destroyed: the buffers of EVERY thread that used it
+    const bool per_thread = st == hipStreamPerThread;
+    const size_t tid = std::hash<std::thread::id>()(std::this_thread::get_id());
     std::lock_guard<std::mutex> lk(g_ws_lock);
-    for (auto it = g_ws.begin(); it != g_ws.end();) {        // every slot of this (device, stream, thread)
-        if (it->first.dev == dev && it->first.st == st && it->first.tid == tid) {
+    for (auto it = g_ws.begin(); it != g_ws.end();) {        // every slot of this (device, stream[, thread])
+        if (it->first.dev == dev && it->first.st == st && (!per_thread || it->first.tid == tid)) {
             if (it->second.ptr) (void)hipFree(it->second.ptr);
             it = g_ws.erase(it);
         } else {
@@ -814,7 +819,7 @@ extern "C" int fhe_ntt_kernel_timing_read(char *names, double *total_ms, uint64_
     return i;
 }
 
-// small moduli (q < 2^30, 2^8 <= n <= 2^17): one 32-bit word per coefficient (smallq.hip); FHE_EXT32=0 keeps the 61-bit kernels
+// small moduli (q < 2^30, 2^8 <= n <= 2^18): one 32-bit word per coefficient (smallq.hip); FHE_EXT32=0 keeps the 61-bit kernels
 bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a) {
     if (!dp.tw32_fwd || !fhe_ext32_enabled()) return false;
     const u64 q = plan->q;

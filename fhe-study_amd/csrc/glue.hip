@@ -327,7 +327,7 @@ extern "C" int fhe_tr_dot_dev(const fhe_ntt_plan *plan, const void *d_a, const v
     u64 *C = out_ev ? (u64 *)d_c : WC;
     // T = k terms, nc = 1 output row, "G" = A per batch element
     { fhe::KernelTimer kt_("mac_rows", 0, st);
-    fhe::launch_mac_rows(dp.arith == 3, fhe_ew_grid(fhe::mac_rows_threads(batch, 1, n)), st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
+    fhe::launch_mac_rows(dp.arith == fhe::kArStrict63, fhe_ew_grid(fhe::mac_rows_threads(batch, 1, n)), st, A, B, C, (u64)batch, (u32)n, (u32)k, (u32)1, (u64)k * n, plan->mod);
     }
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_c, batch, st);
@@ -355,7 +355,7 @@ extern "C" int fhe_tr_mul_r_dev(const fhe_ntt_plan *plan, const void *d_a, const
     u64 *C = out_ev ? (u64 *)d_out : WC;
     // T = 1, nc = rows: out[b][c] = A[b][c] * P[b]
     { fhe::KernelTimer kt_("mac_rows", 0, st);
-    fhe::launch_mac_rows(dp.arith == 3, fhe_ew_grid(fhe::mac_rows_threads(batch, rows, n)), st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
+    fhe::launch_mac_rows(dp.arith == fhe::kArStrict63, fhe_ew_grid(fhe::mac_rows_threads(batch, rows, n)), st, A, P, C, (u64)batch, (u32)n, (u32)1, (u32)rows, (u64)rows * n, plan->mod);
     }
     LAUNCH_OK("mac_rows_kernel");
     return out_ev ? FHE_OK : inv(plan, dp, C, (u64 *)d_out, total, st);
@@ -371,7 +371,7 @@ static int keyed_mac(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const 
     if (!key_is_evals) { if ((rc = fwd(plan, dp, d_key, WK, (u64)T * nc, st)) != FHE_OK) return rc; K = WK; }
     if (!v_is_evals) { if ((rc = fwd(plan, dp, d_v, WV, batch * T, st)) != FHE_OK) return rc; V = WV; }
     { fhe::KernelTimer kt_("mac_rows", 0, st);
-    fhe::launch_mac_rows(dp.arith == 3, fhe_ew_grid(fhe::mac_rows_threads(batch, nc, n)), st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
+    fhe::launch_mac_rows(dp.arith == fhe::kArStrict63, fhe_ew_grid(fhe::mac_rows_threads(batch, nc, n)), st, K, V, d_out, batch, (u32)n, T, nc, (u64)0, plan->mod);
     }
     LAUNCH_OK("mac_rows_kernel");
     return out_evals ? FHE_OK : inv(plan, dp, d_out, d_out, batch * nc, st);

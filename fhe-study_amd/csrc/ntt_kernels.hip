@@ -784,7 +784,7 @@ static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_
 }
 // the tables and n^-1 constants a pass runs on: {w, w 2^32 mod q} for pseudo-Mersenne plans, {w, floor(w 2^64 / q)} otherwise
 static inline void set_tables(PassArgs &a, const DevicePlan &p, bool inverse) {
-    const bool pm = p.arith == 2;
+    const bool pm = p.arith == kArPMersenne;
     a.tw = inverse ? (pm ? p.tw_inv_pm : p.tw_inv) : (pm ? p.tw_fwd_pm : p.tw_fwd);
     a.mod = p.mod;
     a.ninv = pm ? p.ninv_pm : p.ninv;
@@ -795,7 +795,7 @@ static inline void set_tables(PassArgs &a, const DevicePlan &p, bool inverse) {
 
 hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
                               u64 batch_tile, hipStream_t st) {
-    if (p.arith == 3) return launch_g63_forward(p, in, out, batch, st);   // 2^62 <= q < 2^63: generic63.hip
+    if (p.arith == kArStrict63) return launch_g63_forward(p, in, out, batch, st);   // 2^62 <= q < 2^63: generic63.hip
     PassArgs a{};
     const int L = p.log_n;
     // n < 16: one thread per polynomial on the Shoup tables
@@ -845,11 +845,11 @@ static hipError_t launch_rq_mul_fused_lp(const PassArgs &a, hipStream_t st) {
 hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_evals, const u64 *b_, bool b_is_evals,
                                u64 *c, u64 *c_evals, u64 *a_evals, u64 *b_evals, u64 batch, hipStream_t st) {
     const int L = p.log_n;
-    if (L < 4 || L > kMaxSinglePassLog || p.arith == 3) return hipErrorNotSupported;
+    if (L < 4 || L > kMaxSinglePassLog || p.arith == kArStrict63) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     PassArgs a{};
     set_tables(a, p, false);
-    a.tw_inv = p.arith == 2 ? p.tw_inv_pm : p.tw_inv;
+    a.tw_inv = p.arith == kArPMersenne ? p.tw_inv_pm : p.tw_inv;
     a.in = a_; a.in2 = b_; a.out = c; a.out2 = c_evals; a.out3 = a_evals; a.out4 = b_evals;
     a.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
     a.batch = batch;
@@ -882,7 +882,7 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
                                   u64 *c, u64 *c_evals, u64 *wa, bool keep_a_evals, u64 *wb, bool keep_b_evals,
                                   u64 batch, u64 batch_tile, hipStream_t st) {
     const int L = p.log_n;
-    if (L <= kMaxSinglePassLog || L > kMaxLog || p.arith == 3) return hipErrorNotSupported;
+    if (L <= kMaxSinglePassLog || L > kMaxLog || p.arith == kArStrict63) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
@@ -1005,7 +1005,7 @@ hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *ou
 // evals_out when that is non-null).
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st) {
-    if (p.arith == 3) return launch_g63_inverse(p, in, in2, evals_out, out, batch, st);
+    if (p.arith == kArStrict63) return launch_g63_inverse(p, in, in2, evals_out, out, batch, st);
     PassArgs a{};
     const int L = p.log_n;
     const int ar = L < 4 ? (p.wide ? 1 : 0) : p.arith;
@@ -1051,7 +1051,7 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
 // q < 2^61, < 2q otherwise) for a strided last pass the caller runs itself (zring.hip fuses its epilogue there)
 hipError_t launch_ntt_inverse_first_pass(const DevicePlan &p, const u64 *in, u64 *out, u64 batch, hipStream_t st) {
     const int L = p.log_n;
-    if (L <= kMaxSinglePassLog || L > kMaxLog || p.arith == 3) return hipErrorNotSupported;
+    if (L <= kMaxSinglePassLog || L > kMaxLog || p.arith == kArStrict63) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     PassArgs a{};
     a.tw = p.tw_inv; a.mod = p.mod; a.ninv = p.ninv; a.s_ninv = p.s_ninv; a.log_n = p.log_n;
@@ -1068,7 +1068,7 @@ static inline unsigned ew_grid(u64 count) {
 
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
                                 hipStream_t st) {
-    if (p.arith == 3) return launch_g63_pointwise(p, x, y, z, count, st);
+    if (p.arith == kArStrict63) return launch_g63_pointwise(p, x, y, z, count, st);
     if (count == 0) return hipSuccess;
     KernelTimer kt("pointwise_mul", 0, st);
     hipLaunchKernelGGL(pointwise_mul_kernel, dim3(ew_grid(count)), dim3(256), 0, st, x, y, z, count, p.mod);

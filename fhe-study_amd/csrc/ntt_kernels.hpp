@@ -32,7 +32,16 @@ struct DevicePlan {
     const Tw *tw_fwd_pm = nullptr;
     const Tw *tw_inv_pm = nullptr;
     Tw ninv_pm{}, s_ninv_pm{};
-    int arith = 0;      // the transform kernels' AR: 0 = q < 2^62, 1 = wide, 2 = pseudo-Mersenne; 3 = 2^62 <= q < 2^63 (generic63.hip)
+    int arith = 0;      // which kernels the plan's transforms run: kArShoup62 ... kArStrict63 below (the template parameter AR of the kernels)
+};
+
+// DevicePlan::arith — INTERNAL numbering (the kernels' template parameter AR).  The PUBLIC numbering of
+// fhe_ntt_plan_arithmetic() (include/fhe_ntt.h: FHE_ARITH_*) is a different one: never compare the two.
+enum : int {
+    kArShoup62 = 0,     // q < 2^62: Harvey [0, 4q), Shoup products
+    kArWide61 = 1,      // q < 2^61: Shoup products, compile-time bounds up to 8q
+    kArPMersenne = 2,   // q = 2^k - delta: five-multiply butterflies on {w, w 2^32 mod q}
+    kArStrict63 = 3,    // 2^62 <= q < 2^63: strict butterflies in plain kernels (generic63.hip)
 };
 
 struct PassArgs {

@@ -846,7 +846,7 @@ hipError_t launch_persist_twc(const Tw *tw, Tw *twc, u64 *twc8, unsigned log_n, 
     return hipGetLastError();
 }
 
-bool persist_supported(const DevicePlan &p) { return p.log_n == 16 && p.arith == 2; }
+bool persist_supported(const DevicePlan &p) { return p.log_n == 16 && p.arith == kArPMersenne; }
 
 // teams: stable groups of sixteen workgroups per XCD
 static u32 groups_for(unsigned grid) { const u32 g = grid / (kPersistQueues * 16u); return g ? g : 1u; }

@@ -24,17 +24,13 @@
  *     reference panics in the same situations; the Rust shim turns a non-zero
  *     return into `panic!`.
  *   - All functions are thread-safe and may be called concurrently, on the same
- *     or different plans, with ONE restriction: entry points that need
- *     intermediates use a library-owned workspace keyed by (device, stream),
- *     so the calls that use one (fhe_rq_mul_dev with d_work = NULL, the
- *     small-modulus two-pass sizes, rows N1 - N3) must not be issued on the
- *     SAME explicit stream — the NULL default stream included — from several
- *     host threads at once: their kernel sequences would interleave on a
- *     shared buffer.  Calls on one stream from one thread are ordered by the
- *     stream; calls on different streams, and calls on hipStreamPerThread /
- *     the host-buffer entry points from different threads (keyed by thread as
- *     well), never share a buffer.  Plans are immutable and owned by the
- *     library until fhe_ntt_shutdown().
+ *     or different plans, streams and threads.  Entry points that need
+ *     intermediates use a library-owned workspace keyed by (device, stream,
+ *     calling thread): a thread's calls on a stream are ordered by the stream,
+ *     and no two threads or streams ever share a buffer — two host threads
+ *     enqueueing on the SAME stream (the NULL default stream included) are
+ *     fine.  Plans are immutable and owned by the library until
+ *     fhe_ntt_shutdown().
  *   - `*_dev` variants take DEVICE pointers of the current HIP device and a
  *     `hipStream_t` passed as `void*` (NULL = the default stream); they only
  *     enqueue work and never synchronise — except the first use of a plan on a

@@ -69,9 +69,9 @@ def test_no_workgroup_needs_another_to_be_resident(pkg, oracle, need_gpu, persis
     for setting in (("A", 4, 1, 3), ("A", 16, 1, 0), ("B", 1, 1, 2)):
         pkg.binding.set_persist(*setting)
         if setting[0] == "B" and grid < 8:
-            with pytest.raises(pkg.FheError) as e:
+            with pytest.raises(Exception) as e:     # (FheError: the package may be loaded under two module names in one session)
                 plan.forward(a)
-            assert e.value.code == pkg.binding.FHE_E_HIP and "never served" in str(e.value)
+            assert type(e.value).__name__ == "FheError" and e.value.code == pkg.binding.FHE_E_HIP and "never served" in str(e.value)
             continue
         assert np.array_equal(plan.forward(a), ref), (setting, grid)
 
@@ -118,6 +118,48 @@ def test_other_plans_keep_the_two_pass_kernels(pkg, oracle, need_gpu, persist_of
 def test_set_persist_rejects_what_the_kernels_cannot_run(pkg):
     B = pkg.binding
     for bad in ((1, 3, 1, 0), (1, 2048, 1, 0), (1, 16, 2, 2), (2, 1, 0, 0), (3, 1, 1, 1)):
-        with pytest.raises(pkg.FheError):
+        with pytest.raises(Exception) as e:
             B.set_persist(*bad)
+        assert type(e.value).__name__ == "FheError" and e.value.code == B.FHE_E_INVALID
     B.set_persist(0)
+
+
+@pytest.mark.gpu
+def test_two_threads_on_the_default_stream(pkg, oracle, need_gpu):
+    """Two host threads enqueue products that need the library workspace (two-pass size, d_work = NULL) on the SAME stream —
+    the NULL default stream — with no synchronisation between them: the workspace is keyed by the calling thread as well,
+    so their kernel sequences may interleave on the stream without sharing an intermediate (until round 4 the
+    header forbade this and two such threads silently computed wrong words)."""
+    import threading
+
+    import torch
+
+    q, n, batch = Q61, 16384, 12
+    plan = pkg.Plan(q, n)
+    jobs = []
+    for i in range(2):
+        a = oracle.fill_synthetic(q, 700 + i, 0, batch * n)
+        b = oracle.fill_synthetic(q, 800 + i, 0, batch * n)
+        da = torch.from_numpy(a.view(np.int64).copy()).cuda()
+        db = torch.from_numpy(b.view(np.int64).copy()).cuda()
+        jobs.append((da, db, torch.empty_like(da), oracle.rq_mul(q, n, a, b)[0]))
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(j):
+        da, db, dc, _ = jobs[j]
+        try:
+            for _ in range(40):
+                plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, stream=None)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(j,)) for j in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for _, _, dc, want in jobs:
+        assert np.array_equal(dc.cpu().numpy().view(np.uint64), want)

@@ -54,6 +54,19 @@ def _worker(rank, world, port, batch, n, q, out_dir):
     for rows in (1, 2, 5):
         again = eng.forward_sharded(rows_fn, batch, gather=True, overlap_rows=rows)
         assert torch.equal(again, full), (rank, rows)
+    # a transform that fills a caller's buffer (Plan.forward_dev's shape): the short last shard is written straight into
+    # the equal-count send buffer
+    def transform_out(rows, out=None):
+        r = transform(rows)
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+    eng_out = pkg.sharding.ShardedNTT(transform_out)
+    assert eng_out._takes_out and not eng._takes_out
+    assert torch.equal(eng_out.forward_sharded(rows_fn, batch, gather=True), full), rank
+    assert torch.equal(eng_out.forward_sharded(rows_fn, batch, gather=True, overlap_rows=2), full), rank
     # the same gather in chunks of rows (several collectives + copies into place): same batch
     for chunk in (1, 2, 3, 64):
         again = pkg.sharding.all_gather_rows(local, batch, chunk_rows=chunk)

@@ -26,6 +26,11 @@ if [ "$2" = "collect" ]; then
   cp $OUT/bench_pm0.json profiles/${TAG}_bench_shoup_kernels.json 2>/dev/null || true
   cp $OUT/isa_counters_a.json profiles/${TAG}_isa_counters_a.json 2>/dev/null || true
   cp $OUT/isa_counters_b.json profiles/${TAG}_isa_counters_b.json 2>/dev/null || true
+  # the one-launch transform: one report per variant
+  python3 tools/persist_report.py $OUT ${TAG} || true
+  for f in bench_persist_A bench_persist_B bench_rank_of_8; do [ -s $OUT/$f.json ] && grep '^{' $OUT/$f.json | tail -1 > profiles/${TAG}_$f.json; done
+  # JSON evidence files hold the JSON line only (RCCL prints banners on stdout)
+  for f in profiles/${TAG}_bench_rccl_world1.json profiles/${TAG}_bench_2ranks_one_gpu.json; do [ -s $f ] && { grep '^{' $f | tail -1 > $f.tmp; mv $f.tmp $f; }; done
   sed -i '/amdgpu.ids/d' profiles/${TAG}_*.txt
   exit 0
 fi
@@ -113,6 +118,30 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY --k
 python3 tools/pmc_isa.py $OUT/pmc3_a $OUT/config3_counters_a.json > /dev/null 2>&1 || true
 python3 tools/pmc_isa.py $OUT/pmc3_b $OUT/config3_counters_b.json > /dev/null 2>&1 || true
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt
+
+echo "[8] the one-launch transform (variants A and B): ms per step at three settings each, per-part profile, traffic, counters"; date
+PERSIST_PROFILE=1 timeout -k 10 900 python tools/persist_bench.py 65536 A:16,1,0 A:64,1,0 A:256,1,0 B:1,1 B:2,1 B:4,1 > $OUT/persist_bench.txt 2>&1 || tail -5 $OUT/persist_bench.txt
+grep -E "^time|parity:" $OUT/persist_bench.txt || true
+for cfg in two-pass A:64,1,0 B:2,1; do
+  tag=$(echo $cfg | tr ':,' '__')
+  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pt_f_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_f_$tag.log 2>&1 || true
+  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pt_w_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_w_$tag.log 2>&1 || true
+  timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pt_a_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_a_$tag.log 2>&1 || true
+  timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $OUT/pt_b_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_b_$tag.log 2>&1 || true
+  { echo "== $cfg: HBM-side bytes per launch (8192 polynomials per launch = 4295 MB in + 4295 MB out; two-pass: per 2048-polynomial launch = 1074 + 1074 MB per pass)"
+    python3 tools/pmc_kernels.py $OUT/pt_f_$tag $OUT/pt_w_$tag 100
+    echo "== $cfg: instruction counters per wave"
+    python3 tools/pmc_isa.py $OUT/pt_a_$tag $OUT/persist_counters_a_$tag.json | grep -v fill_synthetic
+    python3 tools/pmc_isa.py $OUT/pt_b_$tag $OUT/persist_counters_b_$tag.json | grep -v fill_synthetic; } >> $OUT/persist_counters.txt 2>&1 || true
+done
+cat $OUT/persist_counters.txt || true
+FHE_NTT_PERSIST=A:64,1,0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_persist_A.json 2> $OUT/bench_persist_A.err || true
+FHE_NTT_PERSIST=B:2,1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_persist_B.json 2> $OUT/bench_persist_B.err || true
+timeout -k 10 300 python bench.py --global-batch 8192 --steps 40 --no-cpu-baseline > $OUT/bench_rank_of_8.json 2> $OUT/bench_rank_of_8.err || true
+for f in bench_persist_A bench_persist_B bench_rank_of_8; do python3 -c "
+import json
+o=json.loads([l for l in open('$OUT/$f.json') if l.startswith('{')][-1]); print('$f', round(o['value']), o['unit'], 'ms/step', round(o['ms_per_step'],3), 'step_frac', round(o['roofline']['step_frac'],4))" || true; done
 rm -rf $OUT/pmc3_*/*/*.db $OUT/pmc_isa_*/*/*.db $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc4_*/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true
+rm -rf $OUT/pt_*/*/*.db 2>/dev/null || true
 find $OUT -name "*.db" -delete 2>/dev/null || true
 date

@@ -454,9 +454,10 @@ static bool persist_tune(fhe::PersistTune *t) {
         const char *e = getenv("FHE_NTT_PERSIST");       // "A:T,L,R" (tiles, lagged) or "B:R" (teams)
         unsigned T = 0, L = 1, R = 4;
         unsigned stagger = 0;
-        if (e && (e[0] == 'B' || e[0] == 'b') && e[1] == ':' && sscanf(e + 2, "%u,%u", &R, &stagger) >= 1 && R >= 1) {
+        if (e && (e[0] == 'B' || e[0] == 'b' || e[0] == 'D' || e[0] == 'd') && e[1] == ':' && sscanf(e + 2, "%u,%u", &R, &stagger) >= 1 && R >= 1) {
             g_persist = fhe::PersistTune{};
             g_persist.log_t = 0; g_persist.lag = stagger; g_persist.ringslots = R; g_persist.teams = true;
+            g_persist.deep = e[0] == 'D' || e[0] == 'd';      // "D:R,s": the teams at two workgroups per CU
             g_persist_on = true;
         } else if (e && (e[0] == 'A' || e[0] == 'a') && e[1] == ':' && sscanf(e + 2, "%u,%u,%u", &T, &L, &R) >= 1 && T > 0 &&
                    (T & (T - 1)) == 0 && T <= 1024 && (R == 0 || R >= L + 1)) {
@@ -470,12 +471,12 @@ static bool persist_tune(fhe::PersistTune *t) {
     return g_persist_on;
 }
 extern "C" int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned lag, unsigned ringslots) {
-    if (mode > 2) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: mode %u (0 off, 1 = A: lagged tiles, 2 = B: teams)", mode);
+    if (mode > 3) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: mode %u (0 off, 1 = A: lagged tiles, 2 = B: teams, 3 = B at two workgroups per CU)", mode);
     if (mode == 1 && (tile_polys == 0 || (tile_polys & (tile_polys - 1)) != 0 || tile_polys > 1024))
         return fail(FHE_E_INVALID, "fhe_ntt_set_persist: tile of %u polynomials (need a power of two <= 1024)", tile_polys);
     if (mode == 1 && ringslots && ringslots < lag + 1)
         return fail(FHE_E_INVALID, "fhe_ntt_set_persist: a ring of %u slots cannot hold a lag of %u tiles (need >= lag + 1)", ringslots, lag);
-    if (mode == 2 && ringslots == 0) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: teams need a ring (ringslots >= 1)");
+    if (mode >= 2 && ringslots == 0) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: teams need a ring (ringslots >= 1)");
     std::lock_guard<std::mutex> lk(g_cfg_lock);
     g_persist_set = true;
     g_persist_on = mode != 0;
@@ -483,8 +484,9 @@ extern "C" int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned 
     if (mode == 1) {
         while ((1u << g_persist.log_t) < tile_polys) g_persist.log_t++;
         g_persist.lag = lag; g_persist.ringslots = ringslots;
-    } else if (mode == 2) {
+    } else if (mode >= 2) {
         g_persist.log_t = 0; g_persist.lag = lag; g_persist.ringslots = ringslots; g_persist.teams = true;   // lag: start-up stagger
+        g_persist.deep = mode == 3;
     }
     return FHE_OK;
 }
@@ -556,11 +558,11 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
     if (rc != FHE_OK) return rc;
     uint32_t *herr = nullptr;
     if ((rc = persist_host_err(&herr)) != FHE_OK) return rc;
-    static unsigned grids[2] = {0, 0};
-    unsigned &grid = grids[tune.teams ? 1 : 0];
+    static unsigned grids[3] = {0, 0, 0};
+    unsigned &grid = grids[tune.teams ? (tune.deep ? 2 : 1) : 0];
     if (!grid) {
         unsigned g = 0;
-        HIP_TRY(fhe::persist_grid(tune.teams, &g));
+        HIP_TRY(fhe::persist_grid(tune, &g));
         grid = g;
     }
     {   // FHE_NTT_PERSIST_GRID / fhe_ntt_set_persist_grid: another number of workgroups (tests: fewer than the chip holds)

@@ -512,13 +512,22 @@ enum : u32 { kTeamDone = 0, kTeamHelp = 1, kTeamFail = 2 };
 // stages 12..15 of a C part are 15 words per lane of the lane-ordered table twc8 — only w, 8 bytes: the second table word
 // w 2^32 mod q is recomputed (pm_shift32, three instructions) — fetched into 30 registers when the S part has stored, so
 // that they arrive while the team meets.  Four workgroups per CU.
-__global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
+// DEEP: the form for TWO workgroups per CU (launched with half the grid): 256 registers per lane and 43 KiB of LDS, so
+// both twiddle tiles stay in LDS and the next S part's coefficients are loaded into a second set of registers as soon as the
+// C part's exchange barrier is passed — they land while its last four stages compute.  Fewer workgroups = fewer polynomials
+// between "written" and "read" per XCD: at two per CU the ring's lines are still in the L2 when they are read back, at one
+// per CU they are not even written back (profiles/r04_persist_B_l2_probe.txt).
+constexpr size_t kTeamDeepLdsBytes = kTileBytes + 2 * 256 * sizeof(Tw) + 64 + kProfWords * 8;
+template <bool DEEP>
+__global__ __launch_bounds__(kTH, (DEEP ? 2 : 4)) void ntt_fwd_team_kernel(PersistArgs a) {
     using S = StridedCfg<8, kCW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
-    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + kTileBytes);               // the twiddle tile (see above)
-    u32 *ctrl = reinterpret_cast<u32 *>(smem_raw + kTileBytes + 256 * sizeof(Tw));
-    u64 *prof = reinterpret_cast<u64 *>(smem_raw + kTileBytes + 256 * sizeof(Tw) + 64);
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + kTileBytes);               // the twiddle tile (see above); DEEP: the C parts' only
+    Tw *stw = DEEP ? ltw + 256 : ltw;                                       // the strided stages' tile
+    constexpr size_t kTwBytes = (DEEP ? 2 : 1) * 256 * sizeof(Tw);
+    u32 *ctrl = reinterpret_cast<u32 *>(smem_raw + kTileBytes + kTwBytes);
+    u64 *prof = reinterpret_cast<u64 *>(smem_raw + kTileBytes + kTwBytes + 64);
     const u32 tid0 = threadIdx.x;
     const u32 xq = xcc_id();
     const Mod &m = a.mod;
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
         return a.tw[((256u + r * kUnits + bl) << i) + g];
     };
 
-    ltw[tid0] = a.tw[tid0];
+    stw[tid0] = a.tw[tid0];
     u32 cur_ord = 0, cur_r = 0, cur_loaded = 0;
     u32 pf_dep = 0;                             // lane 0: cdone of the current ticket's ring slot's previous tenant, as loaded ahead
     if (tid0 == 0) {
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
     cur_ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlOrd]);
     cur_r = __builtin_amdgcn_readfirstlane(ctrl[kCtlR]);
 
-    u64 v[16];
+    u64 v[16], vn[16];                                     // vn (DEEP): the next S part's coefficients, in flight during a C part
     u32 own = 0;                                           // parts of the current polynomial this workgroup has run the S part of
     u32 held = 0, have_held = 0, k_h = 0;                  // the ticket drawn for afterwards (k_h: lane 0, in flight)
     u32 guard_ahead = 1;                                   // lane 0's pf_dep belongs to the current ticket
@@ -631,6 +640,8 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
         if (last) {
             nxt_ord = __builtin_amdgcn_readfirstlane(ctrl[kCtlWords + kCtlOrd]);
             nxt_r = __builtin_amdgcn_readfirstlane(ctrl[kCtlWords + kCtlR]);
+            pre = poly_of(nxt_ord) < a.batch;
+            if (DEEP && pre) issue_s_loads(nxt_ord, nxt_r, tid, vn);   // land while stages 12..15 compute
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = lds[pad16(u * 256u + field_of<0>(tfc, k))];
@@ -646,14 +657,11 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             if ((k & 3) == 3) FHE_SCHED_FENCE();
         }
         tick(tid, 1u, 9u);
-        if (last) {
-            pre = poly_of(nxt_ord) < a.batch;
-            if (pre) issue_s_loads(nxt_ord, nxt_r, tid, v);        // the next item's coefficients: land across the hand-over
-        }
+        if (!DEEP && last && pre) issue_s_loads(nxt_ord, nxt_r, tid, v);   // the next item's coefficients: land across the hand-over
         tick(tid, 1u, 10u);
         __syncthreads();
         tick(tid, 1u, 11u);
-        if (last) ltw[tid] = a.tw[tid];                    // the strided stages' tile again (read after the barrier at the top)
+        if (!DEEP && last) ltw[tid] = a.tw[tid];           // the strided stages' tile again (read after the barrier at the top)
         {
             u64 *__restrict__ pout = a.out + (poly_of(team) << 16) + (u64)r * kUnits * 256u;
 #pragma unroll
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             if (!cur_loaded) issue_s_loads(team, cur_r, tid, v);
             tick(tid, 0u, 1u);
             if (profiling && tid == 0) prof[24] += 1;
-            round_fwd_pm_f<S::R0, kPmOne, 4>(v, [&](int i, int g) { return ltw[(1 << i) + g]; }, m);
+            round_fwd_pm_f<S::R0, kPmOne, 4>(v, [&](int i, int g) { return stw[(1 << i) + g]; }, m);
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[field_of<S::A0>(tfs, k) * kSRow + c] = v[k];
             tick(tid, 0u, 2u);
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             {
                 constexpr int P1 = pm_fwd_bound_out(S::R0, kPmOne);
                 const u32 T1 = 16u + tfs;
-                round_fwd_pm_f<4, P1, 4>(v, [&](int i, int g) { return ltw[(T1 << i) + g]; }, m);
+                round_fwd_pm_f<4, P1, 4>(v, [&](int i, int g) { return stw[(T1 << i) + g]; }, m);
             }
             tick(tid, 0u, 8u);
             u64 *__restrict__ pout = slot_of(team) + cur_r * kCW;
@@ -781,7 +789,7 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
                 cur_r = t_r;
                 cur_loaded = 0;
                 guard_ahead = 0;
-                ltw[tid] = a.tw[tid];                      // the strided stages' tile again (nobody reads the tile now)
+                if (!DEEP) ltw[tid] = a.tw[tid];           // the strided stages' tile again (nobody reads the tile now)
                 continue;
             }
             held = (t_ord << 4) | t_r;                     // a later ticket: every part of this polynomial has a holder
@@ -815,6 +823,10 @@ __global__ __launch_bounds__(kTH, 4) void ntt_fwd_team_kernel(PersistArgs a) {
             }
         }
         own = 0; have_held = 0; guard_ahead = 1;
+        if (DEEP && pre) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = vn[i];
+        }
         cur_ord = nxt_ord; cur_r = nxt_r; cur_loaded = pre ? 1u : 0u;
     }
 }
@@ -883,7 +895,8 @@ hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const 
     if (t.teams) {
         if (t.log_t != 0 || t.ringslots == 0) return hipErrorInvalidValue;
         KernelTimer kt("ntt_fwd_team", (int)t.ringslots, st);
-        hipLaunchKernelGGL(ntt_fwd_team_kernel, dim3(grid), dim3(kTH), kLdsBytes, st, a);
+        if (t.deep) hipLaunchKernelGGL(ntt_fwd_team_kernel<true>, dim3(grid), dim3(kTH), kTeamDeepLdsBytes, st, a);
+        else hipLaunchKernelGGL(ntt_fwd_team_kernel<false>, dim3(grid), dim3(kTH), kLdsBytes, st, a);
         return hipGetLastError();
     }
     KernelTimer kt("ntt_fwd_persist", (int)t.log_t, st);
@@ -892,14 +905,16 @@ hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const 
     return hipGetLastError();
 }
 
-// workgroups the chip holds at once: 4 per CU (38.3 KiB of LDS each)
-hipError_t persist_grid(bool teams, unsigned *grid) {
+// workgroups a launch uses: as many as the chip holds at once (4 per CU, 38.3 KiB of LDS each); the teams' deep form: 2 per CU
+hipError_t persist_grid(const PersistTune &t, unsigned *grid) {
     int dev = 0, cus = 0, per = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess)
-        e = teams ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_team_kernel, kTH, kLdsBytes)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_persist_kernel<true>, kTH, kLdsBytes);
+    if (e == hipSuccess) {
+        if (t.teams && t.deep) per = 2;
+        else if (t.teams) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_team_kernel<false>, kTH, kLdsBytes);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_persist_kernel<true>, kTH, kLdsBytes);
+    }
     if (e != hipSuccess) return e;
     if (per < 1) per = 1;
     *grid = (unsigned)(cus * per);

@@ -10,6 +10,7 @@ struct PersistTune {
     uint32_t log_t = 0;       // tile = 2^log_t polynomials
     uint32_t lag = 1;         // chunks of S work a queue runs ahead of its C work (teams: start-up stagger between groups, x ~8k cycles)
     uint32_t ringslots = 4;   // tile-sized slots of the per-XCD ring holding the intermediate; 0: it lives in `out`
+    bool deep = false;        // teams: two workgroups per CU, 256 registers, the next part's coefficients prefetched into a second register set
     bool teams = false;       // variant B: one ticket = both halves of 1/16 of ONE polynomial, the sixteen holders meet in between (log_t = 0, lag unused)
 };
 
@@ -34,7 +35,7 @@ size_t persist_twc_entries(unsigned log_n);
 hipError_t launch_persist_twc(const Tw *tw, Tw *twc, u64 *twc8, unsigned log_n, hipStream_t st);
 size_t persist_ctl_bytes(const PersistTune &t, u64 batch, unsigned grid);
 size_t persist_ring_bytes(const PersistTune &t, unsigned grid);
-hipError_t persist_grid(bool teams, unsigned *grid);
+hipError_t persist_grid(const PersistTune &t, unsigned *grid);
 // ctl: persist_ctl_bytes(t, batch) bytes; ring: persist_ring_bytes(t) bytes (nullptr when t.ringslots == 0).
 // The error word is ctl[persist_ctl_err()], mirrored into *host_err: non-zero once the launch has finished = a bounded wait ran out.
 hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const u64 *twc8, const u64 *in, u64 *out, u64 batch,

@@ -90,6 +90,7 @@ int main() {
     CHECK(fhe_ntt_set_persist(1, 16, 1, 0) == FHE_OK && fhe_ntt_set_persist(2, 1, 1, 2) == FHE_OK);
     CHECK(fhe_ntt_set_persist(1, 3, 1, 0) == FHE_E_INVALID && fhe_ntt_set_persist(1, 16, 2, 2) == FHE_E_INVALID);
     CHECK(fhe_ntt_set_persist(2, 1, 0, 0) == FHE_E_INVALID && fhe_ntt_set_persist(9, 1, 1, 1) == FHE_E_INVALID);
+    CHECK(fhe_ntt_set_persist(3, 1, 1, 2) == FHE_OK && fhe_ntt_set_persist(3, 1, 1, 0) == FHE_E_INVALID);
     CHECK(fhe_ntt_set_persist(0, 0, 0, 0) == FHE_OK);
     CHECK(fhe_ntt_set_persist_grid(5) == FHE_OK && fhe_ntt_set_persist_grid(0) == FHE_OK);
     CHECK(fhe_ntt_persist_status() == FHE_OK);

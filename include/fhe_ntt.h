@@ -186,7 +186,9 @@ int fhe_ntt_set_batch_tile(size_t polys);
  *           the output buffer (ringslots = 0).
  *   mode 2  "B": teams — sixteen workgroups of one XCD take ONE polynomial through both halves and meet in between; the
  *           intermediate lives in a ring of `ringslots` (>= 1) polynomial slots per XCD and is read back out of the L2.
- * Environment: FHE_NTT_PERSIST=A:T,L,R or B:R.  fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if a
+ *   mode 3  "D": mode 2 at two workgroups per CU — 256 registers per lane, both twiddle tiles in LDS, the next part's
+ *           coefficients prefetched into a second register set; `lag` = start-up stagger between groups, as for mode 2.
+ * Environment: FHE_NTT_PERSIST=A:T,L,R, B:R[,s] or D:R[,s].  fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if a
  * bounded wait ran out, and clears the flag. */
 int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned lag, unsigned ringslots);
 int fhe_ntt_persist_status(void);

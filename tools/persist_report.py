@@ -22,7 +22,8 @@ head = {
          "# intermediate in the output buffer (R = 0) — i.e. through the Infinity Cache for tiles that fit it.  Settings: A:T,L,R.\n",
     "B": "# Variant B (ntt_fwd_team_kernel): teams of sixteen workgroups of one XCD take ONE polynomial through both halves; the\n"
          "# intermediate lives in a ring of R polynomial slots per group of sixteen and is read back a few microseconds after it\n"
-         "# was written.  Settings: B:R,s (s = start-up stagger between the groups of an XCD).\n",
+         "# was written.  Settings: B:R,s (s = start-up stagger between the groups of an XCD): four workgroups per CU; D:R,s: the\n"
+         "# same at TWO workgroups per CU (256 registers, resident twiddle tiles, the next part prefetched into a second register set).\n",
 }
 for v in ("A", "B"):
     with open(os.path.join("profiles", f"{tag}_persist_{v}.txt"), "w") as f:
@@ -34,14 +35,15 @@ for v in ("A", "B"):
                 "#   (A) ; half1 = first four stages incl. the wait for the coefficients; look-ahead = (A) next ticket's control words, (B, S\n"
                 "#   rows) THE TEAM WAIT; gather / round1 / epi-a / next-loads / half2-rest = second half: LDS gather, last four stages,\n"
                 "#   stores or canonical scatter, issuing the next item's loads, store loop; hand-over = ticket bookkeeping.\n\n")
-        for b in two_pass + [b for b in blocks if f" {v}:" in b[0]]:
+        for b in two_pass + [b for b in blocks if f" {v}:" in b[0] or (v == "B" and " D:" in b[0])]:
             f.write("\n".join(b) + "\n")
         f.write("\n# ---- HBM-side traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled on gfx950) and\n"
                 "# ---- instruction counters (SQ_*, GRBM_GUI_ACTIVE) per launch: tools/persist_one.py <setting> 8192 3 ----\n")
         keep, on = [], False
         for l in cnt.splitlines():
             if l.startswith("== "):
-                on = ("two-pass" in l) or (f" {v}:" in l) or l.startswith(f"== {v}:")
+                name = l[3:].split(" ")[0].rstrip(":")          # "two-pass", "A:64,1,0", "B:2,1", "D:1,1"
+                on = name == "two-pass" or name[0] == v or (v == "B" and name[0] == "D")
             if on:
                 keep.append(l[:400])
         f.write("\n".join(keep) + "\n")

@@ -120,9 +120,9 @@ python3 tools/pmc_isa.py $OUT/pmc3_b $OUT/config3_counters_b.json > /dev/null 2>
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt
 
 echo "[8] the one-launch transform (variants A and B): ms per step at three settings each, per-part profile, traffic, counters"; date
-PERSIST_PROFILE=1 timeout -k 10 900 python tools/persist_bench.py 65536 A:16,1,0 A:64,1,0 A:256,1,0 B:1,1 B:2,1 B:4,1 > $OUT/persist_bench.txt 2>&1 || tail -5 $OUT/persist_bench.txt
+PERSIST_PROFILE=1 timeout -k 10 900 python tools/persist_bench.py 65536 A:16,1,0 A:64,1,0 A:256,1,0 B:1,1 B:2,1 B:4,1 D:1,1 D:2,1 > $OUT/persist_bench.txt 2>&1 || tail -5 $OUT/persist_bench.txt
 grep -E "^time|parity:" $OUT/persist_bench.txt || true
-for cfg in two-pass A:64,1,0 B:2,1; do
+for cfg in two-pass A:64,1,0 B:2,1 D:1,1; do
   tag=$(echo $cfg | tr ':,' '__')
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pt_f_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_f_$tag.log 2>&1 || true
   timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pt_w_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_w_$tag.log 2>&1 || true

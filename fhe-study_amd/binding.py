@@ -462,7 +462,7 @@ def set_batch_tile(polys):
 def set_persist(mode, tile_polys=1, lag=1, ringslots=4):
     """The one-launch n = 2^16 forward transform (csrc/ntt_persist.hip): mode 0 off (two-pass kernels), "A" / 1 lagged
     tiles (tile_polys, lag, ringslots; ringslots 0 = through the output buffer), "B" / 2 teams (ringslots)."""
-    mode = {"A": 1, "B": 2, "D": 3, "a": 1, "b": 2, "d": 3}.get(mode, mode)
+    mode = {"A": 1, "B": 2, "D": 3, "E": 4, "a": 1, "b": 2, "d": 3, "e": 4}.get(mode, mode)
     _check(load_library().fhe_ntt_set_persist(int(mode), int(tile_polys), int(lag), int(ringslots)))
 
 

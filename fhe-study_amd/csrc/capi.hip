@@ -454,10 +454,11 @@ static bool persist_tune(fhe::PersistTune *t) {
         const char *e = getenv("FHE_NTT_PERSIST");       // "A:T,L,R" (tiles, lagged) or "B:R" (teams)
         unsigned T = 0, L = 1, R = 4;
         unsigned stagger = 0;
-        if (e && (e[0] == 'B' || e[0] == 'b' || e[0] == 'D' || e[0] == 'd') && e[1] == ':' && sscanf(e + 2, "%u,%u", &R, &stagger) >= 1 && R >= 1) {
+        if (e && strchr("BbDdEe", e[0]) && e[1] == ':' && sscanf(e + 2, "%u,%u", &R, &stagger) >= 1 && R >= ((e[0] == 'E' || e[0] == 'e') ? 2u : 1u)) {
             g_persist = fhe::PersistTune{};
             g_persist.log_t = 0; g_persist.lag = stagger; g_persist.ringslots = R; g_persist.teams = true;
             g_persist.deep = e[0] == 'D' || e[0] == 'd';      // "D:R,s": the teams at two workgroups per CU
+            g_persist.flow = e[0] == 'E' || e[0] == 'e';      // "E:R,s": ... that never wait (a FIFO of pending parts per workgroup)
             g_persist_on = true;
         } else if (e && (e[0] == 'A' || e[0] == 'a') && e[1] == ':' && sscanf(e + 2, "%u,%u,%u", &T, &L, &R) >= 1 && T > 0 &&
                    (T & (T - 1)) == 0 && T <= 1024 && (R == 0 || R >= L + 1)) {
@@ -471,7 +472,8 @@ static bool persist_tune(fhe::PersistTune *t) {
     return g_persist_on;
 }
 extern "C" int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned lag, unsigned ringslots) {
-    if (mode > 3) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: mode %u (0 off, 1 = A: lagged tiles, 2 = B: teams, 3 = B at two workgroups per CU)", mode);
+    if (mode > 4) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: mode %u (0 off, 1 = A: lagged tiles, 2 = B: teams, 3 = D: teams at two workgroups per CU, 4 = E: teams that never wait)", mode);
+    if (mode == 4 && ringslots < 2) return fail(FHE_E_INVALID, "fhe_ntt_set_persist: mode 4 needs at least two ring slots per group");
     if (mode == 1 && (tile_polys == 0 || (tile_polys & (tile_polys - 1)) != 0 || tile_polys > 1024))
         return fail(FHE_E_INVALID, "fhe_ntt_set_persist: tile of %u polynomials (need a power of two <= 1024)", tile_polys);
     if (mode == 1 && ringslots && ringslots < lag + 1)
@@ -487,6 +489,7 @@ extern "C" int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned 
     } else if (mode >= 2) {
         g_persist.log_t = 0; g_persist.lag = lag; g_persist.ringslots = ringslots; g_persist.teams = true;   // lag: start-up stagger
         g_persist.deep = mode == 3;
+        g_persist.flow = mode == 4;
     }
     return FHE_OK;
 }
@@ -559,7 +562,7 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
     uint32_t *herr = nullptr;
     if ((rc = persist_host_err(&herr)) != FHE_OK) return rc;
     static unsigned grids[3] = {0, 0, 0};
-    unsigned &grid = grids[tune.teams ? (tune.deep ? 2 : 1) : 0];
+    unsigned &grid = grids[tune.teams ? ((tune.deep || tune.flow) ? 2 : 1) : 0];
     if (!grid) {
         unsigned g = 0;
         HIP_TRY(fhe::persist_grid(tune, &g));

@@ -81,7 +81,7 @@ __device__ __forceinline__ void round_fwd_pm_f(u64 (&v)[16], F twf, const Mod &m
 
 // what lane 0 hands the workgroup for a ticket: one record of eight words in LDS (two records: the current ticket when it
 // has to be resolved at the top of an iteration, and the NEXT ticket, resolved while the current item computes)
-enum : int { kCtlPhase = 0, kCtlOrd = 1, kCtlR = 2, kCtlBind = 3, kCtlStatus = 4, kCtlRes = 5, kCtlWords = 8 };
+enum : int { kCtlPhase = 0, kCtlOrd = 1, kCtlR = 2, kCtlBind = 3, kCtlStatus = 4, kCtlRes = 5, kCtlGuard = 6, kCtlWords = 8 };
 
 struct Desc {          // a ticket as every lane knows it (wave-uniform)
     u32 phase, ord, r;
@@ -831,6 +831,351 @@ __global__ __launch_bounds__(kTH, (DEEP ? 2 : 4)) void ntt_fwd_team_kernel(Persi
     }
 }
 
+// =====================================================================================================================
+// FLOW (variant E): the teams again, two workgroups per CU, but nobody waits in the normal course of things.
+//
+// A workgroup keeps a FIFO of the parts whose strided half it has run and whose contiguous half is still to come, and runs
+// one half per iteration: the contiguous half of its OLDEST pending part when that polynomial's sixteen strided halves are
+// all in (and it is at least one strided half ahead, or has no strided work left), a strided half of the next ticket
+// otherwise.  In steady state that is S(j+1), C(j), S(j+2), C(j+1), ...: the team of polynomial j "meets" while its members
+// run their strided half of j+1, so the meeting costs nothing, and since the next half is known one half ahead its
+// coefficients — from HBM for an S half, from the ring in the L2 for a C half — its 15 register twiddles and its twiddle tile
+// are loaded while the current half computes.  The same rule is the helping rule: a workgroup that finds its oldest part's
+// polynomial incomplete simply runs another strided half (all sixteen of a polynomial, if it is alone on its queue), bounded by
+// the ring (a slot is rewritten only when all sixteen parts of its previous tenant have been read).  It waits — bounded — only
+// when it has no strided work left and its oldest part is not ready; before it waits it signals what it owes.
+// Per XCD: 64 workgroups = 4 groups, about 1.5 ring slots per group between "written" and "read" (2 - 3 MiB of a 4 MiB L2).
+// =====================================================================================================================
+constexpr u32 kFlowFifo = 64;                   // pending parts a workgroup can hold (ring slots x 16 at most are ever needed)
+constexpr size_t kFlowLdsBytes = kTileBytes + 2 * 256 * sizeof(Tw) + 64 + kFlowFifo * 4 + kProfWords * 8;
+
+__global__ __launch_bounds__(kTH, 2) void ntt_fwd_flow_kernel(PersistArgs a) {
+    using S = StridedCfg<8, kCW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *lds = reinterpret_cast<u64 *>(smem_raw);
+    Tw *ltw = reinterpret_cast<Tw *>(smem_raw + kTileBytes);               // a C half's stage 8..11 tile [row][15]
+    Tw *stw = ltw + 256;                                                    // the strided stages' tile
+    u32 *ctrl = reinterpret_cast<u32 *>(smem_raw + kTileBytes + 2 * 256 * sizeof(Tw));
+    u32 *fifo = ctrl + 16;                                                  // pending parts: (queue << 24) | (ordinal << 4) | part
+    u64 *prof = reinterpret_cast<u64 *>(smem_raw + kTileBytes + 2 * 256 * sizeof(Tw) + 64 + kFlowFifo * 4);
+    const u32 tid0 = threadIdx.x;
+    const u32 xq = xcc_id();
+    const Mod &m = a.mod;
+    const u32 maxord = a.maxord, R = a.ringslots, G = a.groups, nq = kPersistQueues * G;
+    constexpr u32 kParts = 16u;
+    u32 *const ctl = a.ctl;
+
+    const bool profiling = a.prof != nullptr;
+    if (profiling && tid0 == 0) {
+        for (u32 i = 0; i < kProfWords; i++) prof[i] = 0;
+        prof[kProfWords - 1] = (u64)clock64();
+    }
+    auto tick = [&](u32 tid, u32 phase, u32 part) {
+        if (profiling && tid == 0) {
+            const u64 now = (u64)clock64();
+            prof[phase * 12u + part] += now - prof[kProfWords - 1];
+            prof[kProfWords - 1] = now;
+        }
+    };
+    auto fail = [&](u32 status) {
+        atomicOr(ctl + team_ctl_err(nq), status);
+        __hip_atomic_fetch_or(a.host_err, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    // a part = (queue, ordinal, part of 16); everything about it follows from that
+    auto q_of = [](u32 e) -> u32 { return e >> 24; };
+    auto ord_of = [](u32 e) -> u32 { return (e >> 4) & 0xfffffu; };
+    auto r_of = [](u32 e) -> u32 { return e & 15u; };
+    auto poly_of = [&](u32 q, u32 ord) -> u64 { return team_poly(ord, q / G, q % G, G); };
+    auto slot_of = [&](u32 q, u32 ord) -> u64 * { return a.ring + (((u64)q * R + ord % R) << 16); };
+    auto issue_s_loads = [&](u32 e, u32 tid, u64 (&x)[16]) {
+        const u32 c = tid % kCW, tf = tid / kCW;
+        const u64 *__restrict__ pin = a.in + (poly_of(q_of(e), ord_of(e)) << 16) + r_of(e) * kCW;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = ld_at<u64>(pin, ((field_of<S::A0>(tf, k) << 8) + c) * 8u);
+    };
+    auto issue_c_loads = [&](u32 e, u32 tid, u64 (&x)[16], u64 (&tcx)[15], u64 &te_w, u64 &te_p) {
+        const u32 u = tid >> 4, tfc = tid & 15u, r = r_of(e), blk = r * kUnits + u;
+        {   // this lane's entry of the stage 8..11 tile: roots[((256 + 16 r + row) << i) + g] at [row][2^i - 1 + g]
+            const u32 ee = tid < 240u ? tid : 239u;
+            const u32 bl = ee / 15u, j = ee - bl * 15u;
+            const u32 i = 31u - (u32)__builtin_clz(j + 1u), g = j + 1u - (1u << i);
+            const Tw *tp = a.tw + (((256u + r * kUnits + bl) << i) + g);
+            te_w = tp->w;
+            te_p = tp->wp;
+        }
+        const u64 *__restrict__ src = slot_of(q_of(e), ord_of(e)) + blk * 256u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = ld_mid(src, field_of<4>(tfc, k) * 8u);
+        const u64 *__restrict__ tcp = a.twc8 + (size_t)blk * 240u + tfc;
+#pragma unroll
+        for (int j = 0; j < 15; j++) tcx[j] = tcp[j * 16];
+    };
+
+    // ---- join a group of this XCD, start staggered ----
+    u32 grp = 0;
+    if (tid0 == 0) {
+        const u32 mnum = ctl_add(ctl + team_ctl_members(nq, xq), 1u);
+        ctrl[kCtlBind] = (mnum / kParts) % G;
+    }
+    stw[tid0] = a.tw[tid0];
+    __syncthreads();
+    grp = __builtin_amdgcn_readfirstlane(ctrl[kCtlBind]);
+    if (tid0 == 0)
+        for (u32 i = 0; i < grp * a.lag; i++) __builtin_amdgcn_s_sleep(127);
+    u32 qx = xq * G + grp, dry = 0;
+
+    // the next S ticket: drawn by lane 0 (synchronously here; one S half ahead in the loop), or the next queue's when this
+    // one has run dry; s_valid = 0: no strided work left on this XCD
+    u32 s_e = 0, s_valid = 0;
+    auto draw_sync = [&](u32 tid) {           // uniform result through LDS; moves on to the next group's queue when one is dry
+        for (;;) {
+            if (tid == 0) ctrl[kCtlOrd] = ctl_add(ctl + team_ctl_head(qx), 1u);
+            __syncthreads();
+            const u32 t = __builtin_amdgcn_readfirstlane(ctrl[kCtlOrd]);
+            __syncthreads();
+            if (poly_of(qx, t >> 4) < a.batch) { s_e = (qx << 24) | ((t >> 4) << 4) | (t & 15u); s_valid = 1; return; }
+            if (++dry >= G) { s_valid = 0; return; }
+            grp = grp + 1u == G ? 0u : grp + 1u;
+            qx = xq * G + grp;
+        }
+    };
+    draw_sync(tid0);
+
+    u32 pend_head = 0, pend_cnt = 0;                       // FIFO of parts whose C half is to come (uniform)
+    u32 s_loaded = 0, c_loaded = 0;                        // vn / vc hold the next S half's / the oldest pending part's coefficients
+    bool owes = false;                                     // the previous S half's completion is still to be signalled
+    u32 owed_e = 0;
+    u64 v[16], vn[16], vc[16], tc[15];
+    u64 te_w = 0, te_p = 0;
+    u32 k_next = 0;                                        // lane 0: the S ticket after the one at hand, in flight
+
+    auto settle = [&](u32 tid) {
+        if (owes) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) ctl_add(ctl + team_ctl_sdone(nq, q_of(owed_e), ord_of(owed_e), maxord), 1u);
+            owes = false;
+        }
+    };
+
+    // lane 0: has the ring slot the next strided half (s_e) writes been read by all sixteen parts of its previous tenant?
+    // (issued BEFORE the coefficient loads of that half and consumed at the end of the current one: the counter that orders
+    // a wave's loads is in order, so waiting for this word right away would wait for everything issued after it as well)
+    auto guard_of_next = [&]() -> u32 {
+        if (!s_valid || ord_of(s_e) < R) return kParts;
+        return ctl_load(ctl + team_ctl_cdone(nq, q_of(s_e), ord_of(s_e) - R, maxord));
+    };
+    if (tid0 == 0) ctrl[kCtlGuard] = 1u;
+    bool tile_owed = false;                                // vc's twiddle tile entry (te_w, te_p) is still to be written to ltw
+
+    for (;;) {
+        u32 tid = tid0;
+        asm volatile("" : "+v"(tid));
+        tick(tid, 0u, 6u);
+        __syncthreads();                                   // the LDS tile is free; a prefetched C half's twiddle tile is in place
+        tick(tid, 0u, 0u);
+        const u32 oldest = pend_cnt ? __builtin_amdgcn_readfirstlane(fifo[pend_head]) : 0u;
+        const bool guard_ok = __builtin_amdgcn_readfirstlane(ctrl[kCtlGuard]) != 0u;   // the ring slot of s_e is free (seen one half ago)
+        const bool can_s = s_valid && pend_cnt < kFlowFifo;
+        // ---------------- which half now? ----------------
+        u32 act;                                           // 0 = S(s_e), 1 = C(oldest), 2 = leave
+        if (c_loaded && (pend_cnt >= 2 || !(can_s && guard_ok))) act = 1;    // stay one strided half ahead when that is possible
+        else if (can_s && s_loaded && guard_ok) act = 0;
+        else if (c_loaded) act = 1;
+        else {
+            // nothing was decided ahead, or the ring slot the next strided half writes is still being read.
+            // Look at both things this workgroup could do, and wait — bounded — only when it can do neither.
+            settle(tid);                                   // what this workgroup owes may be what others (or it) wait for
+            if (tid == 0) {
+                const u32 *sd = pend_cnt ? ctl + team_ctl_sdone(nq, q_of(oldest), ord_of(oldest), maxord) : nullptr;
+                const u32 *gd = can_s && ord_of(s_e) >= R ? ctl + team_ctl_cdone(nq, q_of(s_e), ord_of(s_e) - R, maxord) : nullptr;
+                u32 res = 0, st = 0;
+                if (sd || can_s) {
+                    u32 it = 0;
+                    for (; it < kSpinCap; it++) {
+                        if (sd && ctl_load(sd) >= kParts) res |= 1u;
+                        if (can_s && (!gd || ctl_load(gd) >= kParts)) res |= 2u;
+                        if (res) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (!res) { st = sd ? kPersistErrSdone : kPersistErrCdone; fail(st); }
+                }
+                ctrl[kCtlRes] = res; ctrl[kCtlStatus] = st;
+            }
+            __syncthreads();
+            const u32 res = __builtin_amdgcn_readfirstlane(ctrl[kCtlRes]);
+            if (__builtin_amdgcn_readfirstlane(ctrl[kCtlStatus])) return;
+            __syncthreads();
+            if (profiling && tid == 0) {                   // (diagnostics, reported in columns the halves do not use)
+                prof[11] += 1;                             // S row, last column: how often nothing was decided ahead
+                prof[10] += s_loaded && !guard_ok;         // S row, "next-loads": ... because the ring slot was still being read
+                prof[13] += !s_loaded;                     // C row, "poll": ... because no strided half was fetched
+                prof[18] += (res & 1u) && (pend_cnt >= 2 || !(res & 2u));   // C row, "hand-over": ... and a C half followed
+                prof[22] += res == 0u;                     // C row, "next-loads": ... and there was nothing left to do
+            }
+            if ((res & 1u) && (pend_cnt >= 2 || !(res & 2u))) act = 1;
+            else if (res & 2u) act = 0;
+            else act = 2;                                  // nothing pending, no strided work left on this XCD
+        }
+        if (act == 2) {                                    // no strided work left on this XCD, nothing pending
+            settle(tid);
+            if (profiling && tid == 0)
+                for (u32 i = 0; i < kProfWords - 1; i++) atomicAdd((unsigned long long *)a.prof + i, (unsigned long long)prof[i]);
+            if (tid == 0 && ctl_add(ctl + team_ctl_left(nq), 1u) + 1u == gridDim.x) {
+                u32 bad = 0;                               // the last workgroup out: every queue's tickets must have been drawn
+                for (u32 q = 0; q < nq; q++)
+                    if ((u64)ctl_load(ctl + team_ctl_head(q)) < team_queue_polys(a.batch, q / G, q % G, G) * kParts) bad = 1;
+                if (bad) fail(kPersistErrQueue);
+            }
+            return;
+        }
+        tick(tid, 0u, 1u);
+
+        if (act == 0) {
+            // ================= S half of s_e =================
+            const u32 e = s_e, eq = q_of(e), eo = ord_of(e), er = r_of(e);
+            const u32 c = tid % kCW, tfs = tid / kCW;
+            if (s_loaded) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = vn[i];
+            } else {
+                issue_s_loads(e, tid, v);
+            }
+            s_loaded = 0;
+            if (profiling && tid == 0) prof[24] += 1;
+            u32 pf_meet = 0;
+            if (tid == 0) {                                // control words, in flight while stages 0..3 compute
+                k_next = ctl_add(ctl + team_ctl_head(qx), 1u);
+                if (pend_cnt && !c_loaded) pf_meet = ctl_load(ctl + team_ctl_sdone(nq, q_of(oldest), ord_of(oldest), maxord));
+            }
+            round_fwd_pm_f<S::R0, kPmOne, 4>(v, [&](int i, int g) { return stw[(1 << i) + g]; }, m);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[field_of<S::A0>(tfs, k) * kSRow + c] = v[k];
+            tick(tid, 0u, 2u);
+            if (tid == 0) {
+                ctrl[kCtlOrd] = k_next;                    // the next S ticket of this queue (validity: every lane computes it)
+                ctrl[kCtlRes] = pend_cnt && !c_loaded && pf_meet >= kParts;
+                fifo[(pend_head + pend_cnt) % kFlowFifo] = e;
+            }
+            if (owes) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tick(tid, 0u, 3u);
+            __syncthreads();
+            tick(tid, 0u, 4u);
+            if (owes && tid == 0) ctl_add(ctl + team_ctl_sdone(nq, q_of(owed_e), ord_of(owed_e), maxord), 1u);
+            owes = true; owed_e = e;
+            const u32 t_next = __builtin_amdgcn_readfirstlane(ctrl[kCtlOrd]);
+            const u32 meet = __builtin_amdgcn_readfirstlane(ctrl[kCtlRes]);
+            pend_cnt++;
+            // the next S ticket: this queue's, or — once, when this one has run dry — the next group's (drawn synchronously)
+            if (poly_of(qx, t_next >> 4) < a.batch) { s_e = (qx << 24) | ((t_next >> 4) << 4) | (t_next & 15u); s_valid = 1; }
+            else if (++dry >= G) s_valid = 0;
+            else { grp = grp + 1u == G ? 0u : grp + 1u; qx = xq * G + grp; __syncthreads(); draw_sync(tid); }
+            // everything the next two halves need starts now: the ring guard of the next S half, the oldest pending part's
+            // coefficients and twiddles if its polynomial is complete, the next S half's coefficients
+            u32 pf_guard = kParts;
+            if (tid == 0) pf_guard = guard_of_next();
+            if (meet) { issue_c_loads(oldest, tid, vc, tc, te_w, te_p); c_loaded = 1; tile_owed = true; }
+            if (s_valid && pend_cnt < kFlowFifo) { issue_s_loads(s_e, tid, vn); s_loaded = 1; }
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[field_of<S::a_of(1)>(tfs, k) * kSRow + c];
+            tick(tid, 0u, 7u);
+            {
+                constexpr int P1 = pm_fwd_bound_out(S::R0, kPmOne);
+                const u32 T1 = 16u + tfs;
+                round_fwd_pm_f<4, P1, 4>(v, [&](int i, int g) { return stw[(T1 << i) + g]; }, m);
+            }
+            tick(tid, 0u, 8u);
+            {
+                u64 *__restrict__ pout = slot_of(eq, eo) + er * kCW;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    st_c<u64>(pout, ((field_of<S::a_of(1)>(tfs, k) << 8) + c) * 8u, v[k]);     // plain: stays in this XCD's L2
+                    if ((k & 3) == 3) FHE_SCHED_FENCE();
+                }
+            }
+            tick(tid, 0u, 9u);
+            if (tile_owed) { ltw[tid] = Tw{te_w, te_p}; tile_owed = false; }   // read after the barrier at the top (no S half reads this tile)
+            if (tid == 0) ctrl[kCtlGuard] = pf_guard >= kParts;
+            tick(tid, 0u, 5u);
+        } else {
+            // ================= C half of the oldest pending part =================
+            const u32 e = oldest, eq = q_of(e), eo = ord_of(e), er = r_of(e);
+            const u32 u = tid >> 4, tfc = tid & 15u;
+            tick(tid, 1u, 0u);
+            if (!c_loaded) {                               // decided at the top: nothing was fetched ahead
+                issue_c_loads(e, tid, vc, tc, te_w, te_p);
+                ltw[tid] = Tw{te_w, te_p};
+                tile_owed = false;
+                __syncthreads();
+            }
+            c_loaded = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = vc[i];
+            u64 tcc[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) tcc[i] = tc[i];
+            if (profiling && tid == 0) prof[25] += 1;
+            // control words, in flight while stages 8..11 compute: the ring guard of the next S half (it may have failed
+            // when it was last looked at), and whether the NEXT pending part's polynomial is complete
+            const u32 second = pend_cnt >= 2 ? __builtin_amdgcn_readfirstlane(fifo[(pend_head + 1u) % kFlowFifo]) : 0u;
+            u32 pf_guard = kParts, pf_meet = 0;
+            if (tid == 0) {
+                pf_guard = guard_of_next();
+                if (pend_cnt >= 2) pf_meet = ctl_load(ctl + team_ctl_sdone(nq, q_of(second), ord_of(second), maxord));
+            }
+            {
+                const Tw *tw0 = ltw + u * 15u;
+                round_fwd_pm_f<4, kPmPassBound, 4>(v, [&](int i, int g) { return tw0[(1 << i) - 1 + g]; }, m);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[pad16(u * 256u + field_of<4>(tfc, k))] = v[k];
+            tick(tid, 1u, 2u);
+            if (tid == 0) ctrl[kCtlRes] = pend_cnt >= 2 && pf_meet >= kParts;
+            if (owes) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tick(tid, 1u, 3u);
+            __syncthreads();
+            tick(tid, 1u, 4u);
+            if (tid == 0) {
+                if (owes) ctl_add(ctl + team_ctl_sdone(nq, q_of(owed_e), ord_of(owed_e), maxord), 1u);
+                ctl_add(ctl + team_ctl_cdone(nq, eq, eo, maxord), 1u);    // this part has read the slot
+            }
+            owes = false;
+            pend_head = (pend_head + 1u) % kFlowFifo;
+            pend_cnt--;
+            if (__builtin_amdgcn_readfirstlane(ctrl[kCtlRes])) { issue_c_loads(second, tid, vc, tc, te_w, te_p); c_loaded = 1; tile_owed = true; }
+            if (!s_loaded && s_valid && pend_cnt < kFlowFifo) { issue_s_loads(s_e, tid, vn); s_loaded = 1; }
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[pad16(u * 256u + field_of<0>(tfc, k))];
+            tick(tid, 1u, 7u);
+            {
+                constexpr int B1 = pm_fwd_bound_out(4, kPmPassBound);
+                round_fwd_pm_f<4, B1, 0>(v, [&](int i, int g) { const u64 w = tcc[(1 << i) - 1 + g]; return Tw{w, pm_shift32(w, m)}; }, m);
+            }
+            tick(tid, 1u, 8u);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                lds[pad16(u * 256u + field_of<0>(tfc, k))] = pm_canon(v[k], m);
+                if ((k & 3) == 3) FHE_SCHED_FENCE();
+            }
+            tick(tid, 1u, 9u);
+            __syncthreads();
+            tick(tid, 1u, 11u);
+            {
+                u64 *__restrict__ pout = a.out + (poly_of(eq, eo) << 16) + (u64)er * kUnits * 256u;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const u32 ee = i * kTH + tid;
+                    st_at(pout, ee * 8u, lds[pad16(ee)]);  // rows 16 r .. 16 r + 15 are contiguous: 32 KiB
+                    if ((i & 3) == 3) FHE_SCHED_FENCE();
+                }
+            }
+            if (tile_owed) { ltw[tid] = Tw{te_w, te_p}; tile_owed = false; }
+            if (tid == 0) ctrl[kCtlGuard] = pf_guard >= kParts;
+            tick(tid, 1u, 5u);
+        }
+    }
+}
+
 // twc[blk][2^i - 1 + g][tf] = tw[((2^(s0+4) + 16 blk + tf) << i) + g]  (the last four stages' twiddles of 256-blocks, in
 // the order the lanes of a unit read them: 16 lanes = 256 contiguous bytes)
 __global__ __launch_bounds__(256) void persist_twc_kernel(const Tw *__restrict__ tw, Tw *__restrict__ twc, u32 s0) {
@@ -892,6 +1237,12 @@ hipError_t launch_ntt_forward_persist(const DevicePlan &p, const Tw *twc, const 
     a.ctl = ctl; a.host_err = host_err; a.prof = prof;
     hipError_t e = hipMemsetAsync(ctl, 0, persist_ctl_bytes(t, batch, grid), st);
     if (e != hipSuccess) return e;
+    if (t.teams && t.flow) {
+        if (t.log_t != 0 || t.ringslots < 2) return hipErrorInvalidValue;
+        KernelTimer kt("ntt_fwd_flow", (int)t.ringslots, st);
+        hipLaunchKernelGGL(ntt_fwd_flow_kernel, dim3(grid), dim3(kTH), kFlowLdsBytes, st, a);
+        return hipGetLastError();
+    }
     if (t.teams) {
         if (t.log_t != 0 || t.ringslots == 0) return hipErrorInvalidValue;
         KernelTimer kt("ntt_fwd_team", (int)t.ringslots, st);
@@ -911,7 +1262,7 @@ hipError_t persist_grid(const PersistTune &t, unsigned *grid) {
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e == hipSuccess) {
-        if (t.teams && t.deep) per = 2;
+        if (t.teams && (t.deep || t.flow)) per = 2;
         else if (t.teams) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_team_kernel<false>, kTH, kLdsBytes);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, ntt_fwd_persist_kernel<true>, kTH, kLdsBytes);
     }

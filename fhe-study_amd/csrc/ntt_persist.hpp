@@ -10,6 +10,7 @@ struct PersistTune {
     uint32_t log_t = 0;       // tile = 2^log_t polynomials
     uint32_t lag = 1;         // chunks of S work a queue runs ahead of its C work (teams: start-up stagger between groups, x ~8k cycles)
     uint32_t ringslots = 4;   // tile-sized slots of the per-XCD ring holding the intermediate; 0: it lives in `out`
+    bool flow = false;        // teams, two workgroups per CU, a FIFO of pending parts per workgroup: one half per iteration, nobody waits (variant E)
     bool deep = false;        // teams: two workgroups per CU, 256 registers, the next part's coefficients prefetched into a second register set
     bool teams = false;       // variant B: one ticket = both halves of 1/16 of ONE polynomial, the sixteen holders meet in between (log_t = 0, lag unused)
 };

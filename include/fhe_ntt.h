@@ -188,7 +188,11 @@ int fhe_ntt_set_batch_tile(size_t polys);
  *           intermediate lives in a ring of `ringslots` (>= 1) polynomial slots per XCD and is read back out of the L2.
  *   mode 3  "D": mode 2 at two workgroups per CU — 256 registers per lane, both twiddle tiles in LDS, the next part's
  *           coefficients prefetched into a second register set; `lag` = start-up stagger between groups, as for mode 2.
- * Environment: FHE_NTT_PERSIST=A:T,L,R, B:R[,s] or D:R[,s].  fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if a
+ *   mode 4  "E": the teams without the meeting, two workgroups per CU: a workgroup keeps a FIFO of the parts whose
+ *           contiguous half is still to come and runs ONE half per iteration — the contiguous half of its oldest part once
+ *           that polynomial's sixteen strided halves are in, a strided half of the next ticket otherwise — with the
+ *           coefficients of the next two halves in flight; it waits (bounded) only when it can do neither.  ringslots >= 2.
+ * Environment: FHE_NTT_PERSIST=A:T,L,R, B:R[,s], D:R[,s] or E:R[,s].  fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if a
  * bounded wait ran out, and clears the flag. */
 int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned lag, unsigned ringslots);
 int fhe_ntt_persist_status(void);

@@ -1,7 +1,8 @@
 """Round 4: the one-launch n = 2^16 forward transform (fhe-study_amd/csrc/ntt_persist.hip) — persistent workgroups, one
 ticket queue per XCD, in two forms: "A" (tiles, the strided stages lagging ahead of the contiguous ones) and "B" (teams of
 sixteen workgroups taking one polynomial through both halves, the intermediate read back out of the L2; "D": the same at
-two workgroups per CU with 256 registers and the next part prefetched).  NTT::ntt is
+two workgroups per CU with 256 registers and the next part prefetched; "E": the teams without the meeting — a workgroup
+keeps a FIFO of the parts whose contiguous half is still to come and runs whichever half is ready).  NTT::ntt is
 arith/src/ntt.rs:44-73; the words must be the two-pass kernels' and the oracle's, whatever the settings, the batch shape
 and the number of workgroups the launch gets."""
 import numpy as np
@@ -11,7 +12,8 @@ from conftest import Q61
 
 N = 1 << 16
 SETTINGS = [("A", 1, 4, 6), ("A", 4, 2, 4), ("A", 16, 1, 0), ("A", 16, 1, 3), ("A", 64, 0, 0), ("A", 256, 1, 0),
-            ("B", 1, 0, 1), ("B", 1, 1, 2), ("B", 1, 2, 4), ("D", 1, 1, 1), ("D", 1, 0, 2)]
+            ("B", 1, 0, 1), ("B", 1, 1, 2), ("B", 1, 2, 4), ("D", 1, 1, 1), ("D", 1, 0, 2), ("E", 1, 1, 2), ("E", 1, 0, 3),
+            ("E", 1, 1, 6)]
 
 
 @pytest.fixture()
@@ -67,9 +69,9 @@ def test_no_workgroup_needs_another_to_be_resident(pkg, oracle, need_gpu, persis
     pkg.binding.set_persist(0)
     ref = plan.forward(a)
     pkg.binding.set_persist_grid(grid)
-    for setting in (("A", 4, 1, 3), ("A", 16, 1, 0), ("B", 1, 1, 2), ("D", 1, 1, 1)):
+    for setting in (("A", 4, 1, 3), ("A", 16, 1, 0), ("B", 1, 1, 2), ("D", 1, 1, 1), ("E", 1, 1, 2), ("E", 1, 1, 4)):
         pkg.binding.set_persist(*setting)
-        if setting[0] in "BD" and grid < 8:
+        if setting[0] in "BDE" and grid < 8:
             with pytest.raises(Exception) as e:     # (FheError: the package may be loaded under two module names in one session)
                 plan.forward(a)
             assert type(e.value).__name__ == "FheError" and e.value.code == pkg.binding.FHE_E_HIP and "never served" in str(e.value)
@@ -93,7 +95,7 @@ def test_persistent_forward_on_device_buffers_in_place_and_repeated(pkg, oracle,
     B.set_persist(0)
     plan.forward_dev(x.data_ptr(), ref.data_ptr(), batch, st)
     torch.cuda.synchronize()
-    for setting in (("A", 16, 1, 0), ("A", 2, 3, 5), ("B", 1, 1, 2), ("D", 1, 1, 2)):
+    for setting in (("A", 16, 1, 0), ("A", 2, 3, 5), ("B", 1, 1, 2), ("D", 1, 1, 2), ("E", 1, 1, 3)):
         B.set_persist(*setting)
         y = torch.zeros_like(x)
         for _ in range(3):
@@ -118,7 +120,7 @@ def test_other_plans_keep_the_two_pass_kernels(pkg, oracle, need_gpu, persist_of
 
 def test_set_persist_rejects_what_the_kernels_cannot_run(pkg):
     B = pkg.binding
-    for bad in ((1, 3, 1, 0), (1, 2048, 1, 0), (1, 16, 2, 2), (2, 1, 0, 0), (3, 1, 1, 0), (4, 1, 1, 1)):
+    for bad in ((1, 3, 1, 0), (1, 2048, 1, 0), (1, 16, 2, 2), (2, 1, 0, 0), (3, 1, 1, 0), (4, 1, 1, 1), (5, 1, 1, 2)):
         with pytest.raises(Exception) as e:
             B.set_persist(*bad)
         assert type(e.value).__name__ == "FheError" and e.value.code == B.FHE_E_INVALID

@@ -12,11 +12,11 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 def parse(a):
     kind, rest = a.split(":")
     vals = [int(v) for v in rest.split(",")]
-    return (1, vals[0], vals[1], vals[2]) if kind.upper() == "A" else (3 if kind.upper() == "D" else 2, 1, vals[1] if len(vals) > 1 else 0, vals[0])
+    return (1, vals[0], vals[1], vals[2]) if kind.upper() == "A" else ({"B": 2, "D": 3, "E": 4}[kind.upper()], 1, vals[1] if len(vals) > 1 else 0, vals[0])
 
 
 cfgs = [parse(a) for a in sys.argv[2:]] or [parse("B:2,1"), parse("B:4,1"), parse("A:16,1,0"), parse("A:64,1,0")]
-name = lambda c: f"A:{c[1]},{c[2]},{c[3]}" if c[0] == 1 else f"B:{c[3]},{c[2]}" if c[0] == 2 else f"D:{c[3]},{c[2]}" if c[0] == 3 else "two-pass"
+name = lambda c: f"A:{c[1]},{c[2]},{c[3]}" if c[0] == 1 else f"B:{c[3]},{c[2]}" if c[0] == 2 else f"D:{c[3]},{c[2]}" if c[0] == 3 else f"E:{c[3]},{c[2]}" if c[0] == 4 else "two-pass"
 q, n = pkg.Q61, 1 << 16
 plan = pkg.Plan(q, n)
 st = torch.cuda.current_stream().cuda_stream

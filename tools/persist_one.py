@@ -16,7 +16,7 @@ st = torch.cuda.current_stream().cuda_stream
 if cfg != "two-pass":
     kind, rest = cfg.split(":")
     v = [int(t) for t in rest.split(",")]
-    B.set_persist(1, v[0], v[1], v[2]) if kind.upper() == "A" else B.set_persist(3 if kind.upper() == "D" else 2, 1, v[1] if len(v) > 1 else 0, v[0])
+    B.set_persist(1, v[0], v[1], v[2]) if kind.upper() == "A" else B.set_persist({"B": 2, "D": 3, "E": 4}[kind.upper()], 1, v[1] if len(v) > 1 else 0, v[0])
 x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
 y = torch.empty_like(x)
 B.fill_synthetic_dev(q, 1, 0, batch * n, x.data_ptr(), st)

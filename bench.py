@@ -209,6 +209,9 @@ def workload_ntt(args, pkg, torch, dev, st, rank, world, inverse_too):
                 f"variant of BASELINE.json configs[4], global batch {total}), device-resident in->out")
     metric = ("NTT/s (N=4096, 64-bit q, forward+inverse) per node; achieved HBM GB/s vs roofline" if inverse_too
               else "NTT/s (N=2^16, 64-bit q) per node; achieved HBM GB/s vs roofline")
+    if args.q is not None and q != Q61 and not small_q:
+        # a modulus given with --q: the shape is the config's, the modulus (and with it the arithmetic the kernels run) is not
+        name += f" — q given with --q ({pkg.Plan.ARITH_NAMES.get(arith, arith)} arithmetic), NOT BASELINE.json's modulus 2^61 - 2^21 + 1"
     if small_q:
         metric = (f"NTT/s (N=2^{log_n}, q={q}: a {q.bit_length()}-bit modulus given with --q, NOT BASELINE.json's 64-bit q) per node; "
                   "achieved HBM GB/s vs roofline")

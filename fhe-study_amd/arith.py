@@ -144,3 +144,14 @@ def pm_params(q):
         return None
     return {"k": k, "delta": delta, "c2": 2 * delta, "sh": k - 31, "mask": (1 << (k - 31)) - 1,
             "rsh": k - 32, "rmask": (1 << (k - 32)) - 1}
+
+
+def mg_params(q):
+    """The word-Montgomery form the engine detects at plan time (csrc/capi.hip: build_plan, csrc/zq_device.hpp: ct_bfly_mg):
+    q = qh 2^32 + 1 below 2^61 (and not pseudo-Mersenne, which cannot coincide).  Such a modulus runs its FORWARD transforms
+    on tables {w 2^32 mod q, w 2^64 mod q}: q^-1 = 1 (mod 2^32), so a Montgomery word step needs no multiplication by it.
+    Returns the kernels' constant (2^32 - qh), or None.  Host-side restatement for the tests; the library decides on its own."""
+    q = int(q)
+    if (q & 0xffffffff) != 1 or (q >> 32) == 0 or (q >> 61) != 0 or pm_params(q) is not None:
+        return None
+    return {"qh": q >> 32, "nqh": (1 << 32) - (q >> 32)}

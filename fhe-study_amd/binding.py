@@ -269,7 +269,7 @@ class Plan:
         self.handle = h
         self.q, self.n = int(q), int(n)
 
-    ARITH_NAMES = {0: "shoup62", 1: "shoup61", 2: "pseudo-mersenne", 3: "word32", 4: "strict63"}
+    ARITH_NAMES = {0: "shoup62", 1: "shoup61", 2: "pseudo-mersenne", 3: "word32", 4: "strict63", 5: "montgomery"}
 
     def arithmetic(self):
         """fhe_ntt_plan_arithmetic: which exact form of Zq::mul the transform kernels run for this modulus"""

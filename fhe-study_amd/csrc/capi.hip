@@ -150,6 +150,9 @@ static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
             p->s_ninv_pm.wp = mulmod(p->s_ninv.w, 1ull << 32, q);
         }
     }
+    // q = qh 2^32 + 1 below 2^61 (zq_device.hpp, word Montgomery): the forward transforms run on {w 2^32, w 2^64 mod q}
+    if ((q & 0xffffffffull) == 1ull && (q >> 32) != 0 && (q >> 61) == 0 && p->mod.pm_k == 0)
+        p->mod.mg_nqh = (uint32_t)(0u - (uint32_t)(q >> 32));
     return FHE_OK;
 }
 
@@ -300,6 +303,25 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
                 return hip_fail(e, "uploading the pseudo-Mersenne twiddle tables");
             }
         }
+        // q = 1 (mod 2^32): the forward table in word-Montgomery form {w 2^32, w 2^64 mod q}
+        fhe::Tw *mf = nullptr;
+        if (plan->mod.mg_nqh != 0) {
+            for (u64 k = 0; k < n; k++) {
+                f[k].w = mulmod(plan->roots[k], 1ull << 32, q);
+                f[k].wp = mulmod(f[k].w, 1ull << 32, q);
+            }
+            e = hipMalloc((void **)&mf, n * sizeof(fhe::Tw));
+            if (e == hipSuccess) e = hipMemcpy(mf, f.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (mf) (void)hipFree(mf);
+                if (sf) (void)hipFree(sf);
+                if (si) (void)hipFree(si);
+                (void)hipFree(df); (void)hipFree(di);
+                if (dl) (void)hipFree(dl);
+                return hip_fail(e, "uploading the Montgomery twiddle table");
+            }
+        }
+        t.tw_fwd_mg = mf;
         t.tw_fwd_pm = pf;
         t.tw_inv_pm = pi;
         t.tw_fwd = df;
@@ -324,7 +346,14 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     dp->ninv_pm = plan->ninv_pm;
     dp->s_ninv_pm = plan->s_ninv_pm;
     dp->arith = (plan->q >> 62) ? fhe::kArStrict63 : (t.tw_fwd_pm && fhe_pm_enabled()) ? fhe::kArPMersenne : dp->wide ? fhe::kArWide61 : fhe::kArShoup62;
+    dp->tw_fwd_mg = fhe_mg_enabled() ? t.tw_fwd_mg : nullptr;
     return FHE_OK;
+}
+
+// FHE_MG=0 (read once): q = 1 (mod 2^32) keeps the Shoup forward kernels — the A/B of profiles/r04_montgomery_ab.txt
+bool fhe_mg_enabled() {
+    static const bool on = [] { const char *e = getenv("FHE_MG"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // FHE_PM=0 (read once): pseudo-Mersenne moduli stay on the Shoup kernels — how the A/B numbers of DESIGN.md were taken
@@ -337,6 +366,7 @@ extern "C" int fhe_ntt_plan_arithmetic(const fhe_ntt_plan *plan) {
     if (!plan) return fail(FHE_E_NULL, "plan is NULL");
     if (fhe::smallq_supported(plan->q, plan->log_n) && fhe_ext32_enabled()) return FHE_ARITH_WORD32;
     if (plan->mod.pm_k != 0 && fhe_pm_enabled()) return FHE_ARITH_PMERSENNE;
+    if (plan->mod.mg_nqh != 0 && plan->log_n >= 4 && fhe_mg_enabled()) return FHE_ARITH_MONTGOMERY;
     if (plan->q >> 62) return FHE_ARITH_STRICT63;
     return (plan->q >> 61) == 0 ? FHE_ARITH_SHOUP61 : FHE_ARITH_SHOUP62;
 }
@@ -1219,6 +1249,7 @@ extern "C" int fhe_ntt_shutdown(void) {
             if (t.digit_lut) (void)hipFree(t.digit_lut);
             if (t.tw32_fwd) (void)hipFree(t.tw32_fwd);
             if (t.tw32_inv) (void)hipFree(t.tw32_inv);
+            if (t.tw_fwd_mg) (void)hipFree(t.tw_fwd_mg);
             if (t.tw_fwd_pm) (void)hipFree(t.tw_fwd_pm);
             if (t.tw_inv_pm) (void)hipFree(t.tw_inv_pm);
             if (t.twc_pm) (void)hipFree(t.twc_pm);

@@ -18,6 +18,7 @@ struct DeviceTables {
     fhe::u64 *digit_lut = nullptr;   // 136 words, n >= 8 (ntt_rounds.hpp: round0_bits)
     fhe::Tw32 *tw32_fwd = nullptr, *tw32_inv = nullptr;   // small moduli (smallq.hip)
     fhe::Tw *tw_fwd_pm = nullptr, *tw_inv_pm = nullptr;   // pseudo-Mersenne moduli: {w, w 2^32 mod q} (zq_device.hpp)
+    fhe::Tw *tw_fwd_mg = nullptr;                          // q = 1 (mod 2^32) below 2^61: {w 2^32, w 2^64 mod q}, forward only
     fhe::Tw *twc_pm = nullptr;   // the one-launch transform's lane-ordered table of the last four stages (ntt_persist.hip), built on first use
     bool ready = false;
 };
@@ -54,6 +55,7 @@ namespace fhe { struct SmallQArgs; }
 // fills the modulus-dependent fields when the plan has a 32-bit form on this device (smallq.hip) and FHE_EXT32 is on
 bool fhe_smallq_args(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, fhe::SmallQArgs *a);
 int fhe_smallq_scratch(unsigned log_n, uint64_t rows, hipStream_t st, fhe::SmallQArgs *a);   // a->mid for n > 2^14
+bool fhe_mg_enabled();                                 // FHE_MG=0 keeps q = 1 (mod 2^32) on the Shoup forward kernels
 bool fhe_pm_enabled();                                 // FHE_PM=0 keeps pseudo-Mersenne moduli on the Shoup kernels
 bool fhe_ext32_enabled();                              // FHE_EXT32=0 keeps every product on the 61-bit kernels
 // pooled device staging for the host-buffer entry points (capi.hip); release only idle buffers

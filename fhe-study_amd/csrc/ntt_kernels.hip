@@ -45,11 +45,12 @@ namespace fhe {
 // SRC_REDUCE (single-pass sizes only; the two-pass sizes do it in the strided pass): the input
 // rows are 2^src_log_n arbitrary 64-bit words, reduced mod q and zero-padded to n in the load.
 // AR: 0 = q < 2^62 (Harvey [0,4q)), 1 = q < 2^61 (Shoup, compile-time bounds), 2 = pseudo-Mersenne q (zq_device.hpp:
-// five-multiply butterflies; `a.tw` then holds {w, w 2^32 mod q}; SRC_PLAIN only).
+// five-multiply butterflies; `a.tw` then holds {w, w 2^32 mod q}; SRC_PLAIN only), 4 = q = 1 (mod 2^32) below 2^61 (word
+// Montgomery, `a.tw` = {w 2^32, w 2^64 mod q}; the FORWARD kernels only, SRC_PLAIN only).
 template <int LP, bool FINAL, int AR, int SRC = SRC_PLAIN>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
     constexpr bool WIDE = AR == 1;
-    static_assert(AR != 2 || SRC == SRC_PLAIN, "transforming loads run on the Shoup tables");
+    static_assert((AR != 2 && AR != 4) || SRC == SRC_PLAIN, "transforming loads run on the Shoup tables");
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
         for (u32 i = tid; i < (u32)kDigitLutWords; i += C::TH) llut[i] = a.lut[i];
         __syncthreads();
         fwd_rounds_contig<LP, WIDE, FINAL, 2, true, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, llut);
-    } else if constexpr (AR == 2) {
-        fwd_rounds_contig_pm<LP, kPmPassBound, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
+    } else if constexpr (AR == 2 || AR == 4) {
+        fwd_rounds_contig_pm<LP, kPmPassBound, true, AR>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
     } else {
         fwd_rounds_contig<LP, WIDE, FINAL, kPassBound, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m);
     }
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u64 x = !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : canon4(v[k], m);   // FINAL: < 4q in both Shoup modes
+        const u64 x = !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon8(v[k], m) : canon4(v[k], m);   // FINAL: < 4q in both Shoup modes, < 7q from the Montgomery rounds
         lds[pad16(w * C::M + field_of<ALAST>(tf, k))] = x;
     }
     __syncthreads();
@@ -527,20 +528,21 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
     // inputs are canonical (bound 2 leaves slack); the pass ends below kPassBound*q (END6)
     constexpr int B0 = 2, B1 = fwd_bound_out(C::R0, B0), B2 = fwd_bound_out(4, B1);
     static_assert(kPassBound == 6, "END6 ends a pass below 6q");
-    constexpr int P0 = kPmOne, P1 = pm_fwd_bound_out(C::R0, P0), P2 = pm_fwd_bound_out(4, P1), P3 = pm_fwd_bound_out(4, P2);
-    static_assert((C::NR == 1 ? P1 : C::NR == 2 ? P2 : P3) <= kPmPassBound, "AR == 2: a strided pass ends below kPmPassBound");
-    if constexpr (AR == 2) round_fwd_pm<C::R0, P0, true>(v, a.tw, 1u, m);
+    constexpr int AK = AR == 4 ? 4 : 2;
+    constexpr int P0 = kPmOne, P1 = pm_fwd_bound_out(C::R0, P0, AK), P2 = pm_fwd_bound_out(4, P1, AK), P3 = pm_fwd_bound_out(4, P2, AK);
+    static_assert((C::NR == 1 ? P1 : C::NR == 2 ? P2 : P3) <= kPmPassBound, "AR == 2 / 4: a strided pass ends below kPmPassBound");
+    if constexpr (AR == 2 || AR == 4) round_fwd_pm<C::R0, P0, true, AK>(v, a.tw, 1u, m);
     else round_fwd<C::R0, WIDE, B0, false, C::NR == 1>(v, a.tw, 1u, m);   // uniform twiddles: scalar loads from the global table
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         exchange_strided<CW, C::A0, A, true>(v, lds, c, tf);   // its barrier also publishes ltw
-        if constexpr (AR == 2) round_fwd_pm<4, P1, false>(v, tw, (1u << LS) + (tf >> A), m);
+        if constexpr (AR == 2 || AR == 4) round_fwd_pm<4, P1, false, AK>(v, tw, (1u << LS) + (tf >> A), m);
         else round_fwd<4, WIDE, B1, false, C::NR == 2>(v, tw, (1u << LS) + (tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         exchange_strided<CW, C::a_of(1), A, false>(v, lds, c, tf);
-        if constexpr (AR == 2) round_fwd_pm<4, P2, false>(v, tw, (1u << LS) + (tf >> A), m);
+        if constexpr (AR == 2 || AR == 4) round_fwd_pm<4, P2, false, AK>(v, tw, (1u << LS) + (tf >> A), m);
         else round_fwd<4, WIDE, B2, false, C::NR == 3>(v, tw, (1u << LS) + (tf >> A), m);
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
@@ -737,6 +739,7 @@ static hipError_t fwd_contig_dispatch(int lp, bool final, int ar, const PassArgs
     switch (lp) {
 #define X(LP_)                                                                                   \
     case LP_:                                                                                    \
+        if (ar == 4) return final ? launch_fwd_contig<LP_, true, 4>(a, st) : launch_fwd_contig<LP_, false, 4>(a, st); \
         if (ar == 2) return final ? launch_fwd_contig<LP_, true, 2>(a, st) : launch_fwd_contig<LP_, false, 2>(a, st); \
         if (ar == 1) return final ? launch_fwd_contig<LP_, true, 1>(a, st) : launch_fwd_contig<LP_, false, 1>(a, st); \
         return final ? launch_fwd_contig<LP_, true, 0>(a, st) : launch_fwd_contig<LP_, false, 0>(a, st);
@@ -778,6 +781,8 @@ static hipError_t strided_dispatch_ar(int la, const PassArgs &a, hipStream_t st,
 }
 template <bool INV>
 static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
+    if constexpr (!INV)
+        if (ar == kArMontgomeryFwd) return strided_dispatch_ar<false, 4>(la, a, st, operands);
     return ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands)
          : ar == 1 ? strided_dispatch_ar<INV, 1>(la, a, st, operands)
                    : strided_dispatch_ar<INV, 0>(la, a, st, operands);
@@ -799,10 +804,13 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
     PassArgs a{};
     const int L = p.log_n;
     // n < 16: one thread per polynomial on the Shoup tables
-    const int ar = L < 4 ? (p.wide ? 1 : 0) : p.arith;
+    // q = 1 (mod 2^32): the forward kernels on the word-Montgomery table (AR = 4); every other entry point keeps p.arith
+    const bool mg = L >= 4 && p.tw_fwd_mg != nullptr && p.arith == kArWide61;
+    const int ar = L < 4 ? (p.wide ? 1 : 0) : mg ? (int)kArMontgomeryFwd : p.arith;
     DevicePlan pt = p;
-    pt.arith = ar;
+    pt.arith = mg ? (int)kArWide61 : ar;
     set_tables(a, pt, false);
+    if (mg) a.tw = p.tw_fwd_mg;
     if (batch == 0) return hipSuccess;
     if (L < 4) {
         a.in = in; a.out = out; a.batch = batch;

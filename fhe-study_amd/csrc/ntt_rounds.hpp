@@ -197,21 +197,25 @@ __device__ __forceinline__ void round_inv_sel(u64 (&v)[16], const Tw *__restrict
 // y' = u - r + 3q < B + 48, whatever y was; x is reduced first (x -> (x mod 2^k) + (x >> k) delta, below 17) when
 // B + 48 would pass 8q: every other stage.  A pass hands the next one values below kPmPassBound.
 constexpr bool pm_fwd_needs_red(int b) { return b + 3 * kPmOne > kPmCap; }
-constexpr int pm_fwd_bound_out(int R, int bin) {
+// AK = 2: the pseudo-Mersenne butterflies; AK = 4: the word-Montgomery ones (zq_device.hpp: ct_bfly_mg) — the same growth
+// per stage (x' = u + r < B + 48, y' = u + 3q - r < B + 48), but a reduction is a conditional subtraction of 4q and only
+// brings a value below 4q: from canonical inputs the bounds run 16, 64, 112, then 112 after every further stage.
+constexpr int pm_fwd_bound_out(int R, int bin, int ak = 2) {
     int b = bin;
-    for (int i = 0; i < R; i++) b = (pm_fwd_needs_red(b) ? kPmRed : b) + 3 * kPmOne;
+    for (int i = 0; i < R; i++) b = (pm_fwd_needs_red(b) ? (ak == 4 ? kMgRed : kPmRed) : b) + 3 * kPmOne;
     return b;
 }
-constexpr int kPmPassBound = 113;   // what 8 stages from canonical inputs (and from 113 again) end with
+constexpr int kPmPassBound = 113;   // what 8 stages from canonical inputs (and from 113 again) end with (AK = 4: 112)
 
-template <int R, int BIN, bool SGPR_TW>
+template <int R, int BIN, bool SGPR_TW, int AK = 2>
 __device__ __forceinline__ void round_fwd_pm(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m) {
+    static_assert(AK == 2 || AK == 4, "pseudo-Mersenne or word-Montgomery tables");
     static_assert(BIN >= kPmOne && BIN <= kPmCap, "input bound out of range");
-    static_assert(pm_fwd_bound_out(R, BIN) <= kPmCap, "a stage would overflow");
+    static_assert(pm_fwd_bound_out(R, BIN, AK) <= kPmCap, "a stage would overflow");
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int span = 8 >> i;
-        const bool red = pm_fwd_needs_red(pm_fwd_bound_out(i, BIN));
+        const bool red = pm_fwd_needs_red(pm_fwd_bound_out(i, BIN, AK));
 #ifdef FHE_ABLATE_NO_BUTTERFLIES
         if (i >= 0) continue;
 #endif
@@ -221,8 +225,13 @@ __device__ __forceinline__ void round_fwd_pm(u64 (&v)[16], const Tw *__restrict_
 #pragma unroll
             for (int l = 0; l < span; l++) {
                 const int k = g * 2 * span + l;
-                if (red) v[k] = pm_reduce(v[k], m);
-                ct_bfly_pm<SGPR_TW>(v[k], v[k + span], t.w, t.wp, m);
+                if constexpr (AK == 4) {
+                    if (red) v[k] = csub_neg(v[k], m.neg4q);
+                    ct_bfly_mg<SGPR_TW>(v[k], v[k + span], t.w, t.wp, m);
+                } else {
+                    if (red) v[k] = pm_reduce(v[k], m);
+                    ct_bfly_pm<SGPR_TW>(v[k], v[k + span], t.w, t.wp, m);
+                }
             }
         }
     }
@@ -546,7 +555,7 @@ __device__ __forceinline__ void inv_rounds_contig(u64 (&v)[16], u64 *lds, const 
 // Round 0 of a forward pass and the last round of an inverse pass have workgroup-uniform twiddles (H = 0): global
 // table, scalar loads, SGPR operands.  The forward driver leaves values below pm_fwd_bound_out over its rounds
 // (<= kPmPassBound from BIN = 16 or kPmPassBound); the inverse driver below kPmInvBound.
-template <int LP, int BIN, bool FRESH>
+template <int LP, int BIN, bool FRESH, int AK = 2>
 __device__ __forceinline__ void fwd_rounds_contig_pm(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
                                                      u32 w, u32 tf, const Mod &m) {
     using C = ContigCfg<LP>;
@@ -554,25 +563,25 @@ __device__ __forceinline__ void fwd_rounds_contig_pm(u64 (&v)[16], u64 *lds, con
     auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
         return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
     };
-    constexpr int B0 = BIN, B1 = pm_fwd_bound_out(C::R0, B0), B2 = pm_fwd_bound_out(4, B1), B3 = pm_fwd_bound_out(4, B2);
-    round_fwd_pm<C::R0, B0, true>(v, gtw, (1u << s0) + blk, m);
+    constexpr int B0 = BIN, B1 = pm_fwd_bound_out(C::R0, B0, AK), B2 = pm_fwd_bound_out(4, B1, AK), B3 = pm_fwd_bound_out(4, B2, AK);
+    round_fwd_pm<C::R0, B0, true, AK>(v, gtw, (1u << s0) + blk, m);
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         constexpr bool L = C::in_lds(1);
         exchange_contig<LP, C::A0, A, FRESH>(v, lds, w, tf);
-        round_fwd_pm<4, B1, false>(v, TW(L), T0(L, LS, tf >> A), m);
+        round_fwd_pm<4, B1, false, AK>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         constexpr bool L = C::in_lds(2);
         exchange_contig<LP, C::a_of(1), A, false>(v, lds, w, tf);
-        round_fwd_pm<4, B2, false>(v, TW(L), T0(L, LS, tf >> A), m);
+        round_fwd_pm<4, B2, false, AK>(v, TW(L), T0(L, LS, tf >> A), m);
     }
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
         constexpr bool L = C::in_lds(3);
         exchange_contig<LP, C::a_of(2), A, false>(v, lds, w, tf);
-        round_fwd_pm<4, B3, false>(v, TW(L), T0(L, LS, tf >> A), m);
+        round_fwd_pm<4, B3, false, AK>(v, TW(L), T0(L, LS, tf >> A), m);
     }
 }
 

@@ -55,6 +55,8 @@ struct Mod {
     u32 pm_rsh;     // k - 32:  x >> k = (x >> 32) >> (k - 32)
     u32 pm_rmask;   // 2^(k-32) - 1
     u32 pm_k;       // k, or 0 when q is not of this form
+    // q = qh 2^32 + 1 below 2^61 (see "word Montgomery" below): 2^32 - qh, or 0 when q is not of this form
+    u32 mg_nqh;
 };
 
 // ---- single-instruction wrappers (register allocation stays with the compiler) ----
@@ -302,6 +304,60 @@ __device__ __forceinline__ void gs_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, u64 kq
     y = yo;
 }
 #undef FHE_PM_PRODUCT
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Word Montgomery for q = qh 2^32 + 1 < 2^61 (round 4; tools/ubench_bfly.hip v14): the same split multiplicand on a table
+// {A = w 2^32 mod q, B = w 2^64 mod q}:  T = y0 A + y1 B = y w 2^32 (mod q), T < 2^33 q  — the same four multiplies — and
+// ONE Montgomery word step brings back the factor: q^-1 = 1 (mod 2^32), so the step's multiplier is -T0 itself and
+//   r = (T >> 32) - T0 qh + q   =  T 2^-32  =  y w (mod q),   0 < r < 3q  (T >> 32 < 2q, T0 qh < q)
+// is one more multiply (by 2^32 - qh, then T0 taken off the high word) and an addition: nine instructions, as the
+// pseudo-Mersenne product.  What it lacks is that form's cheap reduction: values come down by a conditional subtraction
+// of 4q (four instructions, to below 4q) before every stage from the third on, so a forward butterfly averages ~16.5
+// instructions against ~14.5 — and against the ~21 of the Shoup form these moduli ran on.  FORWARD transforms only: an
+// inverse stage would need up to two such subtractions per butterfly (x + y of two values below 4q is at the cap), and a
+// variable x variable product has no table; those keep the Shoup kernels (same words either way).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMgRed = 64;    // sixteenths of q: after the conditional subtraction of 4q (for values below 8q)
+#define FHE_MG_PRODUCT(Y0, Y1, OUT)                                                                    \
+    "v_mad_u64_u32 v[2:3], vcc, " Y0 ", %[a0], 0\n\t"                                                  \
+    "v_mad_u64_u32 v[2:3], vcc, " Y1 ", %[b0], v[2:3]\n\t"      /* carry -> vcc */                    \
+    "v_mov_b32 v6, v3\n\t"                                                                             \
+    "v_addc_co_u32 v7, vcc, 0, 0, vcc\n\t"                                                             \
+    "v_mad_u64_u32 v[6:7], vcc, " Y0 ", %[a1], v[6:7]\n\t"                                             \
+    "v_mad_u64_u32 v[6:7], vcc, " Y1 ", %[b1], v[6:7]\n\t"      /* T >> 32;  T0 = v2 */               \
+    "v_mad_u64_u32 v[6:7], vcc, v2, %[nqh], v[6:7]\n\t"         /* + T0 (2^32 - qh) */                \
+    "v_sub_u32 v7, v7, v2\n\t"                                  /* - T0 2^32 */                       \
+    "v_lshl_add_u64 " OUT ", v[6:7], 0, %[qq]\n\t"              /* + q: in (0, 3q) */
+
+// Forward butterfly on the Montgomery table: x' = u + r, y' = u - r + 3q as ct_bfly_pm (r < 3q)
+template <bool SGPR_TW>
+__device__ __forceinline__ void ct_bfly_mg(u64 &x, u64 &y, u64 wa, u64 wb, const Mod &m) {
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+    const u32 a0 = (u32)wa, a1 = (u32)(wa >> 32), b0 = (u32)wb, b1 = (u32)(wb >> 32);
+    const u64 k3 = m.q3p1 - 1ull;                                 // 3q
+    u32 yl, yh;
+#define FHE_MG_CT_BODY                                                                                 \
+    "v_lshl_add_u64 v[4:5], %[x], 0, %[k3]\n\t"                   /* u + 3q */                          \
+    FHE_MG_PRODUCT("%[y0]", "%[y1]", "v[2:3]")                                                         \
+    "v_lshl_add_u64 %[x], %[x], 0, v[2:3]\n\t"                   /* x' = u + r */                      \
+    "v_sub_co_u32 %[yl], vcc, v4, v2\n\t"                                                              \
+    "v_subb_co_u32 %[yh], vcc, v5, v3, vcc"                      /* y' = u + 3q - r */
+    if constexpr (SGPR_TW)
+        asm(FHE_MG_CT_BODY
+            : [x] "+&v"(x), [yl] "=v"(yl), [yh] "=v"(yh)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1),
+              [nqh] "s"(m.mg_nqh), [qq] "s"(m.q), [k3] "s"(k3)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
+    else
+        asm(FHE_MG_CT_BODY
+            : [x] "+&v"(x), [yl] "=v"(yl), [yh] "=v"(yh)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
+              [nqh] "s"(m.mg_nqh), [qq] "s"(m.q), [k3] "s"(k3)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
+#undef FHE_MG_CT_BODY
+    y = ((u64)yh << 32) | yl;
+}
+#undef FHE_MG_PRODUCT
 
 // Rust `f64 as i64` (saturating, NaN -> 0)
 __device__ __forceinline__ long long f64_as_i64(double x) {

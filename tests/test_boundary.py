@@ -241,6 +241,7 @@ def test_plan_arithmetic_is_decided_on_the_host(pkg):
     assert L.fhe_ntt_plan_arithmetic(None) == B.FHE_E_NULL
     pm_on = os.environ.get("FHE_PM", "1")[:1] != "0"
     ext_on = os.environ.get("FHE_EXT32", "1")[:1] != "0"
+    mg_on = os.environ.get("FHE_MG", "1")[:1] != "0"
     cases = [
         (Q61, 65536, 2 if pm_on else 1),                      # 2^61 - 2^21 + 1: the headline modulus
         (2305843009210023937, 4096, 2 if pm_on else 1),       # 2^61 - 28 * 2^17 + 1
@@ -252,10 +253,14 @@ def test_plan_arithmetic_is_decided_on_the_host(pkg):
         (Q16, 64, 1),                                         # n below the 32-bit kernels' range
         (1073479681, 4096, 3 if ext_on else 1),               # a 30-bit prime: Harvey form of the 32-bit kernels
         (2147352577, 4096, 1),                                # 31 bits: past them
+        (0x1ffffff900000001, 65536, 5 if mg_on else 1),       # q = 1 (mod 2^32): word Montgomery in the forward transforms (round 4)
+        (0x3fff300000001, 4096, 5 if mg_on else 1),           # ... of 50 bits
+        (0xff00000001, 16, 5 if mg_on else 1),                # ... of 40 bits, the smallest n the block kernels run
+        (0xff00000001, 8, 1),                                 # ... below it: one thread per polynomial, Shoup
     ]
     for q, n, want in cases:
         assert (q - 1) % (2 * n) == 0
         plan = pkg.Plan(q, n)
         assert plan.arithmetic() == want, (q, n)
         assert (pm_params(q) is not None) == (want == 2 or (not pm_on and q in (Q61, 2305843009210023937, 1152921504606584833)))
-    assert set(pkg.Plan.ARITH_NAMES) == {0, 1, 2, 3, 4}     # 4: 2^62 <= q < 2^63, tests/test_round3_gpu.py
+    assert set(pkg.Plan.ARITH_NAMES) == {0, 1, 2, 3, 4, 5}  # 4: 2^62 <= q < 2^63, tests/test_round3_gpu.py; 5: tests/test_round4_gpu.py

@@ -166,3 +166,102 @@ def test_two_threads_on_the_default_stream(pkg, oracle, need_gpu):
     assert not errs, errs
     for _, _, dc, want in jobs:
         assert np.array_equal(dc.cpu().numpy().view(np.uint64), want)
+
+
+# ---- q = 1 (mod 2^32): the forward transforms on the word-Montgomery table (zq_device.hpp: ct_bfly_mg) ----------------------
+QMG61, QMG50, QMG40 = 0x1ffffff900000001, 0x3fff300000001, 0xff00000001
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q,n", [(QMG61, 16), (QMG61, 64), (QMG61, 256), (QMG61, 2048), (QMG61, 8192), (QMG61, 1 << 14),
+                                 (QMG61, 1 << 15), (QMG61, 1 << 16), (QMG61, 1 << 17), (QMG50, 32), (QMG50, 4096),
+                                 (QMG50, 1 << 16), (QMG40, 16), (QMG40, 1024), (QMG40, 1 << 14)])
+def test_montgomery_forward_is_the_oracles_transform(pkg, oracle, need_gpu, q, n):
+    """NTT::ntt (arith/src/ntt.rs:44-73) for q = qh 2^32 + 1 below 2^61: the forward kernels run the word-Montgomery
+    butterfly (plan arithmetic 5), the inverse ones the Shoup form — the words are the oracle's in both directions, on
+    zeros, on q - 1 everywhere (the largest values every bound has to hold for) and on ragged batches."""
+    import os
+
+    plan = pkg.Plan(q, n)
+    assert plan.arithmetic() == (5 if os.environ.get("FHE_MG", "1")[:1] != "0" else 1)
+    batch = 5 if n >= (1 << 14) else 37
+    a = _rows(oracle, q, n, batch, 4300 + n)
+    A = plan.forward(a)
+    assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (hex(q), n)
+    assert np.array_equal(plan.inverse(A).reshape(-1), a.reshape(-1)), (hex(q), n)
+
+
+@pytest.mark.gpu
+def test_montgomery_plans_keep_every_other_entry_point(pkg, oracle, need_gpu):
+    """products (fused at single-pass sizes, two-pass above) and the in-place device entry point on such a modulus"""
+    import torch
+
+    for n in (1024, 1 << 14):
+        plan = pkg.Plan(QMG61, n)
+        a, b = _rows(oracle, QMG61, n, 3, 4400 + n), _rows(oracle, QMG61, n, 3, 4500 + n)
+        got = plan.rq_mul(a, b)
+        got = got[0] if isinstance(got, tuple) else got
+        want = oracle.rq_mul(QMG61, n, a, b)
+        want = want[0] if isinstance(want, tuple) else want
+        assert np.array_equal(np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)), n
+    n, batch = 1 << 16, 40
+    plan = pkg.Plan(QMG61, n)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
+    pkg.binding.fill_synthetic_dev(QMG61, 77, 0, batch * n, x.data_ptr(), st)
+    host = x.cpu().numpy().view(np.uint64).reshape(batch, n)
+    plan.forward_dev(x.data_ptr(), x.data_ptr(), batch, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(x.cpu().numpy().view(np.uint64).reshape(-1), oracle.ntt(QMG61, n, host).reshape(-1))
+
+
+def _mul_mg(y, wa, wb, q, p):
+    """the nine instructions of FHE_MG_PRODUCT (zq_device.hpp) in Python integers, word for word"""
+    M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+    y0, y1 = y & M32, y >> 32
+    a0, a1, b0, b1 = wa & M32, wa >> 32, wb & M32, wb >> 32
+    N = y0 * a0
+    N = N + y1 * b0
+    carry, N = N >> 64, N & M64                       # v_mad_u64_u32 ... carry -> vcc
+    B = (N >> 32) | (carry << 32)                     # v_mov / v_addc: {n1, carry}
+    B = B + y0 * a1
+    B = B + y1 * b1
+    assert B <= M64 and B < 2 * q                     # T >> 32 < 2q
+    T0 = N & M32
+    R = (B + T0 * p["nqh"]) & M64                     # v_mad_u64_u32 (wraps)
+    R = ((((R >> 32) - T0) & M32) << 32) | (R & M32)  # v_sub_u32 on the high word
+    return (R + q) & M64                              # v_lshl_add_u64
+
+
+def test_montgomery_product_identity_and_bounds():
+    """r = y w (mod q) and 0 < r < 3q for ANY 64-bit y on the table {w 2^32, w 2^64 mod q}; the forward schedule of
+    ntt_rounds.hpp (AK = 4: a conditional subtraction of 4q before every stage from the third on) keeps every value below 2^64"""
+    import random
+    from fhe_study_amd.arith import mg_params, pm_params
+
+    rng = random.Random(5)
+    for q in (QMG61, QMG50, QMG40):
+        p = mg_params(q)
+        assert p is not None and pm_params(q) is None
+        for _ in range(4000):
+            w = rng.randrange(q)
+            y = rng.choice([rng.getrandbits(64), (1 << 64) - 1, q - 1, 0, 1, 8 * q - 1 if 8 * q < 1 << 64 else q])
+            wa = (w << 32) % q
+            wb = (wa << 32) % q
+            r = _mul_mg(y, wa, wb, q, p)
+            assert 0 < r < 3 * q and r % q == (y * w) % q
+        # sixteen stages on the worst values the bounds allow: x' = u + r, y' = u + 3q - r, u reduced when its bound asks
+        bx = 16                                             # sixteenths of q
+        x = q - 1
+        for stage in range(16):
+            if bx + 48 > 128:
+                assert x < 8 * q
+                x = x - 4 * q if x >= 4 * q else x
+                bx = 64
+            r = 3 * q - 1
+            x, yv = x + r, x + 3 * q - 1
+            bx += 48
+            assert x < (1 << 64) and yv < (1 << 64) and x * 16 < bx * q + 16
+        assert bx == 112
+    for q in (Q61, 0x1fffffffff000001, 65537, (1 << 32) + 1 + (1 << 61)):
+        assert mg_params(q) is None

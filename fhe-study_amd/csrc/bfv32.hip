@@ -201,8 +201,12 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
 #pragma unroll
     for (int i = 0; i < 4; i++) stage_tw32_block<C::TH>(K::table(smem_raw, i), a.t.tw_inv[i >> 1], C::LTW_N, tf, 1u, (u32)(i & 1));
     __syncthreads();
-    u32 loA[16], hiA[16];
-    u64 *__restrict__ po = a.out + ((u64)which * a.batch + b) * K::M + tf;
+    // The first prime's 32 residues per thread are NOT kept in registers across the second prime's transforms (round 4:
+    // the kernel spilled 74 dwords per lane at its 128 registers and waited on its own scratch traffic).  They are parked in
+    // the words of the output polynomial this thread writes anyway — slot k TH + tf holds {coefficient j, coefficient j + n}
+    // — and come back one pair ahead of the epilogue that consumes them (an L2 hit: written by this workgroup microseconds
+    // before).  `ps` is the same pointer made opaque, so that the compiler neither forwards the stored values through
+    // registers nor moves the reloads up.
     auto prime = [&](auto prc) __attribute__((always_inline)) {     // a lambda per prime: the loop form is not unrolled by the compiler
         constexpr int pr = decltype(prc)::value;
         const u32 p = a.t.p[pr], p2 = 2u * p, pn = a.pinv_neg[pr];
@@ -233,17 +237,26 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
         block(0u, v0);
         block(1u, v1);
         const Tw32 ni = a.ninv_mont[pr], w1 = a.t.tw_inv[pr][1];
+        u64 parked = 0;
+        u32 tfe = tf;
+        asm volatile("" : "+v"(tfe));                           // (formed here, from an opaque lane id: no address registers held across the transforms)
+        u64 *po = a.out + ((u64)which * a.batch + b) * K::M + tfe;
+        u64 *ps = po;
+        asm volatile("" : "+v"(ps));
+        if constexpr (pr == 1) parked = ps[0];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u32 rl = v0[0][k], rh = v1[0][k];
             last_stage(rl, rh, w1, ni, p, p2);
             if constexpr (pr == 0) {
-                loA[k] = rl; hiA[k] = rh;
+                po[(u32)k * C::TH] = ((u64)rh << 32) | rl;
             } else {
+                const u32 loA = (u32)parked, hiA = (u32)(parked >> 32);
+                if (k + 1 < 16) parked = ps[(u32)(k + 1) * C::TH];
                 // coefficients j and j + n of the 2n-word convolution — the pair the X^n+1 fold subtracts (ring_nq.rs:132-141);
                 // mul_div_round (ring_n.rs:130-138) + Rq::from_vec_f64 (ring_nq.rs:160-163)
-                const long long lo = (long long)crt2(loA[k], rl, a.t.p[0], a.t.p[1], a.t.crt);
-                const long long hi = (long long)crt2(hiA[k], rh, a.t.p[0], a.t.p[1], a.t.crt);
+                const long long lo = (long long)crt2(loA, rl, a.t.p[0], a.t.p[1], a.t.crt);
+                const long long hi = (long long)crt2(hiA, rh, a.t.p[0], a.t.p[1], a.t.crt);
 #ifndef FHE_B32_ABLATE_EPI
                 u64 zl, zh;
                 if constexpr (INT) {
@@ -285,9 +298,14 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
     for (int i = 0; i < 6; i++) stage_tw32_block<C::TH>(K::table(smem_raw, i), a.t.tw_inv[i >> 1], C::LTW_N, tf, 1u, (u32)(i & 1));
     __syncthreads();
     // Garner's digits: x = v0 + pA v1 + pA pB v2 with v0 = rA, v1 = (rB - v0) pA^-1 mod pB,
-    // v2 = ((rC - v0) pA^-1 - v1) pB^-1 mod pC; only x mod 2^64 is kept.  [0] = coefficient j, [1] = coefficient j + n
-    u32 g0[2][16], g1[2][16];
+    // v2 = ((rC - v0) pA^-1 - v1) pB^-1 mod pC; only x mod 2^64 is kept.
+    // Round 4: the digits are NOT kept in registers across the next prime's transforms (64 registers of a budget of 128:
+    // the kernel spilled 69 dwords per lane and waited on its own scratch traffic).  v0 and v1 of a coefficient pair
+    // {j, j + n} are parked as one 64-bit word each in two planes of the workspace (a.park), written where they are made
+    // and read back one pair ahead of the arithmetic that consumes them (L2 hits).  ps0 / ps1: the same pointers made
+    // opaque, so that the compiler neither forwards the stored values through registers nor moves the reloads up.
     const u64 off = ((u64)o * a.batch + b) * K::M + tf;
+    u64 *park0 = a.park + off, *park1 = park0 + 2 * a.batch * K::M;
     auto prime = [&](auto prc) __attribute__((always_inline)) {
         constexpr int pr = decltype(prc)::value;
         const u32 p = a.t.p[pr], p2 = 2u * p, pn = a.pinv_neg[pr];
@@ -309,33 +327,41 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
         block(0u, v0);
         block(1u, v1);
         const Tw32 ni = a.ninv_mont[pr], w1 = a.t.tw_inv[pr][1];
+        u64 pk0 = 0, pk1 = 0;                                   // the parked digits of the pair at hand
+        u64 *ps0 = park0, *ps1 = park1;
+        asm volatile("" : "+v"(ps0), "+v"(ps1));                // (here, not at the top: no registers held across the transforms)
+        if constexpr (pr >= 1) pk0 = ps0[0];
+        if constexpr (pr == 2) pk1 = ps1[0];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            u32 r2[2] = {v0[0][k], v1[0][k]};
+            u32 r2[2] = {v0[0][k], v1[0][k]};                    // [0] = coefficient j, [1] = coefficient j + n
             last_stage(r2[0], r2[1], w1, ni, p, p2);
+            if constexpr (pr == 0) {
+                park0[(u32)k * C::TH] = ((u64)r2[1] << 32) | r2[0];
+            } else if constexpr (pr == 1) {
+                const u32 g0[2] = {(u32)pk0, (u32)(pk0 >> 32)};
+                if (k + 1 < 16) pk0 = ps0[(u32)(k + 1) * C::TH];
+                u32 g1[2];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const u32 r = r2[h];
-                if constexpr (pr == 0) {
-                    g0[h][k] = r;
-                } else if constexpr (pr == 1) {
-                    const u32 d = csub_u32(r - csub_u32(g0[h][k], p) + p, p);              // pA - pB < pB: one subtraction reduces v0
-                    g1[h][k] = csub_u32(mul_shoup32(d, a.t.crt, p), p);
-                } else {
-                    const u32 a0 = csub_u32(csub_u32(g0[h][k], p), p);                       // pA - pC < 2 pC
-                    const u32 d = csub_u32(r - a0 + p, p);
-                    const u32 e = csub_u32(mul_shoup32(d, a.t.crt_ac, p), p);
-                    const u32 b1 = csub_u32(g1[h][k], p);                                    // pB - pC < pC
-                    const u32 v2 = csub_u32(mul_shoup32(csub_u32(e - b1 + p, p), a.t.crt_bc, p), p);
-                    r2[h] = 0;
-                    const u64 R = (u64)g0[h][k] + (u64)a.t.p[0] * g1[h][k] + a.t.P * v2;    // mod 2^64; P = pA pB < 2^55
-                    // the two coefficients' words meet below: keep them in g0 / g1 (both halves of a 64-bit word)
-                    g0[h][k] = (u32)R;
-                    g1[h][k] = (u32)(R >> 32);
+                for (int h = 0; h < 2; h++) {
+                    const u32 d = csub_u32(r2[h] - csub_u32(g0[h], p) + p, p);               // pA - pB < pB: one subtraction reduces v0
+                    g1[h] = csub_u32(mul_shoup32(d, a.t.crt, p), p);
                 }
-            }
-            if constexpr (pr == 2) {
-                const long long lo = (long long)(((u64)g1[0][k] << 32) | g0[0][k]), hi = (long long)(((u64)g1[1][k] << 32) | g0[1][k]);
+                park1[(u32)k * C::TH] = ((u64)g1[1] << 32) | g1[0];
+            } else {
+                const u32 g0[2] = {(u32)pk0, (u32)(pk0 >> 32)}, g1[2] = {(u32)pk1, (u32)(pk1 >> 32)};
+                if (k + 1 < 16) { pk0 = ps0[(u32)(k + 1) * C::TH]; pk1 = ps1[(u32)(k + 1) * C::TH]; }
+                long long R2[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const u32 a0 = csub_u32(csub_u32(g0[h], p), p);                          // pA - pC < 2 pC
+                    const u32 d = csub_u32(r2[h] - a0 + p, p);
+                    const u32 e = csub_u32(mul_shoup32(d, a.t.crt_ac, p), p);
+                    const u32 b1 = csub_u32(g1[h], p);                                       // pB - pC < pC
+                    const u32 v2 = csub_u32(mul_shoup32(csub_u32(e - b1 + p, p), a.t.crt_bc, p), p);
+                    R2[h] = (long long)((u64)g0[h] + (u64)a.t.p[0] * g1[h] + a.t.P * v2);    // mod 2^64; P = pA pB < 2^55
+                }
+                const long long lo = R2[0], hi = R2[1];
 #ifndef FHE_B32_ABLATE_EPI
                 const u64 zl = scale_round<SMALL>(a, lo);
                 const u64 zh = scale_round<SMALL>(a, hi);

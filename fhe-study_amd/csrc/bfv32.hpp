@@ -21,6 +21,7 @@ struct Bfv32Args {
     const uint32_t *x, *key;
     const u64 *addend;         // relinearisation: [c0 | c1] x batch x n
     u64 *out;
+    u64 *park;                 // relinearisation: 2 planes x [o0 | o1] x batch x n words, where Garner's digits wait between primes (bfv32.hip)
     u64 batch, q;
     u64 qmu;                   // floor(2^64 / q)
     double numf, denf;

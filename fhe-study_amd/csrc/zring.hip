@@ -598,7 +598,10 @@ static int bfv32_relinearize(uint64_t q, uint64_t n, uint64_t pq, const void *d_
     int rc = bfv32_args(n, &a);
     if (rc != FHE_OK) return rc;
     void *wsv = nullptr;
-    if ((rc = fhe_workspace_get(1, (u64)3 * batch * 2 * n * 4, st, &wsv)) != FHE_OK) return rc;
+    // transforms of c2 modulo three primes (3 * batch rows of 2n u32), then the two planes where Garner's digits are parked
+    const u64 x_bytes = (u64)3 * batch * 2 * n * 4, park_bytes = (u64)2 * 2 * batch * n * 8;
+    if ((rc = fhe_workspace_get(1, x_bytes + park_bytes, st, &wsv)) != FHE_OK) return rc;
+    a.park = (u64 *)((unsigned char *)wsv + x_bytes);
     a.src = (const u64 *)d_c + 2 * (u64)batch * n; a.fw = (uint32_t *)wsv; a.rows = batch; a.primes = 3; a.word32 = 1;
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");

@@ -846,7 +846,8 @@ __global__ __launch_bounds__(kTH, (DEEP ? 2 : 4)) void ntt_fwd_team_kernel(Persi
 // when it has no strided work left and its oldest part is not ready; before it waits it signals what it owes.
 // Per XCD: 64 workgroups = 4 groups, about 1.5 ring slots per group between "written" and "read" (2 - 3 MiB of a 4 MiB L2).
 // =====================================================================================================================
-constexpr u32 kFlowFifo = 64;                   // pending parts a workgroup can hold (ring slots x 16 at most are ever needed)
+constexpr u32 kFlowFifo = 64;                   // pending parts a workgroup can hold; >= 16 or a lone workgroup could never complete a polynomial (host/test_persist_sched.cpp)
+static_assert(kFlowFifo >= 16, "a lone workgroup runs all sixteen strided halves of a polynomial before the first contiguous one");
 constexpr size_t kFlowLdsBytes = kTileBytes + 2 * 256 * sizeof(Tw) + 64 + kFlowFifo * 4 + kProfWords * 8;
 
 __global__ __launch_bounds__(kTH, 2) void ntt_fwd_flow_kernel(PersistArgs a) {

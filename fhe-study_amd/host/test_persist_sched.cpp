@@ -8,6 +8,7 @@
 //   * coverage: every part of every polynomial / tile is run exactly once;
 //   * the ring: a slot is never rewritten before all parts of its previous tenant have read it, and a C part always
 //     finds its own polynomial in the slot.
+// Variant E (the teams without the meeting) is section 4.
 // Usage: test_persist_sched [seeds]     (prints "all persist schedule tests passed")
 #include <cstdint>
 #include <cstdio>
@@ -245,6 +246,124 @@ static void run_variant_b(u32 W, u32 polys, u32 R, u32 help_polls) {
     for (u32 i = 0; i < polys * kParts; i++) CHECK(ranS[i] == 1 && ranC[i] == 1, "variant B: part %u ran %d / %d times (W=%u)", i, ranS[i], ranC[i], W);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 4. variant E: the teams without the meeting.  G queues (the groups of ONE XCD), W workgroups, each with a FIFO of the parts
+//    whose contiguous half is still to come; one half per iteration, each half in two steps (before / at its exchange
+//    barrier) so that the deferred strided-done signal, the look-ahead samples and the other workgroups interleave as on the
+//    chip.  Follows ntt_fwd_flow_kernel: the decision at the top, the general path's one poll of two counters, the ring
+//    guard seen one half ago, the migration to the next group's queue when one runs dry.
+// ---------------------------------------------------------------------------------------------------------------------
+static void run_variant_e(u32 W, u32 G, const std::vector<u32> &polys, u32 R, u32 fifo_cap) {
+    const u32 kParts = 16;
+    std::vector<u32> head(G, 0);
+    std::vector<std::vector<u32>> sdone(G), cdone(G);
+    std::vector<std::vector<int>> ranS(G), ranC(G), tenant(G);
+    for (u32 g = 0; g < G; g++) {
+        sdone[g].assign(polys[g] + 8 + W, 0); cdone[g].assign(polys[g] + 8 + W, 0);
+        ranS[g].assign((size_t)polys[g] * kParts, 0); ranC[g].assign((size_t)polys[g] * kParts, 0);
+        tenant[g].assign(R, -1);
+    }
+    struct Part { u32 q, ord, r; };
+    struct Wg {
+        u32 qx = 0, dry = 0;
+        Part s_e{}; bool s_valid = false, s_loaded = false, c_loaded = false, guard_ok = true, owes = false, left = false;
+        Part owed{};
+        std::vector<Part> fifo;
+        int st = 0;                    // 0 = top, 1 = S before its barrier, 2 = C before its barrier
+        bool meet = false; u32 k_next = 0;
+        Part cur{};
+    };
+    std::vector<Wg> wg(W);
+    auto valid = [&](u32 q, u32 t) { return (t >> 4) < polys[q]; };
+    auto draw_sync = [&](Wg &w) {
+        for (;;) {
+            const u32 t = head[w.qx]++;
+            if (valid(w.qx, t)) { w.s_e = Part{w.qx, t >> 4, t & 15}; w.s_valid = true; return; }
+            if (++w.dry >= G) { w.s_valid = false; return; }
+            w.qx = (w.qx + 1) % G;
+        }
+    };
+    auto guard = [&](const Wg &w) { return !w.s_valid || w.s_e.ord < R || cdone[w.s_e.q][w.s_e.ord - R] >= kParts; };
+    auto settle = [&](Wg &w) { if (w.owes) { sdone[w.owed.q][w.owed.ord]++; w.owes = false; } };
+    for (u32 i = 0; i < W; i++) { wg[i].qx = (i / kParts) % G; draw_sync(wg[i]); }
+    u32 alive = W, idle = 0;
+    while (alive) {
+        CHECK(idle < 600000, "variant E: no progress (W=%u G=%u R=%u)", W, G, R);
+        Wg &w = wg[rnd() % W];
+        if (w.left) { idle++; continue; }
+        if (w.st == 0) {
+            const bool can_s = w.s_valid && w.fifo.size() < fifo_cap;
+            int act = -1;                                                       // 0 = S, 1 = C, 2 = leave, -1 = poll again
+            if (w.c_loaded && (w.fifo.size() >= 2 || !(can_s && w.guard_ok))) act = 1;
+            else if (can_s && w.s_loaded && w.guard_ok) act = 0;
+            else if (w.c_loaded) act = 1;
+            else {
+                settle(w);
+                u32 res = 0;
+                if (!w.fifo.empty() && sdone[w.fifo[0].q][w.fifo[0].ord] >= kParts) res |= 1u;
+                if (can_s && guard(w)) res |= 2u;
+                if (w.fifo.empty() && !can_s) act = 2;
+                else if (!res) { idle++; continue; }                            // one round of the bounded poll
+                else if ((res & 1u) && (w.fifo.size() >= 2 || !(res & 2u))) act = 1;
+                else act = 0;
+            }
+            idle = 0;
+            if (act == 2) {
+                CHECK(!w.owes && w.fifo.empty(), "left with work pending");
+                w.left = true; alive--;
+                continue;
+            }
+            if (act == 0) {
+                w.cur = w.s_e; w.s_loaded = false;
+                CHECK(w.cur.ord < R || cdone[w.cur.q][w.cur.ord - R] >= kParts, "S(%u) before its ring slot was read", w.cur.ord);
+                w.k_next = head[w.qx]++;                                        // the next ticket, drawn one half ahead
+                w.meet = !w.c_loaded && !w.fifo.empty() && sdone[w.fifo[0].q][w.fifo[0].ord] >= kParts;
+                w.st = 1;
+            } else {
+                CHECK(!w.fifo.empty(), "C with nothing pending");
+                w.cur = w.fifo[0]; w.c_loaded = false;
+                CHECK(sdone[w.cur.q][w.cur.ord] == kParts, "C before its polynomial was complete");
+                CHECK(tenant[w.cur.q][w.cur.ord % R] == (int)w.cur.ord, "C(%u) found ordinal %d in its slot", w.cur.ord, tenant[w.cur.q][w.cur.ord % R]);
+                w.guard_ok = guard(w);                                          // (sampled now, used at the next top)
+                w.meet = w.fifo.size() >= 2 && sdone[w.fifo[1].q][w.fifo[1].ord] >= kParts;
+                w.st = 2;
+            }
+        } else if (w.st == 1) {                                                 // S at its exchange barrier
+            idle = 0;
+            settle(w);
+            w.fifo.push_back(w.cur);
+            w.owes = true; w.owed = w.cur;
+            if (valid(w.qx, w.k_next)) w.s_e = Part{w.qx, w.k_next >> 4, w.k_next & 15};
+            else if (++w.dry >= G) w.s_valid = false;
+            else { w.qx = (w.qx + 1) % G; draw_sync(w); }
+            w.guard_ok = guard(w);
+            if (w.meet) w.c_loaded = true;
+            if (w.s_valid && w.fifo.size() < fifo_cap) w.s_loaded = true;
+            {   // the stores of this half: the ring slot changes tenant
+                int &t = tenant[w.cur.q][w.cur.ord % R];
+                CHECK(t < 0 || t == (int)w.cur.ord || cdone[w.cur.q][(u32)t] == kParts, "slot rewritten before ordinal %d was read", t);
+                t = (int)w.cur.ord;
+            }
+            ranS[w.cur.q][(size_t)w.cur.ord * kParts + w.cur.r]++;
+            w.st = 0;
+        } else {                                                                // C at its exchange barrier
+            idle = 0;
+            settle(w);
+            cdone[w.cur.q][w.cur.ord]++;
+            ranC[w.cur.q][(size_t)w.cur.ord * kParts + w.cur.r]++;
+            w.fifo.erase(w.fifo.begin());
+            if (w.meet) w.c_loaded = true;
+            if (!w.s_loaded && w.s_valid && w.fifo.size() < fifo_cap) w.s_loaded = true;
+            w.st = 0;
+        }
+    }
+    for (u32 g = 0; g < G; g++) {
+        CHECK(head[g] >= polys[g] * kParts, "queue %u: tickets left undrawn", g);
+        for (size_t i = 0; i < ranS[g].size(); i++)
+            CHECK(ranS[g][i] == 1 && ranC[g][i] == 1, "variant E: queue %u part %zu ran %d / %d times (W=%u G=%u R=%u)", g, i, ranS[g][i], ranC[g][i], W, G, R);
+    }
+}
+
 int main(int argc, char **argv) {
     const int seeds = argc > 1 ? std::atoi(argv[1]) : 6;
     test_decode();
@@ -274,6 +393,19 @@ int main(int argc, char **argv) {
             for (u32 polys : {1u, 2u, 3u, 9u, 20u})
                 for (u32 R : {1u, 2u, 4u})
                     for (u32 help : {0u, 3u, 50u}) run_variant_b(W, polys, R, help);
+        // E: from ONE workgroup for all the groups of an XCD upwards, ragged queues (an empty one included), every ring size
+        // the launcher accepts, and FIFOs shorter than the kernel's 64 so that the "no room" branch runs too.  (Sixteen is the
+        // least a FIFO may hold: a lone workgroup must be able to run all sixteen strided halves of a polynomial before the
+        // first contiguous one — with fewer the simulation deadlocks, as it should.)
+        for (u32 W : {1u, 2u, 5u, 16u, 17u, 31u, 64u, 70u})
+            for (u32 G : {1u, 2u, 4u})
+                for (u32 R : {2u, 3u, 6u})
+                    for (u32 cap : {16u, 17u, 64u})
+                        for (u32 shape = 0; shape < 3; shape++) {
+                            std::vector<u32> polys(G);
+                            for (u32 g = 0; g < G; g++) polys[g] = shape == 0 ? 1u + g : shape == 1 ? (g == 0 ? 0u : 7u) : 3u + (rnd() % 9u);
+                            run_variant_e(W, G, polys, R, cap);
+                        }
     }
     std::printf("all persist schedule tests passed\n");
     return 0;

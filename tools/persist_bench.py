@@ -118,6 +118,6 @@ for cfg in [(0, 0, 0, 0)] + cfgs:
         for ph, nm in ((0, "S"), (1, "C")):
             items = max(w[24 + ph], 1)
             tot = sum(w[ph * 12:ph * 12 + 12])
-            prof += f"\n      {nm}: {items} items, {tot / items:.0f} ticks/item: " + ", ".join(f"{n} {w[ph * 12 + i] / items:.0f}" for i, n in enumerate(names))
+            prof += f"\n      {nm}: {items} items, {tot / items:.0f} ticks/item: " + ", ".join(f"{n} {w[ph * 12 + i] / items:.2f}" if 0 < w[ph * 12 + i] / items < 10 else f"{n} {w[ph * 12 + i] / items:.0f}" for i, n in enumerate(names))
     print(f"time batch={batch} {name(cfg)}: {dt*1e3:.3f} ms  {batch/dt/1e6:.3f} M NTT/s  {batch*n*16/dt/8e12:.4f} of 8 TB/s"
           f"  (x 65536/batch = {dt*1e3*65536/batch:.2f} ms per step){prof}", flush=True)

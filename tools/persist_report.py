@@ -23,7 +23,11 @@ head = {
     "B": "# Variant B (ntt_fwd_team_kernel): teams of sixteen workgroups of one XCD take ONE polynomial through both halves; the\n"
          "# intermediate lives in a ring of R polynomial slots per group of sixteen and is read back a few microseconds after it\n"
          "# was written.  Settings: B:R,s (s = start-up stagger between the groups of an XCD): four workgroups per CU; D:R,s: the\n"
-         "# same at TWO workgroups per CU (256 registers, resident twiddle tiles, the next part prefetched into a second register set).\n",
+         "# same at TWO workgroups per CU (256 registers, resident twiddle tiles, the next part prefetched into a second register set);\n"
+         "# E:R,s (ntt_fwd_flow_kernel): the teams without the meeting — a FIFO of pending parts per workgroup, ONE half per iteration, the\n"
+         "# next two halves' loads in flight.  E rows: 'poll' = deciding which half runs (both S and C iterations, charged to S);\n"
+         "# S 'store-barrier' column = how often nothing was decided ahead, S 'next-loads' = ... because the ring slot was still being\n"
+         "# read, C 'poll' = ... because no strided half was fetched, C 'hand-over' = ... and a C half followed (counts per part).\n",
 }
 for v in ("A", "B"):
     with open(os.path.join("profiles", f"{tag}_persist_{v}.txt"), "w") as f:
@@ -35,7 +39,7 @@ for v in ("A", "B"):
                 "#   (A) ; half1 = first four stages incl. the wait for the coefficients; look-ahead = (A) next ticket's control words, (B, S\n"
                 "#   rows) THE TEAM WAIT; gather / round1 / epi-a / next-loads / half2-rest = second half: LDS gather, last four stages,\n"
                 "#   stores or canonical scatter, issuing the next item's loads, store loop; hand-over = ticket bookkeeping.\n\n")
-        for b in two_pass + [b for b in blocks if f" {v}:" in b[0] or (v == "B" and " D:" in b[0])]:
+        for b in two_pass + [b for b in blocks if f" {v}:" in b[0] or (v == "B" and (" D:" in b[0] or " E:" in b[0]))]:
             f.write("\n".join(b) + "\n")
         f.write("\n# ---- HBM-side traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled on gfx950) and\n"
                 "# ---- instruction counters (SQ_*, GRBM_GUI_ACTIVE) per launch: tools/persist_one.py <setting> 8192 3 ----\n")
@@ -43,7 +47,7 @@ for v in ("A", "B"):
         for l in cnt.splitlines():
             if l.startswith("== "):
                 name = l[3:].split(" ")[0].rstrip(":")          # "two-pass", "A:64,1,0", "B:2,1", "D:1,1"
-                on = name == "two-pass" or name[0] == v or (v == "B" and name[0] == "D")
+                on = name == "two-pass" or name[0] == v or (v == "B" and name[0] in "DE")
             if on:
                 keep.append(l[:400])
         f.write("\n".join(keep) + "\n")

@@ -20,6 +20,7 @@ if [ "$2" = "collect" ]; then
   cp $OUT/rq_mul_throughput.txt profiles/${TAG}_rq_mul_throughput.txt
   cp $OUT/ubench_bfly.txt profiles/${TAG}_ubench_bfly.txt
   cp $OUT/bfv_kernels.txt profiles/${TAG}_bfv_kernels.txt
+  cp $OUT/config3_counters_a.json profiles/${TAG}_config3_valu_counters.json 2>/dev/null || true
   grep FHE_EXT32 $OUT/smallq.txt > profiles/${TAG}_small_modulus.txt
   cp $OUT/bench_2ranks.json profiles/${TAG}_bench_2ranks_one_gpu.json 2>/dev/null || true
   cp $OUT/bench_rccl_world1.json profiles/${TAG}_bench_rccl_world1.json 2>/dev/null || true
@@ -28,7 +29,7 @@ if [ "$2" = "collect" ]; then
   cp $OUT/isa_counters_b.json profiles/${TAG}_isa_counters_b.json 2>/dev/null || true
   # the one-launch transform: one report per variant
   python3 tools/persist_report.py $OUT ${TAG} || true
-  for f in bench_persist_A bench_persist_B bench_rank_of_8; do [ -s $OUT/$f.json ] && grep '^{' $OUT/$f.json | tail -1 > profiles/${TAG}_$f.json; done
+  for f in bench_persist_A bench_persist_B bench_persist_E bench_rank_of_8 bench_mg bench_mg_shoup; do [ -s $OUT/$f.json ] && grep '^{' $OUT/$f.json | tail -1 > profiles/${TAG}_$f.json; done
   # JSON evidence files hold the JSON line only (RCCL prints banners on stdout)
   for f in profiles/${TAG}_bench_rccl_world1.json profiles/${TAG}_bench_2ranks_one_gpu.json; do [ -s $f ] && { grep '^{' $f | tail -1 > $f.tmp; mv $f.tmp $f; }; done
   sed -i '/amdgpu.ids/d' profiles/${TAG}_*.txt
@@ -120,9 +121,9 @@ python3 tools/pmc_isa.py $OUT/pmc3_b $OUT/config3_counters_b.json > /dev/null 2>
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt
 
 echo "[8] the one-launch transform (variants A and B): ms per step at three settings each, per-part profile, traffic, counters"; date
-PERSIST_PROFILE=1 timeout -k 10 900 python tools/persist_bench.py 65536 A:16,1,0 A:64,1,0 A:256,1,0 B:1,1 B:2,1 B:4,1 D:1,1 D:2,1 > $OUT/persist_bench.txt 2>&1 || tail -5 $OUT/persist_bench.txt
+PERSIST_PROFILE=1 timeout -k 10 900 python tools/persist_bench.py 65536 A:16,1,0 A:64,1,0 A:256,1,0 B:1,1 B:2,1 B:4,1 D:1,1 D:2,1 E:2,1 E:3,1 E:4,1 E:6,1 > $OUT/persist_bench.txt 2>&1 || tail -5 $OUT/persist_bench.txt
 grep -E "^time|parity:" $OUT/persist_bench.txt || true
-for cfg in two-pass A:64,1,0 B:2,1 D:1,1; do
+for cfg in two-pass A:64,1,0 B:2,1 D:1,1 E:4,1; do
   tag=$(echo $cfg | tr ':,' '__')
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pt_f_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_f_$tag.log 2>&1 || true
   timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pt_w_$tag -o run --output-format csv -- python3 tools/persist_one.py $cfg 8192 3 > $OUT/pt_w_$tag.log 2>&1 || true
@@ -137,8 +138,13 @@ done
 cat $OUT/persist_counters.txt || true
 FHE_NTT_PERSIST=A:64,1,0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_persist_A.json 2> $OUT/bench_persist_A.err || true
 FHE_NTT_PERSIST=B:2,1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_persist_B.json 2> $OUT/bench_persist_B.err || true
+FHE_NTT_PERSIST=E:4,1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_persist_E.json 2> $OUT/bench_persist_E.err || true
+# q = 1 (mod 2^32): the word-Montgomery forward kernels against the Shoup ones on this box (NOT BASELINE's modulus)
+QMG=2305842979148922881
+timeout -k 10 300 python bench.py --q $QMG --no-cpu-baseline > $OUT/bench_mg.json 2> $OUT/bench_mg.err || true
+FHE_MG=0 timeout -k 10 300 python bench.py --q $QMG --no-cpu-baseline > $OUT/bench_mg_shoup.json 2> $OUT/bench_mg_shoup.err || true
 timeout -k 10 300 python bench.py --global-batch 8192 --steps 40 --no-cpu-baseline > $OUT/bench_rank_of_8.json 2> $OUT/bench_rank_of_8.err || true
-for f in bench_persist_A bench_persist_B bench_rank_of_8; do python3 -c "
+for f in bench_persist_A bench_persist_B bench_persist_E bench_rank_of_8 bench_mg bench_mg_shoup; do python3 -c "
 import json
 o=json.loads([l for l in open('$OUT/$f.json') if l.startswith('{')][-1]); print('$f', round(o['value']), o['unit'], 'ms/step', round(o['ms_per_step'],3), 'step_frac', round(o['roofline']['step_frac'],4))" || true; done
 rm -rf $OUT/pmc3_*/*/*.db $OUT/pmc_isa_*/*/*.db $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc4_*/*/*.db $OUT/stats*/*/*.db 2>/dev/null || true

@@ -551,11 +551,14 @@ static int bfv32_args(uint64_t n, fhe::Bfv32Args *a) {
     }
     return FHE_OK;
 }
-// Opt-in (FHE_BFV_SMALL_F64=1): bit-identical (tests/test_round3_gpu.py) and ~90 instructions shorter per coefficient, but
-// measured SLOWER inside the block kernels (tensor 954 vs 854 us, relinearisation 962 vs 899 us per 2048 pairs): the shorter
-// epilogue lets the compiler keep more of it in flight and the kernels, already at their 128 registers, spill more.
+// Zq::from_f64 in f64 alone where every scaled coefficient stays below 2^50 (bfv32.hip: zq_from_f64_small): bit-identical
+// (tests/test_round3_gpu.py) and ~90 instructions shorter per coefficient.  Round 3 measured it SLOWER inside the block
+// kernels (tensor 954 vs 854 us per 2048 pairs: the shorter epilogue made kernels that were already spilling spill more)
+// and left it opt-in; with the residues parked outside the registers (round 4: no scratch in either form) it is the
+// faster one — tensor 867 -> 821 us, relinearisation 815 -> 796 us, VALU instructions per wave 8120 -> 6946 / 11297 -> 10133
+// (gpurun_out/bfv/small*.json) — and the default.  FHE_BFV_SMALL_F64=0 selects the general conversion.
 static bool bfv32_small_f64_on() {
-    static const bool on = [] { const char *e = getenv("FHE_BFV_SMALL_F64"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char *e = getenv("FHE_BFV_SMALL_F64"); return !(e && e[0] == '0'); }();
     return on;
 }
 static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, void *d_c, size_t batch, hipStream_t st) {
@@ -576,7 +579,7 @@ static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, vo
         const unsigned __int128 vmax = (unsigned __int128)2 * n * (q - 1) * (q - 1);
         a.int_num = (on && t != 0 && vmax * t < ((unsigned __int128)1 << 52)) ? t : 0;
         // Zq::from_f64 in f64 alone (bfv32.hip: zq_from_f64_small) where every scaled coefficient stays below 2^50
-        // (opt-in, see bfv32_small_f64_on)
+        // (the default since round 4, see bfv32_small_f64_on)
         a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 31) && vmax * t / q < ((unsigned __int128)1 << 50)) ? 1u : 0u;
         a.qinvf = 1.0 / (double)q;
     }

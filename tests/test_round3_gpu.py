@@ -518,8 +518,8 @@ def test_zq_from_f64_in_f64_alone_is_the_same_residue():
 @pytest.mark.gpu
 def test_bfv_epilogue_forms_give_the_same_words(pkg, oracle, need_gpu):
     """The tensor / relinearisation epilogues have three forms of Zq::from_f64(round(num * v / den)): f64 with the
-    general saturating conversion (the default: measured fastest inside these kernels), f64 alone (FHE_BFV_SMALL_F64=1,
-    where the scaled coefficients stay below 2^50), and the integer form (FHE_BFV_INT_ROUND=1, tensor only).  Identical ciphertext words on the reference's
+    general saturating conversion (FHE_BFV_SMALL_F64=0; the default until round 4), f64 alone (the default since, where
+    the scaled coefficients stay below 2^50), and the integer form (FHE_BFV_INT_ROUND=1, tensor only).  Identical ciphertext words on the reference's
     parameters and on config 3's, where ~2/q of the coefficients sit next to a half-integer boundary; RLWE::mul
     covers the relinearisation's epilogue."""
     code = (
@@ -538,7 +538,7 @@ def test_bfv_epilogue_forms_give_the_same_words(pkg, oracle, need_gpu):
         "    for x in list(c) + list(o): h.update(np.ascontiguousarray(x).tobytes())\n"
         "    print('digest', q, n, h.hexdigest())\n" % ROOT)
     outs = {}
-    for name, extra in (("general", {}), ("f64", {"FHE_BFV_SMALL_F64": "1"}), ("int", {"FHE_BFV_INT_ROUND": "1"})):
+    for name, extra in (("general", {"FHE_BFV_SMALL_F64": "0"}), ("f64", {"FHE_BFV_SMALL_F64": "1"}), ("int", {"FHE_BFV_INT_ROUND": "1"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, name + r.stdout + r.stderr

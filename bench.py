@@ -49,6 +49,9 @@ VALU_PEAK_GBFLY = 2018.7
 # the five-multiply butterfly of pseudo-Mersenne moduli (zq_device.hpp: ct_bfly_pm), which the headline modulus runs:
 # tools/ubench_bfly.hip v18 (13 instructions, round 4) at 8 waves per SIMD, profiles/r04_ubench_bfly.txt
 VALU_PEAK_GBFLY_PM = 2837.2
+# the word-Montgomery butterfly of moduli q = 1 (mod 2^32) (zq_device.hpp: ct_bfly_mg; forward transforms only): tools/ubench_bfly.hip
+# v14 at 8 waves per SIMD, profiles/r04_ubench_bfly.txt (v14 is the statement-per-instruction form of it: a lower bound of the peak)
+VALU_PEAK_GBFLY_MG = 2219.9
 # the 32-bit butterfly of the small-prime kernels (digit32.hip / bfv32.hip): tools/ubench_bfly.hip v13, registers only
 VALU_PEAK_GBFLY32 = 5730.0
 # HBM traffic per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
@@ -428,7 +431,8 @@ def main():
         step_achieved = per_gpu * W["alg_bytes_per_unit"] / 1e9      # the whole step, algorithmic GB/s per GPU
         small = W.get("bfly_bits", 64) == 32
         pm = W.get("arith") == 2
-        valu_peak = VALU_PEAK_GBFLY32 if small else VALU_PEAK_GBFLY_PM if pm else VALU_PEAK_GBFLY
+        mg = W.get("arith") == 5                                   # FHE_ARITH_MONTGOMERY (public numbering)
+        valu_peak = VALU_PEAK_GBFLY32 if small else VALU_PEAK_GBFLY_PM if pm else VALU_PEAK_GBFLY_MG if mg else VALU_PEAK_GBFLY
         roofline = {
             "bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": step_achieved / HBM_PEAK_GBS, "traffic": None,
@@ -444,9 +448,11 @@ def main():
                      "butterflies_per_unit": W["bfly_per_unit"],
                      "butterfly": ("32-bit words modulo 27-bit primes (6 instructions)" if small else
                                    "64-bit words modulo a pseudo-Mersenne q = 2^k - delta (split multiplicand, 5 multiplies, 13 instructions)" if pm else
+                                   "64-bit words modulo q = 1 (mod 2^32) (split multiplicand + one Montgomery word step, 5 multiplies; forward transforms)" if mg else
                                    "64-bit words modulo q < 2^61 (Shoup, 10 multiplies)"),
                      "peak_source": ("tools/ubench_bfly.hip v13 (registers only), profiles/r02_ubench_bfly.txt" if small else
                                      "tools/ubench_bfly.hip v18 (production butterfly, registers only), profiles/r04_ubench_bfly.txt" if pm else
+                                     "tools/ubench_bfly.hip v14 (registers only; the kernels run its one-statement form), profiles/r04_ubench_bfly.txt" if mg else
                                      "tools/ubench_bfly.hip v8 (production butterfly, registers only), profiles/r01_ubench_bfly.txt")},
         }
         if dom and W["pass_bytes_per_launch_per_unit"]:

@@ -151,8 +151,13 @@ static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
         }
     }
     // q = qh 2^32 + 1 below 2^61 (zq_device.hpp, word Montgomery): the forward transforms run on {w 2^32, w 2^64 mod q}
-    if ((q & 0xffffffffull) == 1ull && (q >> 32) != 0 && (q >> 61) == 0 && p->mod.pm_k == 0)
+    if ((q & 0xffffffffull) == 1ull && (q >> 32) != 0 && (q >> 61) == 0 && p->mod.pm_k == 0) {
         p->mod.mg_nqh = (uint32_t)(0u - (uint32_t)(q >> 32));
+        p->ninv_mg.w = mulmod(p->ninv.w, 1ull << 32, q);
+        p->ninv_mg.wp = mulmod(p->ninv_mg.w, 1ull << 32, q);
+        p->s_ninv_mg.w = mulmod(p->s_ninv.w, 1ull << 32, q);
+        p->s_ninv_mg.wp = mulmod(p->s_ninv_mg.w, 1ull << 32, q);
+    }
     return FHE_OK;
 }
 
@@ -303,17 +308,22 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
                 return hip_fail(e, "uploading the pseudo-Mersenne twiddle tables");
             }
         }
-        // q = 1 (mod 2^32): the forward table in word-Montgomery form {w 2^32, w 2^64 mod q}
-        fhe::Tw *mf = nullptr;
+        // q = 1 (mod 2^32): both tables in word-Montgomery form {w 2^32, w 2^64 mod q}
+        fhe::Tw *mf = nullptr, *mi = nullptr;
         if (plan->mod.mg_nqh != 0) {
             for (u64 k = 0; k < n; k++) {
                 f[k].w = mulmod(plan->roots[k], 1ull << 32, q);
                 f[k].wp = mulmod(f[k].w, 1ull << 32, q);
+                i[k].w = mulmod(plan->roots_inv[k], 1ull << 32, q);
+                i[k].wp = mulmod(i[k].w, 1ull << 32, q);
             }
             e = hipMalloc((void **)&mf, n * sizeof(fhe::Tw));
+            if (e == hipSuccess) e = hipMalloc((void **)&mi, n * sizeof(fhe::Tw));
             if (e == hipSuccess) e = hipMemcpy(mf, f.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(mi, i.data(), n * sizeof(fhe::Tw), hipMemcpyHostToDevice);
             if (e != hipSuccess) {
                 if (mf) (void)hipFree(mf);
+                if (mi) (void)hipFree(mi);
                 if (sf) (void)hipFree(sf);
                 if (si) (void)hipFree(si);
                 (void)hipFree(df); (void)hipFree(di);
@@ -322,6 +332,7 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
             }
         }
         t.tw_fwd_mg = mf;
+        t.tw_inv_mg = mi;
         t.tw_fwd_pm = pf;
         t.tw_inv_pm = pi;
         t.tw_fwd = df;
@@ -347,6 +358,9 @@ int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp) {
     dp->s_ninv_pm = plan->s_ninv_pm;
     dp->arith = (plan->q >> 62) ? fhe::kArStrict63 : (t.tw_fwd_pm && fhe_pm_enabled()) ? fhe::kArPMersenne : dp->wide ? fhe::kArWide61 : fhe::kArShoup62;
     dp->tw_fwd_mg = fhe_mg_enabled() ? t.tw_fwd_mg : nullptr;
+    dp->tw_inv_mg = fhe_mg_enabled() ? t.tw_inv_mg : nullptr;
+    dp->ninv_mg = plan->ninv_mg;
+    dp->s_ninv_mg = plan->s_ninv_mg;
     return FHE_OK;
 }
 
@@ -1250,6 +1264,7 @@ extern "C" int fhe_ntt_shutdown(void) {
             if (t.tw32_fwd) (void)hipFree(t.tw32_fwd);
             if (t.tw32_inv) (void)hipFree(t.tw32_inv);
             if (t.tw_fwd_mg) (void)hipFree(t.tw_fwd_mg);
+            if (t.tw_inv_mg) (void)hipFree(t.tw_inv_mg);
             if (t.tw_fwd_pm) (void)hipFree(t.tw_fwd_pm);
             if (t.tw_inv_pm) (void)hipFree(t.tw_inv_pm);
             if (t.twc_pm) (void)hipFree(t.twc_pm);

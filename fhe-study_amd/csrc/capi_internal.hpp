@@ -18,7 +18,7 @@ struct DeviceTables {
     fhe::u64 *digit_lut = nullptr;   // 136 words, n >= 8 (ntt_rounds.hpp: round0_bits)
     fhe::Tw32 *tw32_fwd = nullptr, *tw32_inv = nullptr;   // small moduli (smallq.hip)
     fhe::Tw *tw_fwd_pm = nullptr, *tw_inv_pm = nullptr;   // pseudo-Mersenne moduli: {w, w 2^32 mod q} (zq_device.hpp)
-    fhe::Tw *tw_fwd_mg = nullptr;                          // q = 1 (mod 2^32) below 2^61: {w 2^32, w 2^64 mod q}, forward only
+    fhe::Tw *tw_fwd_mg = nullptr, *tw_inv_mg = nullptr;   // q = 1 (mod 2^32) below 2^61: {w 2^32, w 2^64 mod q}
     fhe::Tw *twc_pm = nullptr;   // the one-launch transform's lane-ordered table of the last four stages (ntt_persist.hip), built on first use
     bool ready = false;
 };
@@ -30,6 +30,7 @@ struct fhe_ntt_plan {
     fhe::Mod mod{};
     fhe::Tw ninv{}, s_ninv{};
     fhe::Tw ninv_pm{}, s_ninv_pm{};   // the same two constants as {w, w 2^32 mod q} when mod.pm_k != 0
+    fhe::Tw ninv_mg{}, s_ninv_mg{};   // ... as {w 2^32, w 2^64 mod q} when mod.mg_nqh != 0
     mutable std::mutex dev_lock;
     mutable DeviceTables dev[kMaxDevices];
 };

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
 template <int LP, bool FINAL, bool MUL_IN, int AR>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassArgs a) {
     constexpr bool WIDE = AR == 1;
+    static_assert(!(AR == 4 && MUL_IN), "a variable x variable product has no Montgomery table: the fused product runs on the Shoup tables");
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     // contiguous bytes, whole lines, so the non-temporal hint applies — and transposed through LDS into the register window;
     // the pointwise product of a fused multiply is formed (and its evals stored) in that layout, position by position.
     // Otherwise: 8 x 16 B per lane straight into registers (a line arrives in pieces; the cache merges them).
-    constexpr bool TLOAD = FHE_INV_TLOAD && !FINAL && AR == 2;
+    constexpr bool TLOAD = FHE_INV_TLOAD && !FINAL && (AR == 2 || AR == 4);
     u64 v[16];
     if constexpr (TLOAD) {
         const u64 *__restrict__ pin = a.in + ubase;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
             const u32 e = i * C::TH + tid, wu = e >> LP, f = e & (C::M - 1);
             const u32 o = (((wu < live ? wu : 0u) << a.log_n) + f) * 8u;
             u64 x = ld_at<u64>(pin, o);
-            if constexpr (MUL_IN) {
+            if constexpr (MUL_IN && AR == 2) {
                 const u64 y = ld_at<u64>(a.in2 + ubase, o);
                 x = mul_var_pm(x, y, a.mod);                     // both canonical: five multiplies
                 if (a.out2) {
@@ -231,13 +232,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     }
 
     // inputs are canonical (evals, or their product); a non-FINAL pass hands values below 4q (WIDE) / 2q on
-    if constexpr (AR == 2) inv_rounds_contig_pm<LP, FINAL, !TLOAD, (MUL_IN ? kPmMul : kPmOne)>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    if constexpr (AR == 2 || AR == 4) inv_rounds_contig_pm<LP, FINAL, !TLOAD, (MUL_IN ? kPmMul : kPmOne), AR>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_contig<LP, WIDE, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
 
     if (active) {
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : canon2(v[k], m));
+            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m));   // AR == 4: products, below 3q
     }
 }
 
@@ -578,21 +579,21 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     // the contiguous pass before this one hands values below 4q (WIDE) / 2q: every round starts from 4
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
-        if constexpr (AR == 2) round_inv_pm<4, false, kPmInvBound, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        if constexpr (AR == 2 || AR == 4) round_inv_pm<4, false, ar_inv_bound(AR), false, AR>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         else round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::a_of(1), true>(v, lds, c, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
-        if constexpr (AR == 2) round_inv_pm<4, false, kPmInvBound, false>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
+        if constexpr (AR == 2 || AR == 4) round_inv_pm<4, false, ar_inv_bound(AR), false, AR>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         else round_inv_sel<4, false, WIDE, 4>(v, tw, (1u << LS) + (tf >> A), m, a.ninv, a.s_ninv);
         exchange_strided<CW, A, C::A0, (C::NR <= 2)>(v, lds, c, tf);
     }
-    if constexpr (AR == 2) round_inv_pm<C::R0, true, kPmInvBound, true>(v, a.tw, 1u, m, a.ninv, a.s_ninv);   // uniform: scalar loads
+    if constexpr (AR == 2 || AR == 4) round_inv_pm<C::R0, true, ar_inv_bound(AR), true, AR>(v, a.tw, 1u, m, a.ninv, a.s_ninv);   // uniform: scalar loads
     else round_inv_sel<C::R0, true, WIDE, 4>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        st_at(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, AR == 2 ? pm_canon(v[k], m) : canon2(v[k], m));
+        st_at(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m));
 }
 
 // ---------------------------------------------------------------------------
@@ -764,7 +765,17 @@ static hipError_t inv_contig_dispatch_ar(int lp, bool final, bool mul_in, const 
     }
     return hipErrorInvalidValue;
 }
+// the Montgomery tables (AR = 4): plain inverse transforms only (no product in the load)
+static hipError_t inv_contig_dispatch_mg(int lp, bool final, const PassArgs &a, hipStream_t st) {
+    switch (lp) {
+#define X(LP_) case LP_: return final ? launch_inv_contig<LP_, true, false, 4>(a, st) : launch_inv_contig<LP_, false, false, 4>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
 static hipError_t inv_contig_dispatch(int ar, int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st) {
+    if (ar == kArMontgomeryFwd) return mul_in ? hipErrorInvalidValue : inv_contig_dispatch_mg(lp, final, a, st);
     return ar == 2 ? inv_contig_dispatch_ar<2>(lp, final, mul_in, a, st)
          : ar == 1 ? inv_contig_dispatch_ar<1>(lp, final, mul_in, a, st)
                    : inv_contig_dispatch_ar<0>(lp, final, mul_in, a, st);
@@ -781,8 +792,7 @@ static hipError_t strided_dispatch_ar(int la, const PassArgs &a, hipStream_t st,
 }
 template <bool INV>
 static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
-    if constexpr (!INV)
-        if (ar == kArMontgomeryFwd) return strided_dispatch_ar<false, 4>(la, a, st, operands);
+    if (ar == kArMontgomeryFwd) return strided_dispatch_ar<INV, 4>(la, a, st, operands);
     return ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands)
          : ar == 1 ? strided_dispatch_ar<INV, 1>(la, a, st, operands)
                    : strided_dispatch_ar<INV, 0>(la, a, st, operands);
@@ -1016,10 +1026,13 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
     if (p.arith == kArStrict63) return launch_g63_inverse(p, in, in2, evals_out, out, batch, st);
     PassArgs a{};
     const int L = p.log_n;
-    const int ar = L < 4 ? (p.wide ? 1 : 0) : p.arith;
+    // q = 1 (mod 2^32): a plain inverse transform (no product in its load) runs on the word-Montgomery table (AR = 4)
+    const bool mg = L >= 4 && p.tw_inv_mg != nullptr && p.arith == kArWide61 && in2 == nullptr;
+    const int ar = L < 4 ? (p.wide ? 1 : 0) : mg ? (int)kArMontgomeryFwd : p.arith;
     DevicePlan pt = p;
-    pt.arith = ar;
+    pt.arith = mg ? (int)kArWide61 : ar;
     set_tables(a, pt, true);
+    if (mg) { a.tw = p.tw_inv_mg; a.ninv = p.ninv_mg; a.s_ninv = p.s_ninv_mg; }
     if (batch == 0) return hipSuccess;
     if (L < 4) {
         const u64 *src = in;

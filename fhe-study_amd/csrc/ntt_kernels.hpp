@@ -32,9 +32,11 @@ struct DevicePlan {
     const Tw *tw_fwd_pm = nullptr;
     const Tw *tw_inv_pm = nullptr;
     Tw ninv_pm{}, s_ninv_pm{};
-    // q = qh 2^32 + 1 below 2^61 (zq_device.hpp, word Montgomery): the forward transforms run on {w 2^32, w 2^64 mod q};
+    // q = qh 2^32 + 1 below 2^61 (zq_device.hpp, word Montgomery): the plain transforms run on {w 2^32, w 2^64 mod q};
     // nullptr otherwise (or FHE_MG=0).  The plan's arith stays kArWide61: everything else runs the Shoup kernels.
     const Tw *tw_fwd_mg = nullptr;
+    const Tw *tw_inv_mg = nullptr;   // (plain inverse transforms; the fused products keep the Shoup tables)
+    Tw ninv_mg{}, s_ninv_mg{};       // n^-1 and roots_inv[1] n^-1 in the same form
     int arith = 0;      // which kernels the plan's transforms run: kArShoup62 ... kArStrict63 below (the template parameter AR of the kernels)
 };
 
@@ -45,7 +47,7 @@ enum : int {
     kArWide61 = 1,      // q < 2^61: Shoup products, compile-time bounds up to 8q
     kArPMersenne = 2,   // q = 2^k - delta: five-multiply butterflies on {w, w 2^32 mod q}
     kArStrict63 = 3,    // 2^62 <= q < 2^63: strict butterflies in plain kernels (generic63.hip)
-    kArMontgomeryFwd = 4,   // never a plan's arith: what launch_ntt_forward passes its kernels when tw_fwd_mg is set (q = 1 mod 2^32)
+    kArMontgomeryFwd = 4,   // never a plan's arith: what launch_ntt_forward / launch_ntt_inverse pass their kernels when tw_*_mg are set (q = 1 mod 2^32)
 };
 
 struct PassArgs {

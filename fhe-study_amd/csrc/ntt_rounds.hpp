@@ -248,7 +248,8 @@ struct PmInvSched {
     unsigned char fin[16];    // final reduction of the register
 };
 constexpr bool pm_gs_fits(int bx, int by) { return bx + by <= kPmCap && bx + kPmOne * ((by + kPmOne - 1) / kPmOne) <= kPmCap; }
-constexpr PmInvSched pm_inv_sched(int R, int bin, bool fold, int bout) {
+constexpr PmInvSched pm_inv_sched(int R, int bin, bool fold, int bout, int ak = 2) {
+    const int kRed = ak == 4 ? kMgRed : kPmRed, kMul = ak == 4 ? kMgMul : kPmMul;      // AK = 4: the word-Montgomery butterflies
     PmInvSched s{};
     int B[16] = {};
     for (int k = 0; k < 16; k++) B[k] = bin;
@@ -262,27 +263,30 @@ constexpr PmInvSched pm_inv_sched(int R, int bin, bool fold, int bout) {
                 int bx = B[k], by = B[k2];
                 bool rx = false, ry = false;
                 if (!pm_gs_fits(bx, by)) {
-                    if (bx >= by) { rx = true; bx = kPmRed; } else { ry = true; by = kPmRed; }
+                    if (bx >= by) { rx = true; bx = kRed; } else { ry = true; by = kRed; }
                 }
                 if (!pm_gs_fits(bx, by)) {
-                    if (!rx) { rx = true; bx = kPmRed; } else { ry = true; by = kPmRed; }
+                    if (!rx) { rx = true; bx = kRed; } else { ry = true; by = kRed; }
                 }
                 s.rx[st][j] = rx;
                 s.ry[st][j] = ry;
                 s.ky[st][j] = (unsigned char)((by + kPmOne - 1) / kPmOne);
-                B[k] = (fold && i == 0) ? kPmMul : bx + by;
-                B[k2] = kPmMul;
+                B[k] = (fold && i == 0) ? kMul : bx + by;
+                B[k2] = kMul;
             }
     }
     for (int k = 0; k < 16; k++) s.fin[k] = B[k] > bout;
     return s;
 }
 constexpr int kPmInvBound = 33;   // what an inverse round (and pass) hands on: products are below it as they are
+constexpr int kMgInvBound = 64;   // ... on the Montgomery tables: what a conditional subtraction of 4q leaves (products: 48)
+constexpr int ar_inv_bound(int ak) { return ak == 4 ? kMgInvBound : kPmInvBound; }
 
-template <int R, bool FOLD, int BIN, bool SGPR_TW>
+template <int R, bool FOLD, int BIN, bool SGPR_TW, int AK = 2>
 __device__ __forceinline__ void round_inv_pm(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
                                              const Tw ninv, const Tw s_ninv) {
-    constexpr PmInvSched S = pm_inv_sched(R, BIN, FOLD, kPmInvBound);
+    static_assert(AK == 2 || AK == 4, "pseudo-Mersenne or word-Montgomery tables");
+    constexpr PmInvSched S = pm_inv_sched(R, BIN, FOLD, ar_inv_bound(AK), AK);
     int st = 0;
 #pragma unroll
     for (int i = R - 1; i >= 0; i--, st++) {
@@ -295,13 +299,20 @@ __device__ __forceinline__ void round_inv_pm(u64 (&v)[16], const Tw *__restrict_
             for (int l = 0; l < span; l++) {
                 const int k = g * 2 * span + l, j = g * span + l;
                 u64 x = v[k], y = v[k + span];
-                if (S.rx[st][j]) x = pm_reduce(x, m);
-                if (S.ry[st][j]) y = pm_reduce(y, m);
+                if (S.rx[st][j]) x = AK == 4 ? csub_neg(x, m.neg4q) : pm_reduce(x, m);
+                if (S.ry[st][j]) y = AK == 4 ? csub_neg(y, m.neg4q) : pm_reduce(y, m);
                 const u64 kq1 = (u64)S.ky[st][j] * m.q + 1ull;
                 if (FOLD && i == 0) {
                     const u64 s = x + y, d = x + kq1 + ~y;
-                    x = mul_pm<true>(s, ninv.w, ninv.wp, m);        // kernel arguments: wave-uniform
-                    y = mul_pm<true>(d, s_ninv.w, s_ninv.wp, m);
+                    if constexpr (AK == 4) {
+                        x = mul_mg<true>(s, ninv.w, ninv.wp, m);    // kernel arguments: wave-uniform
+                        y = mul_mg<true>(d, s_ninv.w, s_ninv.wp, m);
+                    } else {
+                        x = mul_pm<true>(s, ninv.w, ninv.wp, m);
+                        y = mul_pm<true>(d, s_ninv.w, s_ninv.wp, m);
+                    }
+                } else if constexpr (AK == 4) {
+                    gs_bfly_mg<SGPR_TW>(x, y, t.w, t.wp, kq1, m);
                 } else {
                     gs_bfly_pm<SGPR_TW>(x, y, t.w, t.wp, kq1, m);
                 }
@@ -312,7 +323,7 @@ __device__ __forceinline__ void round_inv_pm(u64 (&v)[16], const Tw *__restrict_
     }
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        if (S.fin[k]) v[k] = pm_reduce(v[k], m);
+        if (S.fin[k]) v[k] = AK == 4 ? csub_neg(v[k], m.neg4q) : pm_reduce(v[k], m);
 }
 
 // ---- round 0 of a transform whose inputs are BITS (gadget digits, base 2) -------------------------
@@ -587,7 +598,7 @@ __device__ __forceinline__ void fwd_rounds_contig_pm(u64 (&v)[16], u64 *lds, con
 
 // BFIRST: bound (sixteenths of q) of what the first round that runs receives: canonical evals from memory (kPmOne), or
 // the lazy pointwise product formed in registers (kPmMul)
-template <int LP, bool FOLD, bool FRESH, int BFIRST = kPmOne>
+template <int LP, bool FOLD, bool FRESH, int BFIRST = kPmOne, int AK = 2>
 __device__ __forceinline__ void inv_rounds_contig_pm(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
                                                      u32 w, u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
     using C = ContigCfg<LP>;
@@ -595,26 +606,26 @@ __device__ __forceinline__ void inv_rounds_contig_pm(u64 (&v)[16], u64 *lds, con
     auto T0 = [&](bool lds_round, int ls, u32 H) -> u32 {
         return lds_round ? (1u << ls) + H : (1u << (s0 + ls)) + (blk << ls) + H;
     };
-    constexpr int BF = BFIRST, BN = kPmInvBound;
+    constexpr int BF = BFIRST, BN = ar_inv_bound(AK);
     if constexpr (C::NR > 3) {
         constexpr int A = C::a_of(3), LS = C::ls0_of(3);
         constexpr bool L = C::in_lds(3);
-        round_inv_pm<4, false, BF, false>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        round_inv_pm<4, false, BF, false, AK>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
         exchange_contig<LP, A, C::a_of(2), FRESH>(v, lds, w, tf);
     }
     if constexpr (C::NR > 2) {
         constexpr int A = C::a_of(2), LS = C::ls0_of(2);
         constexpr bool L = C::in_lds(2);
-        round_inv_pm<4, false, (C::NR == 3 ? BF : BN), false>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        round_inv_pm<4, false, (C::NR == 3 ? BF : BN), false, AK>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
         exchange_contig<LP, A, C::a_of(1), FRESH && (C::NR <= 3)>(v, lds, w, tf);
     }
     if constexpr (C::NR > 1) {
         constexpr int A = C::a_of(1), LS = C::ls0_of(1);
         constexpr bool L = C::in_lds(1);
-        round_inv_pm<4, false, (C::NR == 2 ? BF : BN), false>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
+        round_inv_pm<4, false, (C::NR == 2 ? BF : BN), false, AK>(v, TW(L), T0(L, LS, tf >> A), m, ninv, s_ninv);
         exchange_contig<LP, A, C::A0, FRESH && (C::NR <= 2)>(v, lds, w, tf);
     }
-    round_inv_pm<C::R0, FOLD, (C::NR == 1 ? BF : BN), true>(v, gtw, (1u << s0) + blk, m, ninv, s_ninv);
+    round_inv_pm<C::R0, FOLD, (C::NR == 1 ? BF : BN), true, AK>(v, gtw, (1u << s0) + blk, m, ninv, s_ninv);
 }
 
 // ---------------------------------------------------------------------------

@@ -313,11 +313,13 @@ __device__ __forceinline__ void gs_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, u64 kq
 // is one more multiply (by 2^32 - qh, then T0 taken off the high word) and an addition: nine instructions, as the
 // pseudo-Mersenne product.  What it lacks is that form's cheap reduction: values come down by a conditional subtraction
 // of 4q (four instructions, to below 4q) before every stage from the third on, so a forward butterfly averages ~16.5
-// instructions against ~14.5 — and against the ~21 of the Shoup form these moduli ran on.  FORWARD transforms only: an
-// inverse stage would need up to two such subtractions per butterfly (x + y of two values below 4q is at the cap), and a
-// variable x variable product has no table; those keep the Shoup kernels (same words either way).
+// instructions against ~14.5 — and against the ~21 of the Shoup form these moduli ran on.  An inverse stage needs 0.8 such
+// subtractions per butterfly (x + y of two values below 4q is at the cap: ntt_rounds.hpp follows the bounds register by
+// register): ~15.3 instructions against ~20.  A variable x variable product has no table: the fused products keep the
+// Shoup kernels (same words either way).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kMgRed = 64;    // sixteenths of q: after the conditional subtraction of 4q (for values below 8q)
+constexpr int kMgMul = 48;    // a product: below 3q
 #define FHE_MG_PRODUCT(Y0, Y1, OUT)                                                                    \
     "v_mad_u64_u32 v[2:3], vcc, " Y0 ", %[a0], 0\n\t"                                                  \
     "v_mad_u64_u32 v[2:3], vcc, " Y1 ", %[b0], v[2:3]\n\t"      /* carry -> vcc */                    \
@@ -356,6 +358,53 @@ __device__ __forceinline__ void ct_bfly_mg(u64 &x, u64 &y, u64 wa, u64 wb, const
             : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
 #undef FHE_MG_CT_BODY
     y = ((u64)yh << 32) | yl;
+}
+
+// y * w mod q on the Montgomery table words {wa = w 2^32, wb = w 2^64 mod q}: in (0, 3q), for any 64-bit y
+template <bool SGPR_TW>
+__device__ __forceinline__ u64 mul_mg(u64 y, u64 wa, u64 wb, const Mod &m) {
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+    const u32 a0 = (u32)wa, a1 = (u32)(wa >> 32), b0 = (u32)wb, b1 = (u32)(wb >> 32);
+    u64 r;
+    if constexpr (SGPR_TW)
+        asm(FHE_MG_PRODUCT("%[y0]", "%[y1]", "%[r]")
+            : [r] "=&v"(r)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1), [nqh] "s"(m.mg_nqh), [qq] "s"(m.q)
+            : "vcc", "v2", "v3", "v6", "v7");
+    else
+        asm(FHE_MG_PRODUCT("%[y0]", "%[y1]", "%[r]")
+            : [r] "=&v"(r)
+            : [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [nqh] "s"(m.mg_nqh), [qq] "s"(m.q)
+            : "vcc", "v2", "v3", "v6", "v7");
+    return r;
+}
+// Inverse butterfly on the Montgomery table: x' = x + y, y' = (x - y + K q) w as gs_bfly_pm (the product below 3q)
+template <bool SGPR_TW>
+__device__ __forceinline__ void gs_bfly_mg(u64 &x, u64 &y, u64 wa, u64 wb, u64 kq1, const Mod &m) {
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+    const u32 a0 = (u32)wa, a1 = (u32)(wa >> 32), b0 = (u32)wb, b1 = (u32)(wb >> 32);
+    const u64 kq = kq1 - 1ull;
+    u64 yo;
+#define FHE_MG_GS_BODY                                                                                 \
+    "v_lshl_add_u64 v[4:5], %[x], 0, %[kq]\n\t"                                                        \
+    "v_sub_co_u32 v4, vcc, v4, %[y0]\n\t"                                                              \
+    "v_subb_co_u32 v5, vcc, v5, %[y1], vcc\n\t"                  /* d = x + K q - y */                 \
+    "v_lshl_add_u64 %[x], %[x], 0, %[y]\n\t"                     /* x' = x + y */                      \
+    FHE_MG_PRODUCT("v4", "v5", "%[yo]")
+    if constexpr (SGPR_TW)
+        asm(FHE_MG_GS_BODY
+            : [x] "+&v"(x), [yo] "=v"(yo)
+            : [y] "v"(y), [y0] "v"(y0), [y1] "v"(y1), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0), [b1] "s"(b1),
+              [nqh] "s"(m.mg_nqh), [qq] "s"(m.q), [kq] "s"(kq)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
+    else
+        asm(FHE_MG_GS_BODY
+            : [x] "+&v"(x), [yo] "=v"(yo)
+            : [y] "v"(y), [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1),
+              [nqh] "s"(m.mg_nqh), [qq] "s"(m.q), [kq] "s"(kq)
+            : "vcc", "v2", "v3", "v4", "v5", "v6", "v7");
+#undef FHE_MG_GS_BODY
+    y = yo;
 }
 #undef FHE_MG_PRODUCT
 

@@ -178,8 +178,8 @@ QMG61, QMG50, QMG40 = 0x1ffffff900000001, 0x3fff300000001, 0xff00000001
                                  (QMG50, 1 << 16), (QMG40, 16), (QMG40, 1024), (QMG40, 1 << 14)])
 def test_montgomery_forward_is_the_oracles_transform(pkg, oracle, need_gpu, q, n):
     """NTT::ntt (arith/src/ntt.rs:44-73) for q = qh 2^32 + 1 below 2^61: the forward kernels run the word-Montgomery
-    butterfly (plan arithmetic 5), the inverse ones the Shoup form — the words are the oracle's in both directions, on
-    zeros, on q - 1 everywhere (the largest values every bound has to hold for) and on ragged batches."""
+    butterflies (plan arithmetic 5) in both directions — the words are the oracle's, on zeros, on q - 1 everywhere (the
+    largest values every bound has to hold for) and on ragged batches."""
     import os
 
     plan = pkg.Plan(q, n)
@@ -189,6 +189,8 @@ def test_montgomery_forward_is_the_oracles_transform(pkg, oracle, need_gpu, q, n
     A = plan.forward(a)
     assert np.array_equal(A.reshape(-1), oracle.ntt(q, n, a).reshape(-1)), (hex(q), n)
     assert np.array_equal(plan.inverse(A).reshape(-1), a.reshape(-1)), (hex(q), n)
+    # NTT::intt (ntt.rs:78-110) on the same rows taken as evaluations — zeros and q - 1 everywhere among them
+    assert np.array_equal(plan.inverse(a).reshape(-1), oracle.intt(q, n, a).reshape(-1)), (hex(q), n)
 
 
 @pytest.mark.gpu

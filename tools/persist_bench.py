@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/persist_bench.py — the one-launch n = 2^16 forward transform (csrc/ntt_persist.hip) against the two-pass kernels:
-word-for-word comparison on small / ragged batches, then timings over a list of (tile, lag, ring) settings.
-usage: python tools/persist_bench.py [batch] [A:T,L,R | B:R ...]       (diagnostic; not the contract bench)"""
+word-for-word comparison on small / ragged batches and from 1 / 7 / 20 / 100 workgroups, then timings over a list of settings
+(PERSIST_PROFILE=1: lane 0's shader-clock ticks per part of an iteration as well).
+usage: python tools/persist_bench.py [batch] [A:T,L,R | B:R[,s] | D:R[,s] | E:R[,s] ...]       (diagnostic; not the contract bench)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

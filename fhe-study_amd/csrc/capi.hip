@@ -153,6 +153,8 @@ static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
     // q = qh 2^32 + 1 below 2^61 (zq_device.hpp, word Montgomery): the forward transforms run on {w 2^32, w 2^64 mod q}
     if ((q & 0xffffffffull) == 1ull && (q >> 32) != 0 && (q >> 61) == 0 && p->mod.pm_k == 0) {
         p->mod.mg_nqh = (uint32_t)(0u - (uint32_t)(q >> 32));
+        p->mod.mg_r96 = mulmod(p->mod.r64, 1ull << 32, q);
+        p->mod.mg_r128 = mulmod(p->mod.r64, p->mod.r64, q);
         p->ninv_mg.w = mulmod(p->ninv.w, 1ull << 32, q);
         p->ninv_mg.wp = mulmod(p->ninv_mg.w, 1ull << 32, q);
         p->s_ninv_mg.w = mulmod(p->s_ninv.w, 1ull << 32, q);

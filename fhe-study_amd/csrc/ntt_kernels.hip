@@ -333,11 +333,11 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = ld_c<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
-            if constexpr (AR == 2) {   // canonical only where the evals are an output (see the product below)
-                fwd_rounds_contig_pm<LP, kPmOne, decltype(fresh)::value>(v, lds, ltw_f, a.tw, 0u, 0u, w, tf, m);
+            if constexpr (AR == 2 || AR == 4) {   // canonical only where the evals are an output (see the product below)
+                fwd_rounds_contig_pm<LP, kPmOne, decltype(fresh)::value, AR>(v, lds, ltw_f, a.tw, 0u, 0u, w, tf, m);
                 if (keep) {
 #pragma unroll
-                    for (int k = 0; k < 16; k++) v[k] = pm_canon(v[k], m);
+                    for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : canon8(v[k], m);
                 }
             } else {
                 fwd_rounds_single<LP, WIDE, decltype(fresh)::value>(v, lds, ltw_f, a.tw, w, tf, m);
@@ -364,6 +364,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
 #pragma unroll
             for (int k = 0; k < 16; k++) va[k] = pm_canon(va[k], m);
         }
+    } else if constexpr (AR == 4) {   // q = 1 (mod 2^32): lazy operands below 7q, the product below 3q (zq_device.hpp: mul_var_mg)
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = mul_var_mg(va[k], vb[k], m);
+        if (a.out2) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) va[k] = canon4(va[k], m);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
@@ -371,12 +378,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
     store_evals(a.out2, va);
     if constexpr (C::NR == 1) { /* twiddles published above */ } else if (a.flags == 3u) __syncthreads();   // no forward exchange ran
     if constexpr (AR == 2) inv_rounds_contig_pm<LP, true, false, kPmMul>(va, lds, ltw_i, a.tw_inv, 0u, 0u, w, tf, m, a.ninv, a.s_ninv);
+    else if constexpr (AR == 4) inv_rounds_contig_pm<LP, true, false, kMgMul, 4>(va, lds, ltw_i, a.tw_inv, 0u, 0u, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_single<LP, WIDE>(va, lds, ltw_i, a.tw_inv, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, AR == 2 ? pm_canon(va[k], m) : canon2(va[k], m));
+            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, AR == 2 ? pm_canon(va[k], m) : AR == 4 ? canon4(va[k], m) : canon2(va[k], m));
     }
 }
 
@@ -440,11 +448,11 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     };
     auto operand = [&](bool is_evals, bool keep, u64 (&v)[16], auto fresh) {
         if (!is_evals) {
-            if constexpr (AR == 2) fwd_rounds_contig_pm<LP, kPmPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
+            if constexpr (AR == 2 || AR == 4) fwd_rounds_contig_pm<LP, kPmPassBound, decltype(fresh)::value, AR>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
             else fwd_rounds_contig<LP, WIDE, true, kPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
             if (keep) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : canon4(v[k], m);
+                for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon8(v[k], m) : canon4(v[k], m);
             }
         }
     };
@@ -472,6 +480,13 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
 #pragma unroll
             for (int k = 0; k < 16; k++) va[k] = pm_canon(va[k], m);
         }
+    } else if constexpr (AR == 4) {   // as in rq_mul_fused_kernel
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = mul_var_mg(va[k], vb[k], m);
+        if (a.out2) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) va[k] = canon4(va[k], m);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
@@ -479,6 +494,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     store_evals(a.out2, va);
     __syncthreads();                     // the inverse tile is in place (the first inverse round reads it before any exchange)
     if constexpr (AR == 2) inv_rounds_contig_pm<LP, false, false, kPmMul>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
+    else if constexpr (AR == 4) inv_rounds_contig_pm<LP, false, false, kMgMul, 4>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     else inv_rounds_contig<LP, WIDE, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
@@ -798,6 +814,9 @@ static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_
                    : strided_dispatch_ar<INV, 0>(la, a, st, operands);
 }
 // the tables and n^-1 constants a pass runs on: {w, w 2^32 mod q} for pseudo-Mersenne plans, {w, floor(w 2^64 / q)} otherwise
+static inline bool plan_runs_montgomery(const DevicePlan &p) {
+    return p.log_n >= 4 && p.tw_fwd_mg != nullptr && p.tw_inv_mg != nullptr && p.arith == kArWide61;
+}
 static inline void set_tables(PassArgs &a, const DevicePlan &p, bool inverse) {
     const bool pm = p.arith == kArPMersenne;
     a.tw = inverse ? (pm ? p.tw_inv_pm : p.tw_inv) : (pm ? p.tw_fwd_pm : p.tw_fwd);
@@ -868,11 +887,13 @@ hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_eva
     PassArgs a{};
     set_tables(a, p, false);
     a.tw_inv = p.arith == kArPMersenne ? p.tw_inv_pm : p.tw_inv;
+    const bool mg = plan_runs_montgomery(p);      // q = 1 (mod 2^32): both transforms and the product on the Montgomery tables
+    if (mg) { a.tw = p.tw_fwd_mg; a.tw_inv = p.tw_inv_mg; a.ninv = p.ninv_mg; a.s_ninv = p.s_ninv_mg; }
     a.in = a_; a.in2 = b_; a.out = c; a.out2 = c_evals; a.out3 = a_evals; a.out4 = b_evals;
     a.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
     a.batch = batch;
     switch (L) {
-#define X(LP_) case LP_: return p.arith == 2 ? launch_rq_mul_fused_lp<LP_, 2>(a, st) : p.arith == 1 ? launch_rq_mul_fused_lp<LP_, 1>(a, st) : launch_rq_mul_fused_lp<LP_, 0>(a, st);
+#define X(LP_) case LP_: return mg ? launch_rq_mul_fused_lp<LP_, 4>(a, st) : p.arith == 2 ? launch_rq_mul_fused_lp<LP_, 2>(a, st) : p.arith == 1 ? launch_rq_mul_fused_lp<LP_, 1>(a, st) : launch_rq_mul_fused_lp<LP_, 0>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
@@ -907,9 +928,11 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
     if (batch_tile == 0) batch_tile = batch;
     for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
         const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile, o = b0 * n;
-        const int ar = p.arith;
+        const bool mg = plan_runs_montgomery(p);
+        const int ar = mg ? (int)kArMontgomeryFwd : p.arith;
         PassArgs f{};
         set_tables(f, p, false); f.batch = nb;
+        if (mg) f.tw = p.tw_fwd_mg;
         hipError_t e = hipSuccess;
         if (!a_is_evals && !b_is_evals) {
             f.in = a_ + o; f.out = wa + o; f.in2 = b_ + o; f.out2 = wb + o;
@@ -924,13 +947,14 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
         if (e != hipSuccess) return e;
         PassArgs m{};
         set_tables(m, p, false); m.tw_inv = ar == 2 ? p.tw_inv_pm : p.tw_inv; m.batch = nb;
+        if (mg) { m.tw = p.tw_fwd_mg; m.tw_inv = p.tw_inv_mg; m.ninv = p.ninv_mg; m.s_ninv = p.s_ninv_mg; }
         m.in = (a_is_evals ? a_ : wa) + o; m.in2 = (b_is_evals ? b_ : wb) + o;
         m.out = c + o; m.out2 = c_evals ? c_evals + o : nullptr;
         m.out3 = (keep_a_evals && !a_is_evals) ? wa + o : nullptr;
         m.out4 = (keep_b_evals && !b_is_evals) ? wb + o : nullptr;
         m.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
         switch (LB) {
-#define X(LP_) case LP_: e = ar == 2 ? launch_rq_mul_mid_lp<LP_, 2>(m, st) : ar == 1 ? launch_rq_mul_mid_lp<LP_, 1>(m, st) : launch_rq_mul_mid_lp<LP_, 0>(m, st); break;
+#define X(LP_) case LP_: e = ar == 4 ? launch_rq_mul_mid_lp<LP_, 4>(m, st) : ar == 2 ? launch_rq_mul_mid_lp<LP_, 2>(m, st) : ar == 1 ? launch_rq_mul_mid_lp<LP_, 1>(m, st) : launch_rq_mul_mid_lp<LP_, 0>(m, st); break;
             X(8) X(9) X(10) X(11) X(12)
 #undef X
             default: return hipErrorInvalidValue;
@@ -938,6 +962,7 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
         if (e != hipSuccess) return e;
         PassArgs i{};
         set_tables(i, p, true); i.batch = nb;
+        if (mg) { i.tw = p.tw_inv_mg; i.ninv = p.ninv_mg; i.s_ninv = p.s_ninv_mg; }
         i.in = c + o; i.out = c + o;
         e = strided_dispatch<true>(ar, LA, i, st);
         if (e != hipSuccess) return e;

@@ -33,9 +33,10 @@ struct DevicePlan {
     const Tw *tw_inv_pm = nullptr;
     Tw ninv_pm{}, s_ninv_pm{};
     // q = qh 2^32 + 1 below 2^61 (zq_device.hpp, word Montgomery): the plain transforms run on {w 2^32, w 2^64 mod q};
-    // nullptr otherwise (or FHE_MG=0).  The plan's arith stays kArWide61: everything else runs the Shoup kernels.
+    // nullptr otherwise (or FHE_MG=0).  The plan's arith stays kArWide61 (what the transforming-load kernels run); the launchers of
+    // the transforms and of Rq x Rq pick the Montgomery kernels (AR = 4) when these are set.
     const Tw *tw_fwd_mg = nullptr;
-    const Tw *tw_inv_mg = nullptr;   // (plain inverse transforms; the fused products keep the Shoup tables)
+    const Tw *tw_inv_mg = nullptr;   // (an inverse transform that multiplies two evaluation operands in its load keeps the Shoup tables)
     Tw ninv_mg{}, s_ninv_mg{};       // n^-1 and roots_inv[1] n^-1 in the same form
     int arith = 0;      // which kernels the plan's transforms run: kArShoup62 ... kArStrict63 below (the template parameter AR of the kernels)
 };

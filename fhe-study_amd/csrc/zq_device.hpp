@@ -57,6 +57,7 @@ struct Mod {
     u32 pm_k;       // k, or 0 when q is not of this form
     // q = qh 2^32 + 1 below 2^61 (see "word Montgomery" below): 2^32 - qh, or 0 when q is not of this form
     u32 mg_nqh;
+    u64 mg_r96, mg_r128;   // 2^96 mod q, 2^128 mod q: the table words of the constant 2^64 (mul_var_mg)
 };
 
 // ---- single-instruction wrappers (register allocation stays with the compiler) ----
@@ -315,8 +316,8 @@ __device__ __forceinline__ void gs_bfly_pm(u64 &x, u64 &y, u64 w, u64 w2, u64 kq
 // of 4q (four instructions, to below 4q) before every stage from the third on, so a forward butterfly averages ~16.5
 // instructions against ~14.5 — and against the ~21 of the Shoup form these moduli ran on.  An inverse stage needs 0.8 such
 // subtractions per butterfly (x + y of two values below 4q is at the cap: ntt_rounds.hpp follows the bounds register by
-// register): ~15.3 instructions against ~20.  A variable x variable product has no table: the fused products keep the
-// Shoup kernels (same words either way).
+// register): ~15.3 instructions against ~20.  A variable x variable product has no table: mul_var_mg below goes through the
+// full 128-bit product instead (28 instructions against ~50).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kMgRed = 64;    // sixteenths of q: after the conditional subtraction of 4q (for values below 8q)
 constexpr int kMgMul = 48;    // a product: below 3q
@@ -407,6 +408,23 @@ __device__ __forceinline__ void gs_bfly_mg(u64 &x, u64 &y, u64 wa, u64 wb, u64 k
     y = yo;
 }
 #undef FHE_MG_PRODUCT
+
+// VARIABLE x VARIABLE on such a modulus (zip_eq(l,r).map(l*r), arith/src/ring_nq.rs:601-604): the full 128-bit product, two
+// Montgomery word steps — each is "drop the low word W and subtract W qh", exact because q = 1 (mod 2^32) — give
+// a b 2^-64 + q in (0, 7.1 q) for a, b < 7q; one table product by the constant 2^64 (words 2^96, 2^128 mod q) brings back the
+// factor: a b mod q in (0, 3q).  Plain C: the compiler emits 19 instructions for the first part; 28 in all against ~50 for the
+// Shoup form (mul_mod_var: two 64-bit quotients).
+__device__ __forceinline__ u64 mul_var_mg(u64 a, u64 b, const Mod &m) {
+    typedef unsigned __int128 u128t;
+    typedef __int128 i128t;
+    const u128t P = (u128t)a * b;
+    const u64 qh = (u64)(0u - m.mg_nqh);
+    const u32 P0 = (u32)(u64)P;
+    const i128t R1 = (i128t)(P >> 32) - (i128t)((u64)P0 * qh);            // (P - P0 q) / 2^32, exactly
+    const u32 R10 = (u32)(u64)R1;
+    const i128t R2 = (R1 >> 32) - (i128t)((u64)R10 * qh);                 // (R1 - R10 q) / 2^32: above -q, below 6.1 q + q / 2^32
+    return mul_mg<true>((u64)R2 + m.q, m.mg_r96, m.mg_r128, m);
+}
 
 // Rust `f64 as i64` (saturating, NaN -> 0)
 __device__ __forceinline__ long long f64_as_i64(double x) {

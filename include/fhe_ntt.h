@@ -107,9 +107,10 @@ int fhe_ntt_plan_prepare(const fhe_ntt_plan *plan);
  *   FHE_ARITH_STRICT63  2^62 <= q < 2^63 (the top of the reference's range, zq.rs:225): 4q no longer fits a word, so
  *                       every value is canonical between stages (three conditional subtractions per butterfly) and a
  *                       transform is ceil(log2 n / 4) plain launches through global memory — exact, not fast
- *   FHE_ARITH_MONTGOMERY q = 1 (mod 2^32), q < 2^61, n >= 16: the plain transforms (forward and inverse) run word-Montgomery
- *                       butterflies on {w 2^32, w 2^64 mod q} — q^-1 = 1 (mod 2^32), so a word step needs no multiplication
- *                       by it: 5 multiplies; the fused products keep SHOUP61's kernels (FHE_MG=0: everything does)
+ *   FHE_ARITH_MONTGOMERY q = 1 (mod 2^32), q < 2^61, n >= 16: transforms and Rq x Rq run word-Montgomery butterflies on
+ *                       {w 2^32, w 2^64 mod q} — q^-1 = 1 (mod 2^32), so a word step needs no multiplication by it: 5
+ *                       multiplies; only the inverse transform that multiplies two evaluation operands in its load keeps
+ *                       SHOUP61's kernel (FHE_MG=0: everything does)
  * Results are the same words in every case.  Returns a negative FHE_E_* for a NULL plan. */
 #define FHE_ARITH_SHOUP62 0
 #define FHE_ARITH_SHOUP61 1

@@ -194,18 +194,31 @@ def test_montgomery_forward_is_the_oracles_transform(pkg, oracle, need_gpu, q, n
 
 
 @pytest.mark.gpu
-def test_montgomery_plans_keep_every_other_entry_point(pkg, oracle, need_gpu):
-    """products (fused at single-pass sizes, two-pass above) and the in-place device entry point on such a modulus"""
+@pytest.mark.parametrize("q,n", [(QMG61, 16), (QMG61, 128), (QMG61, 1024), (QMG61, 8192), (QMG61, 1 << 14), (QMG61, 1 << 16),
+                                 (QMG50, 64), (QMG50, 4096), (QMG50, 1 << 15), (QMG40, 16), (QMG40, 2048), (QMG40, 1 << 14)])
+def test_montgomery_products_are_the_oracles(pkg, oracle, need_gpu, q, n):
+    """Rq x Rq (ring_nq.rs:586-607) on such a modulus — fused at single-pass sizes, strided | middle | strided above — with
+    the variable x variable product on the Montgomery constants (zq_device.hpp: mul_var_mg): c, c_evals, a_evals, b_evals are
+    the oracle's words, on q - 1 everywhere and zeros too, and with operands handed over as evaluations."""
+    plan = pkg.Plan(q, n)
+    batch = 3 if n >= (1 << 14) else 19
+    a, b = _rows(oracle, q, n, batch, 4400 + n), _rows(oracle, q, n, batch, 4500 + n)
+    b[0] = q - 1                                                # (q - 1) x 0, (q - 1) x (q - 1), ...
+    got = plan.rq_mul(a, b)
+    want = oracle.rq_mul(q, n, a, b)
+    for g, w, name in zip(got, want, ("c", "c_evals", "a_evals", "b_evals")):
+        assert np.array_equal(np.asarray(g).reshape(-1), np.asarray(w).reshape(-1)), (hex(q), n, name)
+    A, B_ = want[2], want[3]
+    for flags, x, y in (((True, False), A, b), ((False, True), a, B_), ((True, True), A, B_)):
+        c = plan.rq_mul(x, y, a_is_evals=flags[0], b_is_evals=flags[1], want_evals=False)[0]
+        assert np.array_equal(np.asarray(c).reshape(-1), np.asarray(want[0]).reshape(-1)), (hex(q), n, flags)
+
+
+@pytest.mark.gpu
+def test_montgomery_plans_on_device_buffers_in_place(pkg, oracle, need_gpu):
+    """the in-place device entry point on such a modulus"""
     import torch
 
-    for n in (1024, 1 << 14):
-        plan = pkg.Plan(QMG61, n)
-        a, b = _rows(oracle, QMG61, n, 3, 4400 + n), _rows(oracle, QMG61, n, 3, 4500 + n)
-        got = plan.rq_mul(a, b)
-        got = got[0] if isinstance(got, tuple) else got
-        want = oracle.rq_mul(QMG61, n, a, b)
-        want = want[0] if isinstance(want, tuple) else want
-        assert np.array_equal(np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)), n
     n, batch = 1 << 16, 40
     plan = pkg.Plan(QMG61, n)
     st = torch.cuda.current_stream().cuda_stream
@@ -267,3 +280,26 @@ def test_montgomery_product_identity_and_bounds():
         assert bx == 112
     for q in (Q61, 0x1fffffffff000001, 65537, (1 << 32) + 1 + (1 << 61)):
         assert mg_params(q) is None
+
+
+def test_montgomery_variable_product_identity_and_bounds():
+    """mul_var_mg's two word steps on the full 128-bit product, in Python integers: (P - W q) / 2^32 is exact twice over because
+    q = 1 (mod 2^32); the result + q is a b 2^-64 (mod q), positive and below 7.1 q for every a, b below 7q"""
+    import random
+
+    rng = random.Random(9)
+    for q in (QMG61, QMG50, QMG40):
+        qh, inv64 = q >> 32, pow(1 << 64, -1, q)
+        for _ in range(20000):
+            a = rng.choice([rng.randrange(7 * q), 7 * q - 1, q - 1, 0, 1])
+            b = rng.choice([rng.randrange(7 * q), 7 * q - 1, q - 1, 0, 1])
+            P = a * b
+            assert P < 1 << 128
+            P0 = P & 0xffffffff
+            assert (P - P0 * q) % (1 << 32) == 0
+            R1 = (P >> 32) - P0 * qh
+            assert R1 == (P - P0 * q) >> 32
+            R10 = R1 & 0xffffffff
+            R2 = (R1 >> 32) - R10 * qh
+            r = R2 + q
+            assert 0 < r < 7.1 * q and r < 1 << 64 and r % q == (a * b * inv64) % q

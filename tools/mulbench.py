@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/mulbench.py — throughput of the device-resident Rq product (fhe_rq_mul_dev) per size;
-FHE_RQ_MUL_FUSED=0 selects the three-kernel path for single-pass sizes (diagnostic)."""
+FHE_RQ_MUL_FUSED=0 selects the three-kernel path for single-pass sizes (diagnostic); MULBENCH_Q: another modulus than
+2^61 - 2^21 + 1."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +14,7 @@ if len(sys.argv) > 1:   # tools/mulbench.py 14:16384 16:4096 ...
     sizes = [tuple(int(x) for x in arg.split(":")) for arg in sys.argv[1:]]
 print(f"FHE_RQ_MUL_FUSED={os.environ.get('FHE_RQ_MUL_FUSED', '1')}", flush=True)
 for log_n, batch in sizes:
-    q, n = pkg.Q61, 1 << log_n
+    q, n = int(os.environ.get("MULBENCH_Q", pkg.Q61)), 1 << log_n
     plan = pkg.Plan(q, n)
     a = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
     b = torch.empty_like(a); c = torch.empty_like(a); ce = torch.empty_like(a)

@@ -33,7 +33,7 @@ __device__ __forceinline__ u32 mont32(u32 x, u32 y, u32 p, u32 pinv_neg) {
 // the two residues (canonical) -> the integer in [0, pA * pB)
 __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
     const u32 rAb = csub_u32(rA, pB);                           // rA mod pB (pA - pB < pB)
-    const u32 diff = csub_u32(rB - rAb + pB, pB);
+    const u32 diff = rB - rAb + pB;                              // in (0, 2 pB): the lazy product takes any word
     const u32 h = csub_u32(mul_shoup32(diff, crt, pB), pB);
     return (u64)rA + (u64)pA * h;
 }
@@ -78,8 +78,10 @@ struct Blk {
 // ---- forward: row r of n words -> both blocks of its 2n-point transform, modulo the first NPR primes --------------------
 // WORD32: the source words are below 2^32 (ciphertext words modulo a q that small): reduced in one word.
 // Workgroup ids 16 g + 8 blk + (row % 8): the two blocks of a row read the same words through ONE XCD's L2.
-template <int LB, int NPR, bool WORD32>
+// BELOWP: ... and q <= every prime: a canonical word (v < q, the library's input contract) is its own residue — no reduction
+template <int LB, int NPR, bool WORD32, bool BELOWP = false>
 __global__ __launch_bounds__((Big32<LB>::TH), FHE_B32_FWD_WAVES) void bfv32_forward_kernel(Bfv32Args a) {
+    static_assert(!BELOWP || WORD32, "words below a 27-bit prime are below 2^32");
     using C = Big32<LB>;
     using K = Blk<LB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -107,7 +109,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), FHE_B32_FWD_WAVES) void bfv32_forw
         u32 v[1][16];
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            v[0][k] = WORD32 ? csub_u32(barrett2p_32((u32)x[k], p, a.t.bq[pr]), p) : reduce64_32(x[k], p, a.t.mu[pr]);
+            v[0][k] = BELOWP ? (u32)x[k] : WORD32 ? csub_u32(barrett2p_32((u32)x[k], p, a.t.bq[pr]), p) : reduce64_32(x[k], p, a.t.mu[pr]);
         fwd_big<LB, 0, 1, FHE_B32_FWD_PRELOAD != 0>(v, lds, K::table(smem_raw, i), a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr], 1u, blk);
         // stored order (internal to this file): quad j of logical thread t at j * (M / 4) + 4 t of its block — a wave's
         // 16-byte accesses are contiguous (with the natural 16 t + 4 j every access would touch a quarter of each line)
@@ -132,11 +134,13 @@ __device__ __forceinline__ void load16(u32 (&v)[16], const u32 *__restrict__ src
     }
 }
 // the inverse's LAST stage (roots_inv[1]) on the two blocks' results, with the scaling by (2n)^-1 (and the Montgomery
-// factor of the products): register k of logical thread t -> coefficients j = k * TH + t (lo) and j + n (hi), canonical
-__device__ __forceinline__ void last_stage(u32 &lo, u32 &hi, Tw32 w1, Tw32 ni, u32 p, u32 p2) {
-    gs32(lo, hi, w1, p, p2);
-    lo = csub_u32(mul_shoup32(lo, ni, p), p);
-    hi = csub_u32(mul_shoup32(hi, ni, p), p);
+// factor of the products): register k of logical thread t -> coefficients j = k * TH + t (lo) and j + n (hi), canonical.
+// lo' = (lo + hi) c, hi' = (lo - hi) w1 c with c the scaling: ONE product per output (round 4; w1 c is a table constant) —
+// the sum and the difference of two values below 2p stay in a word and the lazy product takes any word.
+__device__ __forceinline__ void last_stage(u32 &lo, u32 &hi, Tw32 ni, Tw32 w1ni, u32 p, u32 p2) {
+    const u32 s = lo + hi, d = lo - hi + p2;
+    lo = csub_u32(mul_shoup32(s, ni, p), p);
+    hi = csub_u32(mul_shoup32(d, w1ni, p), p);
 }
 
 // Zq::from_f64(round(num * v / q)) — ring_n.rs:130-138 (mul_div_round), ring_nq.rs:160-163, zq.rs:32-39 — for an integer
@@ -173,10 +177,23 @@ __device__ __forceinline__ u64 zq_from_f64_small(double ef, double qf, double qi
     r = r >= qf ? r - qf : r;
     return (u64)(u32)r;
 }
+// fl(N / den) WITHOUT the division sequence (v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup): y = fl(1 / den) comes
+// from the host, q0 = fl(N y), r = N - q0 den (one fma: exact up to a rounding of relative size 2^-53 of r), x = fl(q0 + r y).
+// q0 + r y differs from N / den by |N / den - q0| 2^-53 <= 2^-104 |N / den|, so x IS fl(N / den) unless N / den lies within
+// 2^-104 (relative) of the midpoint m / 2^j of two neighbouring doubles — impossible here: N is an integer (num, v integers;
+// a rounded product of integers above 2^53 is still one), den an ODD integer below 2^53 (q or q^2 / ...: the host checks),
+// so N / den = m / 2^j would force den | N, an integer, not a midpoint, and otherwise |N 2^j - m den| >= 1 puts the quotient
+// at least 2^-j / den >= 2^-53 ulp-widths away.  Same double as the reference's `/`, ~8 instructions shorter per coefficient.
+__device__ __forceinline__ double exact_quotient(double N, double den, double rden) {
+    const double q0 = N * rden;
+    const double r = fma(-q0, den, N);
+    return fma(r, rden, q0);
+}
 // the epilogue's Zq::from_f64(round(num * v / den)): SMALL = the f64-only form above (decided on the host)
 template <bool SMALL>
 __device__ __forceinline__ u64 scale_round(const Bfv32Args &a, long long v) {
-    const double x = (a.numf * (double)v) / a.denf;
+    const double N = a.numf * (double)v;
+    const double x = a.rdenf != 0.0 ? exact_quotient(N, a.denf, a.rdenf) : N / a.denf;
     if constexpr (SMALL) return zq_from_f64_small(x, (double)a.q, a.qinvf);
     else return zq_from_f64_mu(a.q, a.qmu, round(x));
 }
@@ -236,7 +253,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
         u32 v0[1][16], v1[1][16];
         block(0u, v0);
         block(1u, v1);
-        const Tw32 ni = a.ninv_mont[pr], w1 = a.t.tw_inv[pr][1];
+        const Tw32 ni = a.ninv_mont[pr], w1ni = a.w1ninv_mont[pr];
         u64 parked = 0;
         u32 tfe = tf;
         asm volatile("" : "+v"(tfe));                           // (formed here, from an opaque lane id: no address registers held across the transforms)
@@ -247,7 +264,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u32 rl = v0[0][k], rh = v1[0][k];
-            last_stage(rl, rh, w1, ni, p, p2);
+            last_stage(rl, rh, ni, w1ni, p, p2);
             if constexpr (pr == 0) {
                 po[(u32)k * C::TH] = ((u64)rh << 32) | rl;
             } else {
@@ -326,7 +343,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
         u32 v0[1][16], v1[1][16];
         block(0u, v0);
         block(1u, v1);
-        const Tw32 ni = a.ninv_mont[pr], w1 = a.t.tw_inv[pr][1];
+        const Tw32 ni = a.ninv_mont[pr], w1ni = a.w1ninv_mont[pr];
         u64 pk0 = 0, pk1 = 0;                                   // the parked digits of the pair at hand
         u64 *ps0 = park0, *ps1 = park1;
         asm volatile("" : "+v"(ps0), "+v"(ps1));                // (here, not at the top: no registers held across the transforms)
@@ -335,7 +352,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u32 r2[2] = {v0[0][k], v1[0][k]};                    // [0] = coefficient j, [1] = coefficient j + n
-            last_stage(r2[0], r2[1], w1, ni, p, p2);
+            last_stage(r2[0], r2[1], ni, w1ni, p, p2);
             if constexpr (pr == 0) {
                 park0[(u32)k * C::TH] = ((u64)r2[1] << 32) | r2[0];
             } else if constexpr (pr == 1) {
@@ -344,7 +361,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
                 u32 g1[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const u32 d = csub_u32(r2[h] - csub_u32(g0[h], p) + p, p);               // pA - pB < pB: one subtraction reduces v0
+                    const u32 d = r2[h] - csub_u32(g0[h], p) + p;                            // pA - pB < pB: one subtraction reduces v0; d in (0, 2p)
                     g1[h] = csub_u32(mul_shoup32(d, a.t.crt, p), p);
                 }
                 park1[(u32)k * C::TH] = ((u64)g1[1] << 32) | g1[0];
@@ -355,10 +372,10 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const u32 a0 = csub_u32(csub_u32(g0[h], p), p);                          // pA - pC < 2 pC
-                    const u32 d = csub_u32(r2[h] - a0 + p, p);
+                    const u32 d = r2[h] - a0 + p;                                            // in (0, 2p): the lazy products take any word
                     const u32 e = csub_u32(mul_shoup32(d, a.t.crt_ac, p), p);
                     const u32 b1 = csub_u32(g1[h], p);                                       // pB - pC < pC
-                    const u32 v2 = csub_u32(mul_shoup32(csub_u32(e - b1 + p, p), a.t.crt_bc, p), p);
+                    const u32 v2 = csub_u32(mul_shoup32(e - b1 + p, a.t.crt_bc, p), p);
                     R2[h] = (long long)((u64)g0[h] + (u64)a.t.p[0] * g1[h] + a.t.P * v2);    // mod 2^64; P = pA pB < 2^55
                 }
                 const long long lo = R2[0], hi = R2[1];
@@ -415,9 +432,13 @@ static hipError_t launch_big(K kernel, const char *name, int lp, size_t lds, uns
 
 template <int LB> static constexpr auto bfv32_forward2 = bfv32_forward_kernel<LB, 2, true>;
 template <int LB> static constexpr auto bfv32_forward3 = bfv32_forward_kernel<LB, 3, true>;
+template <int LB> static constexpr auto bfv32_forward2b = bfv32_forward_kernel<LB, 2, true, true>;
+template <int LB> static constexpr auto bfv32_forward3b = bfv32_forward_kernel<LB, 3, true, true>;
 template <int LB> static constexpr auto bfv32_forward1w = bfv32_forward_kernel<LB, 1, false>;
 hipError_t launch_bfv32_forward(const Bfv32Args &a, hipStream_t st) {
     const u64 grid = 16 * ((a.rows + 7) / 8);                                                   // (row, block) pairs, 8 rows x 2 blocks per group
+    if (a.primes == 2 && a.word32 && a.below_p) { FHE_BIG_SWITCH(bfv32_forward2b, "bfv32_forward", grid, 1, 2) }
+    if (a.primes == 3 && a.word32 && a.below_p) { FHE_BIG_SWITCH(bfv32_forward3b, "bfv32_forward3", grid, 1, 3) }
     if (a.primes == 2 && a.word32) { FHE_BIG_SWITCH(bfv32_forward2, "bfv32_forward", grid, 1, 2) }
     if (a.primes == 3 && a.word32) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", grid, 1, 3) }
     if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward1w, "bfv32_forward_key", grid, 3, 1) }      // grid (row-blocks, primes)

@@ -548,6 +548,10 @@ static int bfv32_args(uint64_t n, fhe::Bfv32Args *a) {
         a->pinv_neg[i] = 0u - inv;
         const u64 w = ((u64)a->t.ninv[i].w << 32) % p;          // (2n)^-1 * 2^32 mod p
         a->ninv_mont[i] = fhe::Tw32{(uint32_t)w, (uint32_t)((w << 32) / p)};
+        const fhe_ntt_plan *plan = nullptr;                     // (cached: fhe_ext32_tables built the tables from it)
+        if ((rc = fhe_ntt_plan_get(p, 2 * n, &plan)) != FHE_OK) return rc;
+        const u64 w1 = (plan->roots_inv[1] * w) % p;            // roots_inv[1] * (2n)^-1 * 2^32 mod p: the last stage and the scaling in one
+        a->w1ninv_mont[i] = fhe::Tw32{(uint32_t)w1, (uint32_t)((w1 << 32) / p)};
     }
     return FHE_OK;
 }
@@ -561,6 +565,18 @@ static bool bfv32_small_f64_on() {
     static const bool on = [] { const char *e = getenv("FHE_BFV_SMALL_F64"); return !(e && e[0] == '0'); }();
     return on;
 }
+// the epilogue's quotient as reciprocal + two fma (bfv32.hip: exact_quotient) needs an ODD integer denominator below 2^53
+// (FHE_BFV_FAST_DIV=0: the IEEE division sequence — the A/B)
+static double bfv32_rden(uint64_t den) {
+    static const bool on = [] { const char *e = getenv("FHE_BFV_FAST_DIV"); return !(e && e[0] == '0'); }();
+    return (on && (den & 1ull) && den < (1ull << 53)) ? 1.0 / (double)den : 0.0;
+}
+// q <= every prime in use: canonical source words need no reduction (FHE_BFV_BELOW_P=0: reduce anyway)
+static uint32_t bfv32_below_p(uint64_t q, const fhe::Bfv32Args &a, int primes) {
+    static const bool on = [] { const char *e = getenv("FHE_BFV_BELOW_P"); return !(e && e[0] == '0'); }();
+    for (int i = 0; i < primes; i++) if (q > a.t.p[i]) return 0u;
+    return on ? 1u : 0u;
+}
 static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, void *d_c, size_t batch, hipStream_t st) {
     fhe::Bfv32Args a{};
     int rc = bfv32_args(n, &a);
@@ -569,9 +585,12 @@ static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, vo
     // transforms of [a0 | a1 | b0 | b1] x batch modulo two primes: 2 * 4 * batch rows of 2n u32
     if ((rc = fhe_workspace_get(1, (u64)2 * 4 * batch * 2 * n * 4, st, &wsv)) != FHE_OK) return rc;
     a.src = (const u64 *)d_ab; a.fw = (uint32_t *)wsv; a.rows = 4 * (u64)batch; a.primes = 2; a.word32 = 1;   // q < 2^21
+    a.below_p = bfv32_below_p(q, a, 2);
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.batch = batch; a.out = (u64 *)d_c; a.q = q; a.qmu = ~0ull / q; a.numf = (double)t; a.denf = (double)q;
+    // (quotients below 2^52 in magnitude: an integer quotient is then a double, never the midpoint of two)
+    a.rdenf = ((unsigned __int128)2 * n * (q - 1) * (q - 1) * t / q < ((unsigned __int128)1 << 52)) ? bfv32_rden(q) : 0.0;
     {   // the integer epilogue (bfv32.hip: zq_scale_round_int) where t * v < 2^52 for every coefficient v <= 2 n (q - 1)^2
         // — opt-in with FHE_BFV_INT_ROUND=1: bit-identical (tests/test_round3_gpu.py) but measured SLOWER than the f64 form
         // on MI355X (951 vs 855 us per 2048 pairs: f64 runs at full rate here, two 64-bit quotients cost more than one division)
@@ -606,10 +625,12 @@ static int bfv32_relinearize(uint64_t q, uint64_t n, uint64_t pq, const void *d_
     if ((rc = fhe_workspace_get(1, x_bytes + park_bytes, st, &wsv)) != FHE_OK) return rc;
     a.park = (u64 *)((unsigned char *)wsv + x_bytes);
     a.src = (const u64 *)d_c + 2 * (u64)batch * n; a.fw = (uint32_t *)wsv; a.rows = batch; a.primes = 3; a.word32 = 1;
+    a.below_p = bfv32_below_p(q, a, 3);
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.x = (const uint32_t *)wsv; a.key = (const uint32_t *)d_prep;
     a.addend = (const u64 *)d_c; a.out = (u64 *)d_out; a.batch = batch; a.q = q; a.qmu = ~0ull / q; a.numf = 1.0; a.denf = (double)(pq / q);
+    a.rdenf = (pq % q == 0 && pq / q >= (1ull << 12)) ? bfv32_rden(pq / q) : 0.0;      // |R| <= 2^63: quotients below 2^51
     // |R| <= 2^63 (an i64): R / p stays below 2^50 for p >= 2^14
     a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 31) && pq / q >= (1ull << 14)) ? 1u : 0u;
     a.qinvf = 1.0 / (double)q;

@@ -538,13 +538,16 @@ def test_bfv_epilogue_forms_give_the_same_words(pkg, oracle, need_gpu):
         "    for x in list(c) + list(o): h.update(np.ascontiguousarray(x).tobytes())\n"
         "    print('digest', q, n, h.hexdigest())\n" % ROOT)
     outs = {}
-    for name, extra in (("general", {"FHE_BFV_SMALL_F64": "0"}), ("f64", {"FHE_BFV_SMALL_F64": "1"}), ("int", {"FHE_BFV_INT_ROUND": "1"})):
+    # round 4: the quotient as reciprocal + two fma, canonical source words taken as their own residues — and both switched off
+    for name, extra in (("general", {"FHE_BFV_SMALL_F64": "0"}), ("f64", {"FHE_BFV_SMALL_F64": "1"}), ("int", {"FHE_BFV_INT_ROUND": "1"}),
+                        ("ieee-division", {"FHE_BFV_FAST_DIV": "0", "FHE_BFV_BELOW_P": "0"}),
+                        ("ieee-division-general", {"FHE_BFV_FAST_DIV": "0", "FHE_BFV_SMALL_F64": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, name + r.stdout + r.stderr
         outs[name] = [l for l in r.stdout.splitlines() if l.startswith("digest")]
         assert len(outs[name]) == 4
-    assert outs["general"] == outs["f64"] == outs["int"]
+    assert outs["general"] == outs["f64"] == outs["int"] == outs["ieee-division"] == outs["ieee-division-general"]
 
 
 # ---- the top of the reference's modulus range: 2^62 <= q < 2^63 (csrc/generic63.hip) ------------------------------------

@@ -163,19 +163,30 @@ __device__ __forceinline__ u64 zq_scale_round_int(u64 N, u64 q, u64 mu) {
     return r >= q ? r - q : r;
 }
 
-// Zq::from_f64 (zq.rs:32-39: round, `as i64`, ((e % q) + q) % q) for |ef| < 2^50 and q < 2^31, entirely in f64 — full
-// rate on this chip.  The general form (zq_from_f64_mu) goes through a saturating f64 -> i64 conversion and a 64-bit
-// remainder: ~90 instructions of the ~150 an epilogue spends per coefficient.  Here e = round(ef) is an exact integer,
-// k = rint(e * fl(1/q)) is within one of the true quotient, r = e - k q is exact (one fma: |k q| < 2^52) and within
-// (-3q/2, 3q/2): two conditional additions and a subtraction bring it to [0, q).  The same integer modulo q: bit-exact.
-__device__ __forceinline__ u64 zq_from_f64_small(double ef, double qf, double qinv) {
+// Zq::from_f64 (zq.rs:32-39: round, `as i64`, ((e % q) + q) % q) for |ef| < 2^50 and q < 2^30, without the general form's
+// saturating f64 -> i64 conversion and 64-bit remainder (zq_from_f64_mu: ~90 instructions of the ~150 an epilogue spent per
+// coefficient).  e = round(ef) is an exact integer; k = floor(e * fl(1/q)) is within one of floor(e / q) (the product's error is
+// below 2^-2); r = e - k q is exact (one fma: |k q| < 2^52) and lies in (-q, 2q).  Round 4: the two corrections are done on the
+// 32-bit integer — r + (q if r < 0), then min(r, r - q) as unsigned words: five half-cost instructions instead of three
+// compare-select pairs on doubles (FHE_B32_INT_TAIL=0: the f64 tail, around rint).  The same integer modulo q: bit-exact.
+#ifndef FHE_B32_INT_TAIL
+#define FHE_B32_INT_TAIL 1
+#endif
+__device__ __forceinline__ u64 zq_from_f64_small(double ef, double qf, double qinv, u32 q) {
     const double e = round(ef);
+#if FHE_B32_INT_TAIL
+    const double k = floor(e * qinv);
+    int r = (int)fma(-k, qf, e);                 // in (-q, 2q): fits (q < 2^30)
+    r += (r >> 31) & (int)q;                     // [0, 2q)
+    return (u64)min((u32)r, (u32)r - q);         // [0, q)
+#else
     const double k = rint(e * qinv);
     double r = fma(-k, qf, e);
     r = r < 0.0 ? r + qf : r;
     r = r < 0.0 ? r + qf : r;
     r = r >= qf ? r - qf : r;
     return (u64)(u32)r;
+#endif
 }
 // fl(N / den) WITHOUT the division sequence (v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup): y = fl(1 / den) comes
 // from the host, q0 = fl(N y), r = N - q0 den (one fma: exact up to a rounding of relative size 2^-53 of r), x = fl(q0 + r y).
@@ -194,7 +205,7 @@ template <bool SMALL>
 __device__ __forceinline__ u64 scale_round(const Bfv32Args &a, long long v) {
     const double N = a.numf * (double)v;
     const double x = a.rdenf != 0.0 ? exact_quotient(N, a.denf, a.rdenf) : N / a.denf;
-    if constexpr (SMALL) return zq_from_f64_small(x, (double)a.q, a.qinvf);
+    if constexpr (SMALL) return zq_from_f64_small(x, (double)a.q, a.qinvf, (u32)a.q);
     else return zq_from_f64_mu(a.q, a.qmu, round(x));
 }
 

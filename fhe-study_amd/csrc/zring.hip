@@ -599,7 +599,7 @@ static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, vo
         a.int_num = (on && t != 0 && vmax * t < ((unsigned __int128)1 << 52)) ? t : 0;
         // Zq::from_f64 in f64 alone (bfv32.hip: zq_from_f64_small) where every scaled coefficient stays below 2^50
         // (the default since round 4, see bfv32_small_f64_on)
-        a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 31) && vmax * t / q < ((unsigned __int128)1 << 50)) ? 1u : 0u;
+        a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 30) && vmax * t / q < ((unsigned __int128)1 << 50)) ? 1u : 0u;
         a.qinvf = 1.0 / (double)q;
     }
     e = fhe::launch_bfv32_tensor_inverse(a, st);
@@ -632,7 +632,7 @@ static int bfv32_relinearize(uint64_t q, uint64_t n, uint64_t pq, const void *d_
     a.addend = (const u64 *)d_c; a.out = (u64 *)d_out; a.batch = batch; a.q = q; a.qmu = ~0ull / q; a.numf = 1.0; a.denf = (double)(pq / q);
     a.rdenf = (pq % q == 0 && pq / q >= (1ull << 12)) ? bfv32_rden(pq / q) : 0.0;      // |R| <= 2^63: quotients below 2^51
     // |R| <= 2^63 (an i64): R / p stays below 2^50 for p >= 2^14
-    a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 31) && pq / q >= (1ull << 14)) ? 1u : 0u;
+    a.small_f64 = (bfv32_small_f64_on() && q < (1ull << 30) && pq / q >= (1ull << 14)) ? 1u : 0u;
     a.qinvf = 1.0 / (double)q;
     e = fhe::launch_bfv32_relin_inverse(a, st);
     return e == hipSuccess ? FHE_OK : fhe_hip_fail(e, "bfv32_relin_inverse_kernel");

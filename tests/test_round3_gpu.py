@@ -513,6 +513,15 @@ def test_zq_from_f64_in_f64_alone_is_the_same_residue():
             r = r + q if r < 0 else r
             r = r - q if r >= q else r
             assert r == ei % q, (q, ei)
+        if q < 1 << 30:
+            # round 4: k = floor(e * fl(1/q)), r = e - k q in (-q, 2q), fixed up as a 32-bit integer: r + (q if r < 0), then the
+            # unsigned min(r, r - q) — the tail the kernels run for q < 2^30
+            kf = np.floor(e * np.float64(1.0 / q))
+            for ei, ki in zip(es, kf):
+                r = ei - int(ki) * q
+                assert -q < r < 2 * q and -(1 << 31) <= r < 1 << 31
+                r32 = (r + (q if r < 0 else 0)) & 0xffffffff
+                assert min(r32, (r32 - q) & 0xffffffff) == ei % q, (q, ei)
 
 
 @pytest.mark.gpu

@@ -61,9 +61,16 @@ __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
 #ifndef FHE_B32_FWD_WAVES
 #define FHE_B32_FWD_WAVES 4      // forward kernels: waves per SIMD the register allocation must allow
 #endif
+#ifndef FHE_B32_INV_LOOSE
+#define FHE_B32_INV_LOOSE 1      // inverse rounds without a conditional subtraction per butterfly (ntt32_rounds.hpp: round_inv32_loose); modes 1 / 2 only
+#endif
+// what a block transform hands the last stage (units of p): the loose rounds stop at 8p (one stage from values below 4p, nothing
+// reduced), the others below 2p
+template <int MODE> constexpr int last_in_of() { return (FHE_B32_INV_LOOSE && MODE != 0) ? 8 : 2; }
 template <int MODE, int LB>
-__device__ __forceinline__ void inv_block(u32 (&v)[1][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 blk) {
-    if constexpr (MODE == 0) inv_big<LB>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
+__device__ __forceinline__ void inv_block(u32 (&v)[1][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2, u32 bq, u32 blk) {
+    if constexpr (FHE_B32_INV_LOOSE && MODE != 0) inv_big_loose<LB, MODE == 2, last_in_of<MODE>()>(v, lds, ltw, gtw, tf, p, bq, 1u, blk);
+    else if constexpr (MODE == 0) inv_big<LB>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
     else if constexpr (MODE == 1) inv_big_direct<LB, false>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
     else inv_big_direct<LB, true>(v, lds, ltw, gtw, tf, p, p2, 1u, blk);
 }
@@ -136,9 +143,11 @@ __device__ __forceinline__ void load16(u32 (&v)[16], const u32 *__restrict__ src
 // the inverse's LAST stage (roots_inv[1]) on the two blocks' results, with the scaling by (2n)^-1 (and the Montgomery
 // factor of the products): register k of logical thread t -> coefficients j = k * TH + t (lo) and j + n (hi), canonical.
 // lo' = (lo + hi) c, hi' = (lo - hi) w1 c with c the scaling: ONE product per output (round 4; w1 c is a table constant) —
-// the sum and the difference of two values below 2p stay in a word and the lazy product takes any word.
-__device__ __forceinline__ void last_stage(u32 &lo, u32 &hi, Tw32 ni, Tw32 w1ni, u32 p, u32 p2) {
-    const u32 s = lo + hi, d = lo - hi + p2;
+// the sum and the difference (+ KIN p) of two values below KIN p stay in a word and the lazy product takes any word.
+template <int KIN>
+__device__ __forceinline__ void last_stage(u32 &lo, u32 &hi, Tw32 ni, Tw32 w1ni, u32 p) {
+    static_assert(2 * KIN <= 16, "the sum of two values below KIN p stays in a word (p < 2^32 / 25)");
+    const u32 s = lo + hi, d = lo - hi + (u32)KIN * p;
     lo = csub_u32(mul_shoup32(s, ni, p), p);
     hi = csub_u32(mul_shoup32(d, w1ni, p), p);
 }
@@ -258,7 +267,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
                 v[0][4 * j] = t[0]; v[0][4 * j + 1] = t[1]; v[0][4 * j + 2] = t[2]; v[0][4 * j + 3] = t[3];
             }
 #ifndef FHE_B32_ABLATE_INV      // timing-only builds (tools/abl_build.sh): the kernels without their transforms / their f64 epilogues
-            inv_block<FHE_B32_INV_T, LB>(v, lds, K::table(smem_raw, 2 * pr + (int)blk), a.t.tw_inv[pr], tf, p, p2, blk);
+            inv_block<FHE_B32_INV_T, LB>(v, lds, K::table(smem_raw, 2 * pr + (int)blk), a.t.tw_inv[pr], tf, p, p2, a.t.bq[pr], blk);
 #endif
         };
         u32 v0[1][16], v1[1][16];
@@ -275,7 +284,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u32 rl = v0[0][k], rh = v1[0][k];
-            last_stage(rl, rh, ni, w1ni, p, p2);
+            last_stage<last_in_of<FHE_B32_INV_T>()>(rl, rh, ni, w1ni, p);
             if constexpr (pr == 0) {
                 po[(u32)k * C::TH] = ((u64)rh << 32) | rl;
             } else {
@@ -348,7 +357,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
                 v[0][4 * j + 2] = mont32(xa.z, xb.z, p, pn); v[0][4 * j + 3] = mont32(xa.w, xb.w, p, pn);
             }
 #ifndef FHE_B32_ABLATE_INV
-            inv_block<FHE_B32_INV_R, LB>(v, lds, K::table(smem_raw, 2 * pr + (int)blk), a.t.tw_inv[pr], tf, p, p2, blk);
+            inv_block<FHE_B32_INV_R, LB>(v, lds, K::table(smem_raw, 2 * pr + (int)blk), a.t.tw_inv[pr], tf, p, p2, a.t.bq[pr], blk);
 #endif
         };
         u32 v0[1][16], v1[1][16];
@@ -363,7 +372,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u32 r2[2] = {v0[0][k], v1[0][k]};                    // [0] = coefficient j, [1] = coefficient j + n
-            last_stage(r2[0], r2[1], ni, w1ni, p, p2);
+            last_stage<last_in_of<FHE_B32_INV_R>()>(r2[0], r2[1], ni, w1ni, p);
             if constexpr (pr == 0) {
                 park0[(u32)k * C::TH] = ((u64)r2[1] << 32) | r2[0];
             } else if constexpr (pr == 1) {

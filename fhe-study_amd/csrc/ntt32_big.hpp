@@ -2,6 +2,7 @@
 // ntt32_rounds.hpp with an LDS tile of the whole transform.  Shared by bfv32.hip (2n-point transforms of the BFV tensor)
 // and smallq.hip (n = 8192 / 16384 at small moduli).
 #pragma once
+#include <type_traits>
 #include "ntt32_rounds.hpp"
 
 namespace fhe {
@@ -141,6 +142,29 @@ __device__ __forceinline__ void inv_big_direct(u32 (&v)[Big32<LP>::VT][16], u32 
     inv_round_big_direct<LP, 1, STAGED>(v, lds, ltw, gtw, tf, p, p2, s0, blk);
 #pragma unroll
     for (int s = 0; s < C::VT; s++) round_inv32<C::R0>(v[s], ltw, 1u, p, p2);
+}
+// inv_big_direct on the loose rounds (ntt32_rounds.hpp: round_inv32_loose; moduli below 2^32 / 25): inputs below 2p, rounds hand on
+// values below 4p, the result is below BOUT p (2 as inv_big_direct's; a caller whose next step takes larger words asks for more)
+template <int LP, bool STAGED = true, int BOUT = 2>
+__device__ __forceinline__ void inv_big_loose(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 bq,
+                                              u32 s0 = 0, u32 blk = 0) {
+    using C = Big32<LP>;
+    auto round = [&](auto jc, auto binc) __attribute__((always_inline)) {
+        constexpr int J = decltype(jc)::value, BIN = decltype(binc)::value, A = C::a_of(J);
+#pragma unroll
+        for (int s = 0; s < C::VT; s++)
+            round_inv32_loose<4, BIN, 4, STAGED>(v[s], C::in_lds(J) ? ltw : gtw, big_t0<LP, J>(s0, blk, (tf + s * C::TH) >> A), p, bq);
+        exchange_big<LP, A, C::a_of(J - 1)>(v, lds, tf);
+    };
+    if constexpr (C::NR > 3) {
+        round(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+        round(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+    } else {
+        round(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    }
+    round(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+#pragma unroll
+    for (int s = 0; s < C::VT; s++) round_inv32_loose<C::R0, 4, BOUT, false>(v[s], ltw, 1u, p, bq);
 }
 template <int LP>
 __device__ __forceinline__ void inv_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, const Tw32 *ltw, const Tw32 *gtw, u32 tf, u32 p, u32 p2,

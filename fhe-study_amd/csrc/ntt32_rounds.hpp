@@ -69,6 +69,77 @@ __device__ __forceinline__ void round_inv32(u32 (&v)[16], const Tw32 *__restrict
     }
 }
 
+// ---- inverse rounds WITHOUT a conditional subtraction per butterfly (round 4; moduli below 2^32 / 25 only) ----------------
+// A Gentleman-Sande stage doubles the bound of its sums and resets its products to 2p.  With p < 2^32 / 25 a word holds 16p:
+// the bounds of the 16 registers are followed at compile time (units of p, as pm_inv_sched does for the 64-bit rounds) and a
+// value is reduced — barrett2p_32: any word -> [0, 2p), three instructions — only where a pair would pass 16p, plus what the
+// round must hand on below BOUT.  From bound 4 to bound 4 that is 8 reductions per 32 butterflies where gs32 spends 32
+// conditional subtractions.  x - y + K p needs K p >= y: K = the bound of y.
+struct Inv32Sched {
+    bool rx[4][8], ry[4][8];
+    unsigned char ky[4][8];
+    bool fin[16];
+};
+constexpr int kInv32Cap = 16;
+constexpr Inv32Sched inv32_sched(int R, int bin, int bout) {
+    Inv32Sched s{};
+    int B[16] = {};
+    for (int k = 0; k < 16; k++) B[k] = bin;
+    int st = 0;
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+        int j = 0;
+        for (int g = 0; g < (1 << i); g++)
+            for (int l = 0; l < span; l++, j++) {
+                const int k = g * 2 * span + l, k2 = k + span;
+                int bx = B[k], by = B[k2];
+                bool rx = false, ry = false;
+                if (bx + by > kInv32Cap) {
+                    if (bx >= by) { rx = true; bx = 2; } else { ry = true; by = 2; }
+                }
+                if (bx + by > kInv32Cap) {
+                    if (!rx) { rx = true; bx = 2; } else { ry = true; by = 2; }
+                }
+                s.rx[st][j] = rx;
+                s.ry[st][j] = ry;
+                s.ky[st][j] = (unsigned char)by;
+                B[k] = bx + by;
+                B[k2] = 2;
+            }
+    }
+    for (int k = 0; k < 16; k++) s.fin[k] = B[k] > bout;
+    return s;
+}
+// values below BIN p in, below BOUT p out (BIN, BOUT <= 16); STAGED: a scheduling barrier after every stage (round_inv32_staged)
+template <int R, int BIN, int BOUT, bool STAGED>
+__device__ __forceinline__ void round_inv32_loose(u32 (&v)[16], const Tw32 *__restrict__ tw, u32 T0, u32 p, u32 bq) {
+    static_assert(BIN >= 2 && BIN <= kInv32Cap && BOUT >= 2 && BOUT <= kInv32Cap, "bounds in units of p");
+    constexpr Inv32Sched S = inv32_sched(R, BIN, BOUT);
+    int st = 0;
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--, st++) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            const Tw32 t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l, j = g * span + l;
+                u32 x = v[k], y = v[k + span];
+                if (S.rx[st][j]) x = barrett2p_32(x, p, bq);
+                if (S.ry[st][j]) y = barrett2p_32(y, p, bq);
+                const u32 d = x - y + (u32)S.ky[st][j] * p;
+                v[k] = x + y;
+                v[k + span] = mul_shoup32(d, t, p);
+            }
+        }
+        if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (S.fin[k]) v[k] = barrett2p_32(v[k], p, bq);
+}
+
 // The inverse round with its table reads kept INSIDE their stage (a scheduling barrier between stages): the compiler
 // otherwise hoists the 15 reads of a round to its top — 30 registers that kernels holding other results cannot spare.
 template <int R>

@@ -303,3 +303,67 @@ def test_montgomery_variable_product_identity_and_bounds():
             R2 = (R1 >> 32) - R10 * qh
             r = R2 + q
             assert 0 < r < 7.1 * q and r < 1 << 64 and r % q == (a * b * inv64) % q
+
+
+# ---- 32-bit inverse rounds without a conditional subtraction per butterfly (ntt32_rounds.hpp: inv32_sched / round_inv32_loose) ---------
+def _inv32_sched(R, bin_, bout, cap=16):
+    """inv32_sched restated: per stage and butterfly (reduce x, reduce y, K), and which registers are reduced at the end"""
+    B, stages = [bin_] * 16, []
+    for i in range(R - 1, -1, -1):
+        span, st = 8 >> i, []
+        for g in range(1 << i):
+            for l in range(span):
+                k, k2 = g * 2 * span + l, g * 2 * span + l + span
+                bx, by, rx, ry = B[k], B[k2], False, False
+                if bx + by > cap:
+                    if bx >= by:
+                        rx, bx = True, 2
+                    else:
+                        ry, by = True, 2
+                if bx + by > cap:
+                    if not rx:
+                        rx, bx = True, 2
+                    else:
+                        ry, by = True, 2
+                st.append((k, k2, rx, ry, by))
+                B[k], B[k2] = bx + by, 2
+        stages.append(st)
+    return stages, [b > bout for b in B], B
+
+
+def test_loose_inverse_rounds_stay_in_a_word_and_compute_the_same_residues():
+    """For the 27-bit primes of digit32.hpp (p < 2^32 / 25): every sum and every x - y + K p of the schedule stays below 2^32 and
+    above -1 for the LARGEST values its bounds allow, a round hands on values below its BOUT, and on random words the registers
+    are congruent to what the plain Gentleman-Sande stages give — for every (R, BIN, BOUT) the block kernels instantiate."""
+    import random
+
+    rng = random.Random(11)
+    for p in (0x0a3c8001, 0x0a320001, 0x0a318001):                 # kExt32PrimeA / B / C (digit32.hpp): all below 2^32 / 25
+        assert p < (1 << 32) // 25
+        for R, bin_, bout in ((4, 2, 4), (4, 4, 4), (1, 4, 2), (1, 4, 8), (2, 4, 2), (3, 4, 8)):
+            stages, fin, B = _inv32_sched(R, bin_, bout)
+            for b, f in zip(B, fin):
+                assert (2 if f else b) <= bout
+            # worst case: every register at its bound - 1
+            bound = [bin_] * 16
+            for st in stages:
+                for k, k2, rx, ry, K in st:
+                    bx, by = (2 if rx else bound[k]), (2 if ry else bound[k2])
+                    assert K >= by and bx + by <= 16 and (bx + K) * p < 1 << 32 and (bx + by) * p < 1 << 32
+                    bound[k], bound[k2] = bx + by, 2
+            # random words: congruence with the exact butterflies
+            w = [rng.randrange(1, p) for _ in range(16)]
+            v = [rng.randrange(bin_ * p) for _ in range(16)]
+            exact = list(v)
+            for si, st in enumerate(stages):
+                for k, k2, rx, ry, K in st:
+                    x, y = v[k], v[k2]
+                    x = x % p + (p if rx and rng.random() < 0.5 else 0) if rx else x     # Barrett lands in [0, 2p)
+                    y = y % p + (p if ry and rng.random() < 0.5 else 0) if ry else y
+                    d = x - y + K * p
+                    assert 0 <= d < 1 << 32 and x + y < 1 << 32
+                    v[k], v[k2] = x + y, (d * w[si]) % p + (p if rng.random() < 0.5 else 0)   # the lazy product lands in [0, 2p)
+                    ex, ey = exact[k], exact[k2]
+                    exact[k], exact[k2] = (ex + ey) % p, ((ex - ey) * w[si]) % p
+            for k in range(16):
+                assert v[k] % p == exact[k] and (v[k] < B[k] * p)

@@ -345,15 +345,46 @@ def workload_extprod(args, pkg, torch, dev, st, rank, world):
     }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N ranks here — as a child
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` — BEFORE this process has imported
+    torch or made any HIP call (a process that has initialised the GPU must never be replaced or forked into ranks),
+    relay the children's output (rank 0 prints the one JSON line) and exit with the launcher's code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["FHE_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
-    import torch
-
+    if args.gpus < 1:
+        print(f"[bench] --gpus {args.gpus}: need at least one GPU", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))                 # nothing below runs in this (GPU-free) parent
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        # the line's n_gpus must be what was asked for: a launcher that started a different number of ranks is an error,
+        # not a note (round 4 printed a note and measured WORLD_SIZE ranks)
+        if rank == 0:
+            print(f"[bench] error: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                  f"start `python bench.py --gpus {args.gpus} ...` without a launcher (it starts its own ranks) or "
+                  f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`", file=sys.stderr)
+        sys.exit(2)
+    import torch
+
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)

@@ -107,8 +107,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
             v[k] = f < nsrc ? reduce_any(src[f], a.mod) : 0ull;
         }
     } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, off + field_of<C::A0>(tf, k) * 8u);
+        ld16<true>(v, pin, C::A0, off + tf * 8u);   // field_of<A0>(tf, k) = (k << A0) + tf: the k-term on the scalar base
     }
     // Round 0's twiddles are the same for the whole workgroup (H = 0): read from the global
     // table at a wave-uniform address (scalar loads, SGPR operands).  The LDS copy is only
@@ -137,11 +136,17 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
         lds[pad16(w * C::M + field_of<ALAST>(tf, k))] = x;
     }
     __syncthreads();
+    const SlabIo<LP> io(tid, a.log_n);
+    if (live == (u32)C::W) {   // wave-uniform: every polynomial of the group exists — sixteen LDS reads in flight, no per-store test
+        u64 t[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const u32 e = i * C::TH + tid;
-        const u32 wu = e >> LP, f = e & (C::M - 1);
-        if (wu < live) st_at(pout, ((wu << a.log_n) + f) * 8u, lds[pad16(e)]);
+        for (int i = 0; i < 16; i++) t[i] = lds[io.slot + i * io.lds_step];
+#pragma unroll
+        for (int i = 0; i < 16; i++) st_s<true>(io.base(pout, i, a.log_n), io.boff, t[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (io.wu(i) < live) st_s<true>(io.base(pout, i, a.log_n), io.boff, lds[io.slot + i * io.lds_step]);
     }
 }
 
@@ -181,20 +186,32 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     u64 v[16];
     if constexpr (TLOAD) {
         const u64 *__restrict__ pin = a.in + ubase;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const u32 e = i * C::TH + tid, wu = e >> LP, f = e & (C::M - 1);
-            const u32 o = (((wu < live ? wu : 0u) << a.log_n) + f) * 8u;
-            u64 x = ld_at<u64>(pin, o);
+        const SlabIo<LP> io(tid, a.log_n);
+        const bool full = live == (u32)C::W;                     // wave-uniform: every polynomial of the group exists
+        // one element of the slab: loaded (multiplied, its product stored) and put into its LDS slot
+        auto element = [&](int i, u64 pi, u64 pi2, u64 po2, u32 o, bool exists) {   // scalar addresses + one lane offset
+            u64 x = ld_s<true>(pi, o);
             if constexpr (MUL_IN && AR == 2) {
-                const u64 y = ld_at<u64>(a.in2 + ubase, o);
+                const u64 y = ld_s<true>(pi2, o);
                 x = mul_var_pm(x, y, a.mod);                     // both canonical: five multiplies
                 if (a.out2) {
                     x = pm_canon(x, a.mod);                      // canonical only if the product is an output
-                    if (wu < live) st_at(a.out2 + ubase, o, x);
+                    if (exists) st_s<true>(po2, o, x);
                 }
             }
-            lds[pad16(e)] = x;
+            lds[io.slot + i * io.lds_step] = x;
+        };
+        if (full) {                                              // the i-term on the scalar base, one lane offset
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                element(i, io.base(pin, i, a.log_n), io.base(a.in2 + ubase, i, a.log_n), io.base(a.out2 + ubase, i, a.log_n), io.boff, true);
+        } else {                                                 // ragged last group: a missing polynomial's lanes read the group's first one
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const u32 e = i * C::TH + tid, wu = e >> LP, f = e & (C::M - 1);
+                const u32 o = (((wu < live ? wu : 0u) << a.log_n) + f) * 8u;
+                element(i, scalar_addr(pin), scalar_addr(a.in2 + ubase), scalar_addr(a.out2 + ubase), o, wu < live);
+            }
         }
         __syncthreads();                                         // (also publishes the twiddle tile)
 #pragma unroll
@@ -236,9 +253,11 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     else inv_rounds_contig<LP, WIDE, FINAL, true>(v, lds, ltw, a.tw, s0, blk, w, tf, m, a.ninv, a.s_ninv);
 
     if (active) {
+        if constexpr (FINAL) {
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m));   // AR == 4: products, below 3q
+            for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m);   // AR == 4: products, below 3q
+        }
+        st16<false>(pout, C::A0, off + tf * 8u, v);   // field_of<A0>(tf, k) = (k << A0) + tf
     }
 }
 
@@ -331,8 +350,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
                 v[2 * j + 1] = x.y;
             }
         } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = ld_c<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
+            ld16<false>(v, p, C::A0, off + tf * 8u);
             if constexpr (AR == 2 || AR == 4) {   // canonical only where the evals are an output (see the product below)
                 fwd_rounds_contig_pm<LP, kPmOne, decltype(fresh)::value, AR>(v, lds, ltw_f, a.tw, 0u, 0u, w, tf, m);
                 if (keep) {
@@ -383,8 +401,8 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, AR == 2 ? pm_canon(va[k], m) : AR == 4 ? canon4(va[k], m) : canon2(va[k], m));
+        for (int k = 0; k < 16; k++) va[k] = AR == 2 ? pm_canon(va[k], m) : AR == 4 ? canon4(va[k], m) : canon2(va[k], m);
+        st16<false>(pout, C::A0, off + tf * 8u, va);
     }
 }
 
@@ -442,8 +460,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
                 v[2 * j + 1] = x.y;
             }
         } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(p, off + field_of<C::A0>(tf, k) * 8u);
+            ld16<true>(v, p, C::A0, off + tf * 8u);
         }
     };
     auto operand = [&](bool is_evals, bool keep, u64 (&v)[16], auto fresh) {
@@ -498,8 +515,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
     else inv_rounds_contig<LP, WIDE, false, false>(va, lds, ltw_i, a.tw_inv, s0, blk, w, tf, m, a.ninv, a.s_ninv);
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
-#pragma unroll
-        for (int k = 0; k < 16; k++) st_c<u64>(pout, off + field_of<C::A0>(tf, k) * 8u, va[k]);   // lazy
+        st16<false>(pout, C::A0, off + tf * 8u, va);   // lazy
     }
 }
 
@@ -537,8 +553,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
             v[k] = e + col < nsrc ? reduce_any(ld_at<u64>(src, (e + c) * 8u), m) : 0ull;
         }
     } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<C::A0>(tf, k) << lb) + c) * 8u);
+        ld16<true>(v, pin, C::A0 + lb, ((field_of<C::A0>(tf, 0) << lb) + c) * 8u);   // row k-term on the scalar base
     }
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];   // first pass: s0 = 0, blk = 0
 
@@ -563,8 +578,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
         else round_fwd<4, WIDE, B2, false, C::NR == 3>(v, tw, (1u << LS) + (tf >> A), m);
     }
     constexpr int ALAST = C::a_of(C::NR - 1);
-#pragma unroll
-    for (int k = 0; k < 16; k++) st_at(pout, ((field_of<ALAST>(tf, k) << lb) + c) * 8u, v[k]);  // lazy: < 4q, or < 6q (WIDE)
+    st16<true>(pout, ALAST + lb, ((field_of<ALAST>(tf, 0) << lb) + c) * 8u, v);  // lazy: < 4q, or < 6q (WIDE)
 }
 
 template <int LA, int CW, int AR>
@@ -587,8 +601,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
 
     constexpr int ALAST = C::a_of(C::NR - 1);
     u64 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = ld_at<u64>(pin, ((field_of<ALAST>(tf, k) << lb) + c) * 8u);  // < 2q
+    ld16<true>(v, pin, ALAST + lb, ((field_of<ALAST>(tf, 0) << lb) + c) * 8u);  // < 2q
     for (u32 li = tid; li < (u32)C::F; li += C::TH) ltw[li] = a.tw[li];
     __syncthreads();
 
@@ -608,8 +621,8 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     if constexpr (AR == 2 || AR == 4) round_inv_pm<C::R0, true, ar_inv_bound(AR), true, AR>(v, a.tw, 1u, m, a.ninv, a.s_ninv);   // uniform: scalar loads
     else round_inv_sel<C::R0, true, WIDE, 4>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        st_at(pout, ((field_of<C::A0>(tf, k) << lb) + c) * 8u, AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m));
+    for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m);
+    st16<true>(pout, C::A0 + lb, ((field_of<C::A0>(tf, 0) << lb) + c) * 8u, v);
 }
 
 // ---------------------------------------------------------------------------
@@ -749,7 +762,9 @@ static hipError_t launch_strided(const PassArgs &a, hipStream_t st, unsigned ope
 #ifndef FHE_STRIDED_CW8
 #define FHE_STRIDED_CW8 32        // columns of a strided-pass workgroup at 8 strided stages (shape experiments: 16 / 64)
 #endif
+#ifndef CONTIG_CASES             // (tools/isa_audit.sh narrows the list for a quick listing of the headline kernels)
 #define CONTIG_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#endif
 
 // ar: the kernels' AR (0 / 1 = Shoup tables, 2 = pseudo-Mersenne tables: DevicePlan::arith)
 static hipError_t fwd_contig_dispatch(int lp, bool final, int ar, const PassArgs &a, hipStream_t st) {

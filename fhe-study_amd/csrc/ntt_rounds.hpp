@@ -435,6 +435,46 @@ __device__ __forceinline__ void st_c(u64 *ubase, u32 byte_off, T x) {
     *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ubase) + byte_off) = x;
 }
 
+// Sixteen accesses whose element indices are (k << sh) + (a per-lane term), k = 0..15: the k-term goes onto the
+// wave-uniform 64-bit base — scalar adds, or the instruction's immediate offset where it fits — and ONE per-lane byte
+// offset serves all sixteen.  Written as `base + off + k-term` in 32-bit lane arithmetic (rounds 1-4) every access
+// cost one to three vector instructions of its own (v_or / v_lshlrev / v_add_lshl: the compiler may not fold a 32-bit
+// add into the 64-bit address): 96 of the strided kernel's 1032 vector instructions per wave (round 5).
+// NT: the non-temporal forms (whole lines per wave instruction, touched once).
+// A wave-uniform address pinned to a scalar register pair and made opaque: left to itself the compiler reassociates
+// (base + k-term) + lane offset into (base + lane offset) + k-term, a 64-bit vector add per access.  The opaque value is
+// an integer, so the access names the global address space itself (a laundered generic pointer becomes a flat_ access).
+typedef __attribute__((address_space(1))) u64 gu64;
+__device__ __forceinline__ u64 scalar_addr(const u64 *p) {
+    u64 a = reinterpret_cast<u64>(p);
+    asm("" : "+s"(a));
+    return a;
+}
+template <bool NT>
+__device__ __forceinline__ u64 ld_s(u64 saddr, u32 lane_boff) {   // global load at (scalar address) + (32-bit lane offset)
+    const gu64 *p = reinterpret_cast<const gu64 *>(saddr + lane_boff);
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_s(u64 saddr, u32 lane_boff, u64 x) {
+    gu64 *p = reinterpret_cast<gu64 *>(saddr + lane_boff);
+    if (NT) __builtin_nontemporal_store(x, p); else *p = x;
+}
+template <bool NT>
+__device__ __forceinline__ void ld16(u64 (&v)[16], const u64 *ubase, u32 sh, u32 lane_boff) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        v[k] = ld_s<NT>(scalar_addr(ubase + ((u64)k << sh)), lane_boff);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st16(u64 *ubase, u32 sh, u32 lane_boff, const u64 (&v)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        st_s<NT>(scalar_addr(ubase + ((u64)k << sh)), lane_boff, v[k]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // CONTIGUOUS pass: blocks of M = 2^LP consecutive coefficients.
 // Workgroup = W units (unit = one M-block of one polynomial, all W units share
@@ -466,6 +506,30 @@ struct ContigCfg {
     static constexpr int a_of(int j) { return j == 0 ? A0 : LP - R0 - 4 * j; }
     static constexpr int ls0_of(int j) { return j == 0 ? 0 : R0 + 4 * (j - 1); }
     static constexpr bool in_lds(int j) { return ls0_of(j) + (j == 0 ? R0 : 4) <= LTW_LOG; }
+};
+
+// The workgroup's tile taken in SLAB order: element e = i TH + tid, i = 0..15 — a wave instruction covers 512 contiguous
+// bytes, whole lines.  e splits into polynomial wu = e >> LP and position f = e & (M - 1); i TH is a multiple of min(TH, M),
+// so the i-term of both is wave-uniform and goes onto the scalar base, the lane keeps one byte offset for all sixteen
+// accesses and one LDS slot (pad16 is additive over multiples of 16).  Round 5: written per element, every store of the
+// forward kernel cost seven vector instructions, a branch and its own LDS wait (profiles/r05_isa_*).
+template <int LP>
+struct SlabIo {
+    using C = ContigCfg<LP>;
+    static constexpr bool kLaneWu = C::TH > C::M;                       // several polynomials per slab: the lane picks one
+    static constexpr u32 wu_u(int i) { return (u32)(i * C::TH) >> LP; }
+    static constexpr u32 f_u(int i) { return (u32)(i * C::TH) & (u32)(C::M - 1); }
+    static constexpr u32 lds_step = C::TH + C::TH / 16;                  // pad16(i TH + tid) = i lds_step + pad16(tid)
+    u32 wu_l, boff, slot;
+    __device__ __forceinline__ SlabIo(u32 tid, u32 log_n) {
+        wu_l = kLaneWu ? tid >> LP : 0u;
+        const u32 f_l = kLaneWu ? tid & (u32)(C::M - 1) : tid;
+        boff = ((wu_l << log_n) + f_l) * 8u;
+        slot = tid + (tid >> 4);
+    }
+    // scalar address of slab i of the tile at p (for ld_s / st_s with `boff`)
+    __device__ __forceinline__ u64 base(const u64 *p, int i, u32 log_n) const { return scalar_addr(p + ((u64)wu_u(i) << log_n) + f_u(i)); }
+    __device__ __forceinline__ u32 wu(int i) const { return wu_u(i) + wu_l; }
 };
 
 // scatter registers (window AF) -> barrier -> gather registers (window AT).

@@ -182,7 +182,11 @@ constexpr int kPmOne = 16;    // canonical
 constexpr int kPmCap = 128;   // 8q <= 2^64: every value stays below
 
 // x -> (x mod 2^k) + (x >> k) delta  =  x (mod q),  < 2^k + 2^(64-k) delta.  Plain C on purpose (the compiler emits
-// v_lshrrev / v_and / v_mad_u64_u32): a non-asm producer in front of a butterfly's asm statement needs no s_nop.
+// v_lshrrev / v_and / v_mad_u64_u32, often with a v_mov_b32 that builds the masked value in a fresh pair).  Round 5 tried
+// the three-instruction in-place form — shift, `x & mask` on x's own pair, `v_mad_u64_u32 %0, vcc, k, delta, %0` tied
+// ("+v") to it: -1.5 % vector instructions, but in rq_mul_mid_kernel (two operands live, 109 registers) hipcc 7.2 then
+// handed stage 3 of a round a stale register pair for v[0] (words 0..31 of every 256-block wrong; bisected to this
+// statement with tools/dbg_r5.py, gpurun_out/r5b) — not kept.
 __device__ __forceinline__ u64 pm_reduce(u64 x, const Mod &m) {
     const u32 x1 = (u32)(x >> 32);
     const u64 lo = ((u64)(x1 & m.pm_rmask) << 32) | (u32)x;

@@ -51,9 +51,8 @@ def kernel_body(lines, needle):
     body = []
     for l in lines[start + 1:]:
         t = l.strip()
-        if t.startswith("s_endpgm"):
-            body.append(t)
-            break
+        if t.startswith(".Lfunc_end") or t.startswith(".section") or t.startswith(".rodata"):
+            break                                   # end of the function (blocks may follow the first s_endpgm)
         if t.startswith(";;#ASMSTART") or t.startswith(";;#ASMEND"):
             body.append(t[2:].split()[0])           # "#ASMSTART" / "#ASMEND" markers (kept for --split-asm)
             continue

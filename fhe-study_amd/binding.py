@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["capi.hip", "ntt_kernels.hip", "ntt_persist.hip", "digit_mac.hip", "digit32.hip", "bfv32.hip", "smallq.hip", "generic63.hip", "zring.hip", "glue.hip"]
 HEADERS = ["ntt_kernels.hpp", "ntt_rounds.hpp", "ntt_persist.hpp", "persist_sched.hpp", "digit_mac.hpp", "digit32.hpp", "bfv32.hpp", "smallq.hpp", "ntt32_rounds.hpp", "ntt32_big.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp",
-           os.path.join("..", "..", "include", "fhe_ntt.h")]
+           os.path.join("..", "..", "include", "fhe_ntt.h"), os.path.join("..", "..", "include", "fhe_ntt_experimental.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
 # -ffp-contract=off: zring.hip restates the reference's f64 scale-and-round (one IEEE rounding
 # per operation); nothing else in the library uses floating point.
@@ -43,7 +43,7 @@ EXPORTS = [
     "fhe_rq_pointwise_mul", "fhe_rq_check_canonical",
     "fhe_ntt_forward_dev", "fhe_ntt_inverse_dev", "fhe_rq_mul_dev",
     "fhe_rq_mul_workspace_bytes", "fhe_rq_pointwise_mul_dev", "fhe_fill_synthetic_dev",
-    "fhe_ntt_set_batch_tile", "fhe_ntt_set_persist", "fhe_ntt_persist_status", "fhe_ntt_persist_profile", "fhe_ntt_set_persist_grid", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
+    "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
     "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace", "fhe_ntt_workspace_bytes",
@@ -62,6 +62,10 @@ EXPORTS = [
     "fhe_rq_mod_switch_dev", "fhe_rq_mul_div_round_dev", "fhe_rq_decompose_dev",
     "fhe_rq_remodule_dev", "fhe_rq_mul_by_f64_dev", "fhe_rq_div_round_dev",
 ]
+
+
+# include/fhe_ntt_experimental.h: the persistent kernels' switches (exported, NOT part of the boundary)
+EXPORTS_EXPERIMENTAL = ["fhe_ntt_set_persist", "fhe_ntt_persist_status", "fhe_ntt_persist_profile", "fhe_ntt_set_persist_grid"]
 
 
 class FheError(RuntimeError):

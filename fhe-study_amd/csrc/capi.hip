@@ -166,15 +166,25 @@ static int build_plan(u64 q, u64 n, fhe_ntt_plan *p) {
 extern "C" int fhe_ntt_plan_get(uint64_t q, uint64_t n, const fhe_ntt_plan **out) {
     if (!out) return fail(FHE_E_NULL, "fhe_ntt_plan_get: out is NULL");
     *out = nullptr;
-    std::lock_guard<std::mutex> lk(g_plans_lock);
     auto key = std::make_pair((u64)q, (u64)n);
-    auto it = g_plans.find(key);
-    if (it == g_plans.end()) {
-        std::unique_ptr<fhe_ntt_plan> p(new fhe_ntt_plan());
-        int rc = build_plan(q, n, p.get());
-        if (rc != FHE_OK) return rc;
-        it = g_plans.emplace(key, std::move(p)).first;
+    {
+        std::lock_guard<std::mutex> lk(g_plans_lock);
+        auto it = g_plans.find(key);
+        if (it != g_plans.end()) {
+            *out = it->second.get();
+            return FHE_OK;
+        }
     }
+    // Build OUTSIDE the lock (0.5 s at n = 2^20): a thread asking for an EXISTING plan never waits behind another
+    // thread's table build — the reference holds its CACHE mutex across the build (ntt.rs:20-22); the header promises
+    // re-entrancy.  Two threads that miss on the same (q, n) both build; the first to insert wins, the loser's
+    // tables are discarded (same values: the construction is deterministic).
+    std::unique_ptr<fhe_ntt_plan> p(new fhe_ntt_plan());
+    int rc = build_plan(q, n, p.get());
+    if (rc != FHE_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_plans_lock);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) it = g_plans.emplace(key, std::move(p)).first;
     *out = it->second.get();
     return FHE_OK;
 }
@@ -635,6 +645,11 @@ static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, 
 // concurrently from any number of streams and threads — on the same stream too
 // (tests/test_parity_gpu.py::test_two_streams_share_no_workspace, test_two_threads_on_the_default_stream).  Growing never frees a buffer that enqueued work may
 // still be using: the old buffer is retired and released at fhe_ntt_shutdown().
+// Round 5: a thread that EXITS hands its buffers to an orphan pool of their (slot, device, stream) — a
+// thread_local object's destructor does it — and the next thread that needs a workspace of that (slot, device, stream)
+// adopts the best-fitting orphan instead of allocating: work the dead thread enqueued is ahead of the adopter's on the
+// SAME stream, so reuse needs no further ordering, and a pool of short-lived threads on one stream holds as many
+// buffers as ran concurrently, not as many as ever lived.
 struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -653,6 +668,36 @@ struct WsKey {
 static std::mutex g_ws_lock;
 static std::map<WsKey, Workspace> g_ws;
 static std::vector<void *> g_ws_retired;
+static bool g_ws_alive = true;               // false once the process is tearing the statics down
+constexpr size_t kWsOrphanTid = ~(size_t)0;  // the tid under which a dead thread's buffers wait (a multimap would do; slots are few)
+static std::multimap<WsKey, Workspace> g_ws_orphans;
+
+static size_t ws_thread_id() { return std::hash<std::thread::id>()(std::this_thread::get_id()); }
+
+namespace {
+struct WsThreadReaper {      // one per thread that ever took a workspace; runs at thread exit
+    bool armed = false;
+    ~WsThreadReaper() {
+        if (!armed || !g_ws_alive) return;
+        const size_t tid = ws_thread_id();
+        std::lock_guard<std::mutex> lk(g_ws_lock);
+        for (auto it = g_ws.begin(); it != g_ws.end();) {
+            if (it->first.tid == tid) {
+                // hipStreamPerThread named THIS thread's own stream, which dies with it: nobody can adopt in stream order
+                if (it->second.ptr) {
+                    if (it->first.st == hipStreamPerThread) g_ws_retired.push_back(it->second.ptr);
+                    else g_ws_orphans.emplace(WsKey{it->first.slot, it->first.dev, it->first.st, kWsOrphanTid}, it->second);
+                }
+                it = g_ws.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+};
+struct WsStaticsGuard { ~WsStaticsGuard() { g_ws_alive = false; } } g_ws_statics_guard;   // destroyed before the maps above (reverse order)
+thread_local WsThreadReaper g_ws_reaper;
+}  // namespace
 
 int fhe_workspace_get(int slot, size_t bytes, hipStream_t st, void **out) {
     int dev = 0;
@@ -661,9 +706,22 @@ int fhe_workspace_get(int slot, size_t bytes, hipStream_t st, void **out) {
     // keyed by the calling THREAD for every stream (round 4): two host threads that enqueue on the same stream — the NULL
     // default stream is the common case for a shim whose Rq operations are freely shareable — get different buffers, so
     // their kernel sequences may interleave on the stream without sharing an intermediate
-    const size_t tid = std::hash<std::thread::id>()(std::this_thread::get_id());
+    const size_t tid = ws_thread_id();
+    g_ws_reaper.armed = true;
     std::lock_guard<std::mutex> lk(g_ws_lock);
     Workspace &w = g_ws[WsKey{slot, dev, st, tid}];
+    if (w.bytes < bytes && st != hipStreamPerThread) {
+        // adopt a dead thread's buffer of this (slot, device, stream) if one is large enough (the smallest such)
+        auto range = g_ws_orphans.equal_range(WsKey{slot, dev, st, kWsOrphanTid});
+        auto best = range.second;
+        for (auto it = range.first; it != range.second; ++it)
+            if (it->second.bytes >= bytes && (best == range.second || it->second.bytes < best->second.bytes)) best = it;
+        if (best != range.second) {
+            if (w.ptr) g_ws_retired.push_back(w.ptr);
+            w = best->second;
+            g_ws_orphans.erase(best);
+        }
+    }
     if (w.bytes < bytes) {
         // grow geometrically so that the buffers retired on the way sum to less than the live one
         size_t want = w.bytes + w.bytes / 2;
@@ -769,6 +827,14 @@ extern "C" int fhe_ntt_release_stream_workspace(void *hip_stream) {
             ++it;
         }
     }
+    for (auto it = g_ws_orphans.begin(); it != g_ws_orphans.end();) {   // and what dead threads left on it
+        if (it->first.dev == dev && it->first.st == st) {
+            if (it->second.ptr) (void)hipFree(it->second.ptr);
+            it = g_ws_orphans.erase(it);
+        } else {
+            ++it;
+        }
+    }
     return FHE_OK;
 }
 
@@ -778,6 +844,7 @@ extern "C" size_t fhe_ntt_workspace_bytes(void) {
     std::lock_guard<std::mutex> lk(g_ws_lock);
     size_t total = 0;
     for (auto &kv : g_ws) total += kv.second.bytes;
+    for (auto &kv : g_ws_orphans) total += kv.second.bytes;      // left by threads that exited, waiting for adoption
     return total;
 }
 
@@ -787,6 +854,9 @@ void fhe_workspace_free_all() {
     for (auto &kv : g_ws)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     g_ws.clear();
+    for (auto &kv : g_ws_orphans)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_ws_orphans.clear();
     for (void *p : g_ws_retired) (void)hipFree(p);
     g_ws_retired.clear();
 }

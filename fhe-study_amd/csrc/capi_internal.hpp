@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/fhe_ntt.h"
+#include "../../include/fhe_ntt_experimental.h"   // the persistent kernels' switches: exported, outside the boundary
 #include "ntt_kernels.hpp"
 
 constexpr int kMaxDevices = 16;

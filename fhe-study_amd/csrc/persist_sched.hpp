@@ -21,7 +21,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FHE_HD __host__ __device__
 #else
 #define FHE_HD

@@ -8,10 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
 #include "../../include/fhe_ntt.h"
+#include "../../include/fhe_ntt_experimental.h"   // the persistent kernels' switches (argument checks only)
 
 #define CHECK(cond)                                                                  \
     do {                                                                             \
@@ -61,6 +64,31 @@ int main() {
             });
         for (auto &t : th) t.join();
         for (int t = 1; t < 16; t++) CHECK(got[t] == got[0]);
+    }
+    // a thread asking for an EXISTING plan does not wait behind another thread's table build (round 5: plans are built
+    // outside the cache lock): 2^20 entries of a modulus not seen yet take ~0.5 s to build; meanwhile every look-up of the
+    // small plan must come back at once
+    {
+        const fhe_ntt_plan *small = nullptr;
+        CHECK(fhe_ntt_plan_get(Q61, 64, &small) == FHE_OK);
+        std::atomic<bool> building{true};
+        std::thread big([&] {
+            const fhe_ntt_plan *x = nullptr;
+            if (fhe_ntt_plan_get(0x1ffffffffc000001ull, 1ull << 20, &x) != FHE_OK) std::exit(2);
+            building = false;
+        });
+        double worst = 0;
+        int looks = 0;
+        while (building) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const fhe_ntt_plan *x = nullptr;
+            if (fhe_ntt_plan_get(Q61, 64, &x) != FHE_OK || x != small) std::exit(2);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > worst) worst = ms;
+            looks++;
+        }
+        big.join();
+        CHECK(looks > 10 && worst < 50.0);
     }
     // a composite modulus is not detected (ring_nq.rs:17), tables are still built
     CHECK(fhe_ntt_plan_get(65537ull * 3ull - 2ull * 65537ull + 0ull, 4, &p) == FHE_OK);

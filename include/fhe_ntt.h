@@ -182,30 +182,8 @@ int fhe_fill_synthetic_dev(uint64_t q, uint64_t seed, uint64_t first_index, size
  * 256 MiB Infinity Cache when the second pass reads it.  0 restores the default
  * (one launch per pass over the whole batch — measured fastest). */
 int fhe_ntt_set_batch_tile(size_t polys);
-/* The one-launch forward transform (n = 2^16, pseudo-Mersenne moduli; csrc/ntt_persist.hip): persistent workgroups
- * run the strided and the contiguous stages of NTT::ntt (arith/src/ntt.rs:44-73) in ONE kernel, drawing tickets from
- * one queue per XCD, every wait inside the kernel bounded.
- *   mode 0  off: the two-pass kernels.
- *   mode 1  "A": tiles of tile_polys polynomials (power of two <= 1024); the strided stages run `lag` tiles ahead of
- *           the contiguous ones; the intermediate lives in a ring of `ringslots` (>= lag + 1) tile slots per XCD, or in
- *           the output buffer (ringslots = 0).
- *   mode 2  "B": teams — sixteen workgroups of one XCD take ONE polynomial through both halves and meet in between; the
- *           intermediate lives in a ring of `ringslots` (>= 1) polynomial slots per XCD and is read back out of the L2.
- *   mode 3  "D": mode 2 at two workgroups per CU — 256 registers per lane, both twiddle tiles in LDS, the next part's
- *           coefficients prefetched into a second register set; `lag` = start-up stagger between groups, as for mode 2.
- *   mode 4  "E": the teams without the meeting, two workgroups per CU: a workgroup keeps a FIFO of the parts whose
- *           contiguous half is still to come and runs ONE half per iteration — the contiguous half of its oldest part once
- *           that polynomial's sixteen strided halves are in, a strided half of the next ticket otherwise — with the
- *           coefficients of the next two halves in flight; it waits (bounded) only when it can do neither.  ringslots >= 2.
- * Environment: FHE_NTT_PERSIST=A:T,L,R, B:R[,s], D:R[,s] or E:R[,s].  fhe_ntt_persist_status() (after synchronising) returns FHE_E_HIP if a
- * bounded wait ran out, and clears the flag. */
-int fhe_ntt_set_persist(unsigned mode, unsigned tile_polys, unsigned lag, unsigned ringslots);
-int fhe_ntt_persist_status(void);
-/* workgroups a persistent launch uses (default 0: as many as the chip holds).  Any number >= 1 gives the same words:
- * nothing in the kernels assumes that workgroups are resident together (tests run 1, 8, 20, ...). */
-int fhe_ntt_set_persist_grid(int workgroups);
-/* diagnostic: d_words26 = device buffer of 26 uint64_t (zeroed by the caller), or NULL to stop; see tools/persist_bench.py */
-int fhe_ntt_persist_profile(void *d_words26);
+/* (The one-launch forward transform of round 4 — persistent workgroups, slower than the two-pass kernels on every
+ * setting measured — is NOT part of this boundary: its switches live in include/fhe_ntt_experimental.h.) */
 /* When enabled, every kernel launch is bracketed by HIP events on its stream;
  * fhe_ntt_kernel_timing_read() synchronises, and returns per-kernel totals
  * since the last reset.  `names` receives up to `cap` NUL-terminated names of
@@ -400,11 +378,16 @@ int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, cons
  * needs them on one device, is the caller's (RCCL all-gather / hipMemcpyPeer). */
 int fhe_shard_range(size_t total, unsigned world, unsigned rank, size_t *begin, size_t *end);
 
-/* Library workspaces are kept per (device, stream) until fhe_ntt_shutdown(); a caller about to destroy a stream
- * returns that stream's workspaces — every one of them, whatever entry point took it — with this call (it
- * synchronises the stream first).  Workspaces of hipStreamPerThread, which the host-buffer entry points use, are
- * keyed by the calling THREAD as well: a thread that used those entry points (or passed hipStreamPerThread) should
- * call fhe_ntt_release_stream_workspace(hipStreamPerThread) before it exits, or its buffers stay until shutdown. */
+/* Library workspaces are kept per (device, stream, calling thread) until fhe_ntt_shutdown(): two host threads that
+ * enqueue on one stream never share an intermediate.  A thread that exits leaves its buffers to the next thread that
+ * needs one on the same (device, stream) — stream order makes that safe — so short-lived threads do not accumulate
+ * buffers.  A caller about to DESTROY a stream returns that stream's workspaces — every thread's, whatever entry point
+ * took them — with this call, which synchronises the stream first; the caller must make sure that no other thread is
+ * inside a library call on that stream at that moment (the same condition under which the stream may be destroyed at
+ * all): a buffer another thread has just been handed would be freed under it.  hipStreamPerThread names a different
+ * stream in every thread: the call then returns only the calling thread's buffers (a thread that used the host-buffer
+ * entry points, which run on hipStreamPerThread, may call it before it exits; otherwise those buffers are released at
+ * shutdown). */
 int fhe_ntt_release_stream_workspace(void *hip_stream);
 /* bytes of library workspace currently held, over all devices, streams and threads (diagnostic) */
 size_t fhe_ntt_workspace_bytes(void);

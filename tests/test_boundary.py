@@ -11,8 +11,8 @@ import pytest
 from conftest import Q16, Q61, ROOT, golden_cases, load_golden
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "fhe_ntt.h")).read()
+def declared_symbols(header="fhe_ntt.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fhe_[a-z0-9_]+)\s*\(", text)))
 
@@ -24,6 +24,11 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/fhe_ntt.h but not exported"
     assert sorted(pkg.binding.EXPORTS) == syms
+    # the persistent kernels' switches are exported too, but declared OUTSIDE the boundary header (round 5)
+    exp = declared_symbols("fhe_ntt_experimental.h")
+    assert exp == sorted(pkg.binding.EXPORTS_EXPERIMENTAL) and not set(exp) & set(syms)
+    for s in exp:
+        assert hasattr(lib, s), f"{s} declared in include/fhe_ntt_experimental.h but not exported"
 
 
 def test_product_does_not_touch_the_oracle():

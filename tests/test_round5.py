@@ -77,3 +77,91 @@ def test_every_group_shape_full_and_ragged(pkg, oracle, q, log_n):
             want = oracle.rq_mul(q, n, a, b)
             for x, y in zip(got, want):
                 assert np.array_equal(np.asarray(x).reshape(-1), y.reshape(-1)), (q, n, batch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setting", [("B", 1, 1, 1), ("B", 1, 0, 2), ("E", 1, 1, 2), ("E", 1, 0, 4), ("D", 1, 1, 1)],
+                         ids=lambda s: f"{s[0]}:{s[1]},{s[2]},{s[3]}")
+def test_persistent_under_uneven_load(pkg, oracle, setting):
+    """include/fhe_ntt_experimental.h: the one-launch kernels hand their intermediate over with plain stores, an agent-scope
+    counter and 8-byte sc1 loads — a form the microarchitecture guide has no measured row for.  Its advice for any hand-off:
+    test under UNEVEN load with an L1-warm consumer, every word compared.  Here a copy kernel streams on a second stream
+    while the persistent kernel runs (its workgroups progress at different rates and are evicted and resumed unevenly),
+    the rings are as short as the protocol allows (ring slots are rewritten and re-read hundreds of times by the same
+    CUs: consumers meet lines they have read before), and all 300 x 65536 words must be the two-pass kernels' words, three
+    launches in a row."""
+    import torch
+
+    assert pkg.binding.device_count() >= 1, "no HIP device: -m gpu tests need a real MI355X"
+    B = pkg.binding
+    n, batch = 1 << 16, 300
+    plan = pkg.Plan(Q61, n)
+    main = torch.cuda.current_stream()
+    x = torch.empty(batch * n, dtype=torch.int64, device="cuda:0")
+    want = torch.empty_like(x)
+    got = torch.empty_like(x)
+    B.fill_synthetic_dev(Q61, 0xF4E50555, 0, batch * n, x.data_ptr(), main.cuda_stream)
+    try:
+        B.set_persist(0)
+        plan.forward_dev(x.data_ptr(), want.data_ptr(), batch, main.cuda_stream)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        src = torch.empty(96 << 20, dtype=torch.int64, device="cuda:0")        # 768 MiB: beyond the Infinity Cache
+        dst = torch.empty_like(src)
+        B.set_persist(*setting)
+        for rep in range(3):
+            got.zero_()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                for _ in range(6):                                               # ~1.5 ms of streaming per copy
+                    dst.copy_(src, non_blocking=True)
+            plan.forward_dev(x.data_ptr(), got.data_ptr(), batch, main.cuda_stream)
+            torch.cuda.synchronize()
+            B.persist_status()
+            assert torch.equal(got, want), (setting, rep, int((got != want).sum()))
+    finally:
+        B.set_persist(0)
+    k = 2
+    assert np.array_equal(want[: k * n].cpu().numpy().view(np.uint64), oracle.ntt(Q61, n, x[: k * n].cpu().numpy().view(np.uint64)).reshape(-1))
+
+
+@pytest.mark.gpu
+def test_short_lived_threads_do_not_accumulate_workspaces(pkg, oracle):
+    """library workspaces are keyed by the calling thread; a pool of short-lived threads on one stream must not
+    leave one buffer per thread that ever lived.  Forty threads, one after the other, each run a two-pass product (library
+    workspace, d_work = NULL) on the NULL stream and exit: the bytes the library holds after the last one are what it held
+    after the first (a dead thread's buffer is adopted by the next thread on that stream, in stream order), and every
+    product is the oracle's."""
+    import threading
+
+    import torch
+
+    assert pkg.binding.device_count() >= 1, "no HIP device: -m gpu tests need a real MI355X"
+    L = pkg.load_library()
+    q, n, batch = Q61, 16384, 5
+    plan = pkg.Plan(q, n)
+    a = oracle.fill_synthetic(q, 1700, 0, batch * n)
+    b = oracle.fill_synthetic(q, 1800, 0, batch * n)
+    want = oracle.rq_mul(q, n, a, b)[0]
+    da = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    db = torch.from_numpy(b.view(np.int64).copy()).cuda()
+    outs, held, errs = [], [], []
+
+    def work():
+        try:
+            dc = torch.empty_like(da)
+            plan.rq_mul_dev(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, stream=None)
+            outs.append(dc)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    for _ in range(40):
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+        held.append(int(L.fhe_ntt_workspace_bytes()))
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert held[0] > 0 and held[-1] == held[0], held
+    for dc in outs:
+        assert np.array_equal(dc.cpu().numpy().view(np.uint64), want.reshape(-1))

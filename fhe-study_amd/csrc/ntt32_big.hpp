@@ -32,16 +32,21 @@ template <int LP, int AF, int AT>
 __device__ __forceinline__ void exchange_big(u32 (&v)[Big32<LP>::VT][16], u32 *lds, u32 tf) {
     using C = Big32<LP>;
     constexpr u32 TH = C::TH;
+    // (slot of register 0) + a constant per register: ntt_rounds.hpp pad16_koff — per register the compiler recomputed the slot
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < C::VT; s++)
+    for (int s = 0; s < C::VT; s++) {
+        const u32 bf = pad16(field_of<AF>(tf + s * TH, 0));
 #pragma unroll
-        for (int k = 0; k < 16; k++) lds[pad16(field_of<AF>(tf + s * TH, k))] = v[s][k];
+        for (int k = 0; k < 16; k++) lds[bf + pad16_koff<AF>(k)] = v[s][k];
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < C::VT; s++)
+    for (int s = 0; s < C::VT; s++) {
+        const u32 bt = pad16(field_of<AT>(tf + s * TH, 0));
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[s][k] = lds[pad16(field_of<AT>(tf + s * TH, k))];
+        for (int k = 0; k < 16; k++) v[s][k] = lds[bt + pad16_koff<AT>(k)];
+    }
 }
 
 // Forward stages with ct32_loose: the bound of the values grows by 2p per stage from B·p and must stay below 25p, so

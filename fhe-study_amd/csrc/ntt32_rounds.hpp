@@ -198,12 +198,13 @@ __device__ __forceinline__ void round_inv32_tw(u32 (&v)[16], const Tw32 (&t)[15]
 template <int LP, int AF, int AT, bool FIRST>
 __device__ __forceinline__ void exchange32(u32 (&v)[16], u32 *lds, u32 w, u32 tf) {
     constexpr int M = 1 << LP;
+    const u32 bf = pad16(w * M + field_of<AF>(tf, 0)), bt = pad16(w * M + field_of<AT>(tf, 0));   // + a constant per register (ntt_rounds.hpp: pad16_koff)
     if (!FIRST) __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) lds[pad16(w * M + field_of<AF>(tf, k))] = v[k];
+    for (int k = 0; k < 16; k++) lds[bf + pad16_koff<AF>(k)] = v[k];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
+    for (int k = 0; k < 16; k++) v[k] = lds[bt + pad16_koff<AT>(k)];
 }
 
 // round 0 on BITS by table look-up (see ntt_rounds.hpp round0_bits; tables per prime, built on the host)

@@ -941,6 +941,9 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
     if (batch_tile == 0) batch_tile = batch;
+    // (Round 5 measured the tiles of a batch alternating between the caller's stream and a helper stream, so that one
+    // tile's middle kernel — bound by its instruction count — runs beside another's memory-bound strided passes: 0.909 ->
+    // 0.903 .. 0.933 M products/s at 2^16 for tiles of 128 .. 1024 polynomials, i.e. nothing; gpurun_out/r5f.  Not kept.)
     for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
         const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile, o = b0 * n;
         const bool mg = plan_runs_montgomery(p);

@@ -460,15 +460,19 @@ __device__ __forceinline__ void st_s(u64 saddr, u32 lane_boff, u64 x) {
     gu64 *p = reinterpret_cast<gu64 *>(saddr + lane_boff);
     if (NT) __builtin_nontemporal_store(x, p); else *p = x;
 }
-template <bool NT>
+// LOOP: the accesses sit in a loop whose lane offset is loop-invariant: the offset is made opaque once per call, or the
+// compiler hoists its zero-extension out of the loop and every access becomes a 64-bit vector add + a vaddr access
+template <bool NT, bool LOOP = false>
 __device__ __forceinline__ void ld16(u64 (&v)[16], const u64 *ubase, u32 sh, u32 lane_boff) {
+    if (LOOP) asm volatile("" : "+v"(lane_boff));
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         v[k] = ld_s<NT>(scalar_addr(ubase + ((u64)k << sh)), lane_boff);
     }
 }
-template <bool NT>
+template <bool NT, bool LOOP = false>
 __device__ __forceinline__ void st16(u64 *ubase, u32 sh, u32 lane_boff, const u64 (&v)[16]) {
+    if (LOOP) asm volatile("" : "+v"(lane_boff));
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         st_s<NT>(scalar_addr(ubase + ((u64)k << sh)), lane_boff, v[k]);
@@ -536,15 +540,22 @@ struct SlabIo {
 // FIRST = false: the tile was read by an earlier exchange, so a barrier precedes the scatter.
 // No trailing barrier: whoever writes the tile next either is this function (FIRST = false)
 // or writes exactly the slots it has just gathered (the store transpose of the forward pass).
+// pad16 slot of register k of window A, as (slot of register 0) + (a constant): the bit fields of field_of<A>(tf, k) are
+// disjoint, so both e and e >> 4 split into the thread's part and the k-part — (k << A) + ((k << A) >> 4).  Written as
+// pad16(w M + field_of<A>(tf, k)) per register, the compiler recomputed the slot for every k at LP >= 9 (v_or + v_lshr +
+// v_add3 per access: ~100 vector instructions per exchange of the N = 4096 kernels, round 5).
+template <int A>
+constexpr u32 pad16_koff(int k) { return ((u32)k << A) + (((u32)k << A) >> 4); }
 template <int LP, int AF, int AT, bool FIRST>
 __device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u32 tf) {
     constexpr int M = 1 << LP;
+    const u32 bf = pad16(w * M + field_of<AF>(tf, 0)), bt = pad16(w * M + field_of<AT>(tf, 0));
     if (!FIRST) __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) lds[pad16(w * M + field_of<AF>(tf, k))] = v[k];
+    for (int k = 0; k < 16; k++) lds[bf + pad16_koff<AF>(k)] = v[k];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = lds[pad16(w * M + field_of<AT>(tf, k))];
+    for (int k = 0; k < 16; k++) v[k] = lds[bt + pad16_koff<AT>(k)];
 }
 
 // The LP stages of a contiguous pass on the 16 registers of each thread: round 0 in the window the

@@ -35,17 +35,18 @@ struct SqCfg {
 template <int LP, int AF, int AT, bool FIRST>
 __device__ __forceinline__ void sq_exchange2(u32 (&va)[16], u32 (&vb)[16], u32 *la, u32 *lb, u32 w, u32 tf) {
     constexpr int M = 1 << LP;
+    const u32 bf = pad16(w * M + field_of<AF>(tf, 0)), bt = pad16(w * M + field_of<AT>(tf, 0));   // + a constant per register (ntt_rounds.hpp: pad16_koff)
     if (!FIRST) __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u32 s = pad16(w * M + field_of<AF>(tf, k));
+        const u32 s = bf + pad16_koff<AF>(k);
         la[s] = va[k];
         lb[s] = vb[k];
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u32 s = pad16(w * M + field_of<AT>(tf, k));
+        const u32 s = bt + pad16_koff<AT>(k);
         va[k] = la[s];
         vb[k] = lb[s];
     }

@@ -382,6 +382,33 @@ __device__ __forceinline__ void bf_v18(u64& x, u64& y, const TS& t, const QS& c,
         : "vcc", "v58", "v59", "v60", "v61", "v62", "v63");
   x = xo; y = pack(yl, yh);
 }
+// v19 (round 5): v16 — any odd q < 2^61, seven multiplies — as ONE asm statement, the step that turned v14 into a 14 %
+// kernel gain.  14 instructions: N = y0 a0 + y1 b0 (carry c1), m = N0 qinv, N += m q0 (low word -> 0, carry c2),
+// H = {N1, c1 + c2} + y0 a1 + y1 b1 + m q1 = (T + m q) >> 32 in [0, 3q); x' = u + H, y' = u + 3q - H as a borrow chain.
+__device__ __forceinline__ void bf_v19(u64& x, u64& y, const TS& t, const QS& c, bool) {
+  const u64 u = csub32(x, c.neg4q);
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+  u64 xo; u32 yl, yh;
+  asm("v_mad_u64_u32 v[60:61], vcc, %[y0], %[a0], 0\n\t"
+        "v_mad_u64_u32 v[60:61], vcc, %[y1], %[b0], v[60:61]\n\t"     // carry c1 -> vcc
+        "v_addc_co_u32 v63, vcc, 0, 0, vcc\n\t"                        // c1
+        "v_mul_lo_u32 v58, v60, %[qinv]\n\t"                           // m
+        "v_mad_u64_u32 v[60:61], vcc, v58, %[q0], v[60:61]\n\t"       // low word becomes 0; carry c2
+        "v_addc_co_u32 v63, vcc, 0, v63, vcc\n\t"                      // c1 + c2
+        "v_mov_b32 v62, v61\n\t"
+        "v_mad_u64_u32 v[62:63], vcc, %[y0], %[a1], v[62:63]\n\t"
+        "v_mad_u64_u32 v[62:63], vcc, %[y1], %[b1], v[62:63]\n\t"
+        "v_mad_u64_u32 v[62:63], vcc, v58, %[q1], v[62:63]\n\t"       // H
+        "v_lshl_add_u64 v[60:61], %[u], 0, %[k3]\n\t"                  // u + 3q
+        "v_lshl_add_u64 %[x], %[u], 0, v[62:63]\n\t"
+        "v_sub_co_u32 %[yl], vcc, v60, v62\n\t"
+        "v_subb_co_u32 %[yh], vcc, v61, v63, vcc"
+        : [x] "=&v"(xo), [yl] "=&v"(yl), [yh] "=&v"(yh)
+        : [u] "v"(u), [y0] "v"(y0), [y1] "v"(y1), [a0] "v"(t.a0), [a1] "v"(t.a1), [b0] "v"(t.b0), [b1] "v"(t.b1),
+          [qinv] "s"(c.qinv), [q0] "s"(c.q0), [q1] "s"(c.q1), [k3] "s"(c.q3p1 - 1)
+        : "vcc", "v58", "v60", "v61", "v62", "v63");
+  x = xo; y = pack(yl, yh);
+}
 template <int V>
 __global__ void ks(u64* p, QS c, TS t, int iters) {
   u64 x[4], y[4];
@@ -395,6 +422,7 @@ __global__ void ks(u64* p, QS c, TS t, int iters) {
       if (V == 16) bf_v16(x[j], y[j], t, c, false);
       if (V == 17) bf_v17(x[j], y[j], t, c, false);
       if (V == 18) bf_v18(x[j], y[j], t, c, false);
+      if (V == 19) bf_v19(x[j], y[j], t, c, false);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -403,6 +431,7 @@ __global__ void ks(u64* p, QS c, TS t, int iters) {
       if (V == 16) bf_v16(x[j], y[j], t, c, true);
       if (V == 17) bf_v17(x[j], y[j], t, c, true);
       if (V == 18) bf_v18(x[j], y[j], t, c, true);
+      if (V == 19) bf_v19(x[j], y[j], t, c, true);
     }
   }
 #pragma unroll
@@ -578,7 +607,7 @@ int main() {
     }
   }
 
-  for (int v : {14, 15, 16, 17, 18}) {   // round 3: five-multiply (v14, v15) and seven-multiply (v16) butterflies
+  for (int v : {14, 15, 16, 17, 18, 19}) {   // round 3: five-multiply (v14, v15) and seven-multiply (v16) butterflies
     const u64 qq = v == 14 ? 0x1ffffff900000001ull : q;           // v14 needs q = 1 (mod 2^32)
     const u64 ww = w % qq;
     u64 a, b;
@@ -591,7 +620,7 @@ int main() {
           (u32)(0u - (u32)(qq >> 32)), (u32)qq, (u32)(qq >> 32)};
     hipMemcpy(p, h.data(), 512 * 8, hipMemcpyHostToDevice);
     int it = 6;
-    if (v == 14) ks<14><<<1, 64>>>(p, cs, t, it); else if (v == 15) ks<15><<<1, 64>>>(p, cs, t, it); else if (v == 16) ks<16><<<1, 64>>>(p, cs, t, it); else if (v == 17) ks<17><<<1, 64>>>(p, cs, t, it); else ks<18><<<1, 64>>>(p, cs, t, it);
+    if (v == 14) ks<14><<<1, 64>>>(p, cs, t, it); else if (v == 15) ks<15><<<1, 64>>>(p, cs, t, it); else if (v == 16) ks<16><<<1, 64>>>(p, cs, t, it); else if (v == 17) ks<17><<<1, 64>>>(p, cs, t, it); else if (v == 18) ks<18><<<1, 64>>>(p, cs, t, it); else ks<19><<<1, 64>>>(p, cs, t, it);
     hipMemcpy(o.data(), p, 512 * 8, hipMemcpyDeviceToHost);
     int bad = 0; u64 mx = 0;
     for (int tt = 0; tt < 64; tt++) for (int j = 0; j < 4; j++) {
@@ -600,7 +629,7 @@ int main() {
       if (gx % qq != xo || gy % qq != yo) bad++;
       if (gx > mx) mx = gx; if (gy > mx) mx = gy;
     }
-    const char* nm = v == 14 ? "v14 split+Montgomery q=1 mod 2^32 (5 mul)" : v == 15 ? "v15 split+pseudo-Mersenne q61 (5 mul)" : v == 16 ? "v16 split+word Montgomery any q (7 mul)" : v == 17 ? "v17 v15 in one asm statement" : "v18 v17 with a borrow-chain subtraction (13 instr)";
+    const char* nm = v == 14 ? "v14 split+Montgomery q=1 mod 2^32 (5 mul)" : v == 15 ? "v15 split+pseudo-Mersenne q61 (5 mul)" : v == 16 ? "v16 split+word Montgomery any q (7 mul)" : v == 17 ? "v17 v15 in one asm statement" : v == 18 ? "v18 v17 with a borrow-chain subtraction (13 instr)" : "v19 v16 in one asm statement (any odd q, 7 mul, 14 instr)";
     printf("%-20s correctness: %s (max value / q = %.3f)\n", nm, bad ? "FAIL" : "ok", (double)mx / (double)qq);
     for (int wpS : {2, 4, 8}) {
       int blocks = cus * wpS, threads = 256, iters = 2000;
@@ -608,7 +637,7 @@ int main() {
       float best = 1e30f;
       for (int r = 0; r < 4; r++) {
         hipEventRecord(e0);
-        if (v == 14) ks<14><<<blocks, threads>>>(p, cs, t, iters); else if (v == 15) ks<15><<<blocks, threads>>>(p, cs, t, iters); else if (v == 16) ks<16><<<blocks, threads>>>(p, cs, t, iters); else if (v == 17) ks<17><<<blocks, threads>>>(p, cs, t, iters); else ks<18><<<blocks, threads>>>(p, cs, t, iters);
+        if (v == 14) ks<14><<<blocks, threads>>>(p, cs, t, iters); else if (v == 15) ks<15><<<blocks, threads>>>(p, cs, t, iters); else if (v == 16) ks<16><<<blocks, threads>>>(p, cs, t, iters); else if (v == 17) ks<17><<<blocks, threads>>>(p, cs, t, iters); else if (v == 18) ks<18><<<blocks, threads>>>(p, cs, t, iters); else ks<19><<<blocks, threads>>>(p, cs, t, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (r && ms < best) best = ms;
       }

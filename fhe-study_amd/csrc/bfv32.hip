@@ -278,8 +278,11 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
         u32 tfe = tf;
         asm volatile("" : "+v"(tfe));                           // (formed here, from an opaque lane id: no address registers held across the transforms)
         u64 *po = a.out + ((u64)which * a.batch + b) * K::M + tfe;
-        u64 *ps = po;
-        asm volatile("" : "+v"(ps));
+        // (an integer made opaque, then named in the GLOBAL address space: the laundered generic pointer of round 4 read
+        // back with flat_load, which waits for vmcnt(0) AND lgkmcnt(0) — every reload also waited for the previous pair's store)
+        u64 psa = reinterpret_cast<u64>(po);
+        asm volatile("" : "+v"(psa));
+        const gu64 *ps = reinterpret_cast<const gu64 *>(psa);
         if constexpr (pr == 1) parked = ps[0];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -365,8 +368,9 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
         block(1u, v1);
         const Tw32 ni = a.ninv_mont[pr], w1ni = a.w1ninv_mont[pr];
         u64 pk0 = 0, pk1 = 0;                                   // the parked digits of the pair at hand
-        u64 *ps0 = park0, *ps1 = park1;
-        asm volatile("" : "+v"(ps0), "+v"(ps1));                // (here, not at the top: no registers held across the transforms)
+        u64 psa0 = reinterpret_cast<u64>(park0), psa1 = reinterpret_cast<u64>(park1);
+        asm volatile("" : "+v"(psa0), "+v"(psa1));              // (here, not at the top: no registers held across the transforms)
+        const gu64 *ps0 = reinterpret_cast<const gu64 *>(psa0), *ps1 = reinterpret_cast<const gu64 *>(psa1);   // global, not flat: see the tensor kernel
         if constexpr (pr >= 1) pk0 = ps0[0];
         if constexpr (pr == 2) pk1 = ps1[0];
 #pragma unroll

@@ -49,7 +49,7 @@ VALU_PEAK_GBFLY = 2018.7
 # the five-multiply butterfly of pseudo-Mersenne moduli (zq_device.hpp: ct_bfly_pm), which the headline modulus runs:
 # tools/ubench_bfly.hip v18 (13 instructions, round 4) at 8 waves per SIMD, profiles/r04_ubench_bfly.txt
 VALU_PEAK_GBFLY_PM = 2837.2
-# the word-Montgomery butterfly of moduli q = 1 (mod 2^32) (zq_device.hpp: ct_bfly_mg; forward transforms only): tools/ubench_bfly.hip
+# the word-Montgomery butterfly of moduli q = 1 (mod 2^32) (zq_device.hpp: ct_bfly_mg / gs_bfly_mg: transforms and products): tools/ubench_bfly.hip
 # v14 at 8 waves per SIMD, profiles/r04_ubench_bfly.txt (v14 is the statement-per-instruction form of it: a lower bound of the peak)
 VALU_PEAK_GBFLY_MG = 2219.9
 # the 32-bit butterfly of the small-prime kernels (digit32.hip / bfv32.hip): tools/ubench_bfly.hip v13, registers only
@@ -57,7 +57,7 @@ VALU_PEAK_GBFLY32 = 5730.0
 # HBM traffic per launch of each kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
 # WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Counters cannot be read from inside this process.
-PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def parse():

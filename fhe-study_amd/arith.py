@@ -148,7 +148,7 @@ def pm_params(q):
 
 def mg_params(q):
     """The word-Montgomery form the engine detects at plan time (csrc/capi.hip: build_plan, csrc/zq_device.hpp: ct_bfly_mg):
-    q = qh 2^32 + 1 below 2^61 (and not pseudo-Mersenne, which cannot coincide).  Such a modulus runs its FORWARD transforms
+    q = qh 2^32 + 1 below 2^61 (and not pseudo-Mersenne, which cannot coincide).  Such a modulus runs its transforms (both directions) and Rq products
     on tables {w 2^32 mod q, w 2^64 mod q}: q^-1 = 1 (mod 2^32), so a Montgomery word step needs no multiplication by it.
     Returns the kernels' constant (2^32 - qh), or None.  Host-side restatement for the tests; the library decides on its own."""
     q = int(q)

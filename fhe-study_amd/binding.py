@@ -46,7 +46,7 @@ EXPORTS = [
     "fhe_ntt_set_batch_tile", "fhe_ntt_kernel_timing_enable", "fhe_ntt_kernel_timing_read",
     "fhe_ntt_kernel_timing_reset",
     "fhe_ntt_device_count", "fhe_last_error", "fhe_ntt_version", "fhe_ntt_shutdown",
-    "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_ntt_release_stream_workspace", "fhe_ntt_workspace_bytes",
+    "fhe_ntt_plan_prepare", "fhe_ntt_plan_arithmetic", "fhe_ntt_set_check_canonical", "fhe_shard_range", "fhe_shard_gather_dev", "fhe_ntt_release_stream_workspace", "fhe_ntt_workspace_bytes",
     "fhe_tggsw_prepared_words", "fhe_tggsw_prepare_dev", "fhe_tggsw_external_product_prepared_dev",
     "fhe_glwe_ksk_prepared_words", "fhe_glwe_ksk_prepare_dev", "fhe_glwe_key_switch_prepared_dev",
     "fhe_bfv_rlk_prepared_words", "fhe_bfv_rlk_prepare_dev", "fhe_bfv_relinearize_prepared_dev", "fhe_bfv_mul_prepared_dev",
@@ -243,6 +243,7 @@ def load_library():
     L.fhe_ntt_release_stream_workspace.argtypes = [_vp]
     L.fhe_ntt_set_check_canonical.argtypes = [_int]
     L.fhe_shard_range.argtypes = [_sz, _uint, _uint, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
+    L.fhe_shard_gather_dev.argtypes = [_sz, _sz, _uint, ctypes.POINTER(_int), ctypes.POINTER(_vp), _int, _vp, _vp]
     L.fhe_last_error.restype = ctypes.c_char_p
     L.fhe_ntt_version.restype = ctypes.c_char_p
     for name in EXPORTS:
@@ -441,6 +442,15 @@ def tggsw_external_product(n, k, l, tggsw, tglwe):
 def fill_synthetic_dev(q, seed, first_index, count, d_out, stream=None):
     _check(load_library().fhe_fill_synthetic_dev(int(q), int(seed), int(first_index), int(count),
                                                  d_out, stream))
+
+
+def shard_gather_dev(total_rows, row_words, src_devices, d_src_shards, dst_device, d_dst, stream=None):
+    """fhe_shard_gather_dev: the shards of a block-partitioned batch (entry r = device pointer to rank r's rows of
+    shard_range(total_rows, world, r), or None for an empty shard) copied in rank order onto dst_device — no torch, no RCCL."""
+    world = len(src_devices)
+    devs = (_int * world)(*[int(d) for d in src_devices])
+    ptrs = (_vp * world)(*[(_vp(int(p)) if p else _vp(None)) for p in d_src_shards])
+    _check(load_library().fhe_shard_gather_dev(int(total_rows), int(row_words), world, devs, ptrs, int(dst_device), d_dst, stream))
 
 
 def device_count():

@@ -201,9 +201,12 @@ __device__ __forceinline__ u64 zq_from_f64_small(double ef, double qf, double qi
 // from the host, q0 = fl(N y), r = N - q0 den (one fma: exact up to a rounding of relative size 2^-53 of r), x = fl(q0 + r y).
 // q0 + r y differs from N / den by |N / den - q0| 2^-53 <= 2^-104 |N / den|, so x IS fl(N / den) unless N / den lies within
 // 2^-104 (relative) of the midpoint m / 2^j of two neighbouring doubles — impossible here: N is an integer (num, v integers;
-// a rounded product of integers above 2^53 is still one), den an ODD integer below 2^53 (q or q^2 / ...: the host checks),
-// so N / den = m / 2^j would force den | N, an integer, not a midpoint, and otherwise |N 2^j - m den| >= 1 puts the quotient
-// at least 2^-j / den >= 2^-53 ulp-widths away.  Same double as the reference's `/`, ~8 instructions shorter per coefficient.
+// a rounded product of integers above 2^53 is still one), den an ODD integer below 2^48 (q or q^2 / ...: the host checks —
+// zring.hip bfv32_rden), so N / den = m / 2^j would force den | N, an integer, not a midpoint, and otherwise
+// |N 2^j - m den| >= 1 puts the quotient at least 1 / den > 2^-48 ulp-widths from the midpoint, against an error of the
+// two-fma form of ~2^-51 ulp-widths: a margin of 2^3 (with den < 2^53 the same argument leaves none; no counter-example
+// in 600 k adversarial near-midpoint samples there either, but the gate now matches the proof — ADVICE r04).
+// Same double as the reference's `/`, ~8 instructions shorter per coefficient.
 __device__ __forceinline__ double exact_quotient(double N, double den, double rden) {
     const double q0 = N * rden;
     const double r = fma(-q0, den, N);

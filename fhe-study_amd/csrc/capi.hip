@@ -415,6 +415,32 @@ extern "C" int fhe_shard_range(size_t total, unsigned world, unsigned rank, size
     return FHE_OK;
 }
 
+// shards of a block-partitioned batch -> one device, without torch / RCCL (include/fhe_ntt.h)
+extern "C" int fhe_shard_gather_dev(size_t total_rows, size_t row_words, unsigned world, const int *src_devices,
+                                    const void *const *d_src_shards, int dst_device, void *d_dst, void *hip_stream) {
+    if (world == 0) return fail(FHE_E_INVALID, "fhe_shard_gather_dev: world is 0");
+    if (!src_devices || !d_src_shards) return fail(FHE_E_NULL, "fhe_shard_gather_dev: NULL shard table");
+    if (total_rows == 0 || row_words == 0) return FHE_OK;
+    if (!d_dst) return fail(FHE_E_NULL, "fhe_shard_gather_dev: NULL destination");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(FHE_E_NO_DEVICE, "fhe_shard_gather_dev: no HIP device available; libfhe_ntt has no CPU fallback");
+    }
+    if (dst_device < 0 || dst_device >= ndev) return fail(FHE_E_INVALID, "fhe_shard_gather_dev: dst_device %d of %d", dst_device, ndev);
+    for (unsigned r = 0; r < world; r++) {
+        size_t b = 0, e = 0;
+        int rc = fhe_shard_range(total_rows, world, r, &b, &e);
+        if (rc != FHE_OK) return rc;
+        if (e == b) continue;
+        if (!d_src_shards[r]) return fail(FHE_E_NULL, "fhe_shard_gather_dev: shard %u (rows %zu..%zu) is NULL", r, b, e);
+        if (src_devices[r] < 0 || src_devices[r] >= ndev) return fail(FHE_E_INVALID, "fhe_shard_gather_dev: src_devices[%u] = %d of %d", r, src_devices[r], ndev);
+        HIP_TRY(hipMemcpyPeerAsync((u64 *)d_dst + b * row_words, dst_device, d_src_shards[r], src_devices[r],
+                                   (e - b) * row_words * sizeof(u64), (hipStream_t)hip_stream));
+    }
+    return FHE_OK;
+}
+
 // ---- opt-in input validation ---------------------------------------------------------------
 // The reference cannot construct a Zq with v >= q (Zq::from_u64 reduces, zq.rs:21-30); a C caller
 // can hand one over, and the lazy butterflies then return words that are simply wrong.  With
@@ -437,6 +463,11 @@ extern "C" int fhe_ntt_set_check_canonical(int on) {
     return FHE_OK;
 }
 static int check_canonical_dev(const fhe_ntt_plan *plan, const void *d_x, size_t count, hipStream_t st, const char *who) {
+    return fhe_check_canonical_words(plan->q, d_x, count, st, who);
+}
+// the same check for entry points that have a modulus but no plan (zring.hip: the BFV products read canonical words as
+// their own residues when q is below every prime in use — FHE_NTT_CHECK_CANONICAL=1 makes them verify that contract)
+int fhe_check_canonical_words(uint64_t q, const void *d_x, size_t count, hipStream_t st, const char *who) {
     if (!check_canonical_on() || !d_x || count == 0) return FHE_OK;
     void *df = nullptr;
     size_t cap = 0;
@@ -445,14 +476,14 @@ static int check_canonical_dev(const fhe_ntt_plan *plan, const void *d_x, size_t
     if (rc != FHE_OK) return rc;
     int flag = 0;
     hipError_t e = hipMemsetAsync(df, 0, sizeof(int), st);
-    if (e == hipSuccess) e = fhe::launch_check_canonical((const u64 *)d_x, count, plan->q, (int *)df, st);
+    if (e == hipSuccess) e = fhe::launch_check_canonical((const u64 *)d_x, count, q, (int *)df, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&flag, df, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     else (void)hipStreamSynchronize(st);
     fhe_stage_release(df, cap, dev);
     if (e != hipSuccess) return hip_fail(e, "canonical check");
     if (flag) return fail(FHE_E_NOT_CANONICAL, "%s: an input coefficient >= q=%llu (FHE_NTT_CHECK_CANONICAL)", who,
-                          (unsigned long long)plan->q);
+                          (unsigned long long)q);
     return FHE_OK;
 }
 

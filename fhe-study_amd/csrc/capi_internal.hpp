@@ -45,6 +45,8 @@ int fhe_hip_fail(hipError_t e, const char *what);
     } while (0)
 
 int fhe_current_device(int *dev);
+// FHE_NTT_CHECK_CANONICAL / fhe_ntt_set_check_canonical(1): FHE_E_NOT_CANONICAL if any of `count` device words is >= q (synchronises `st`); FHE_OK when the check is off
+int fhe_check_canonical_words(uint64_t q, const void *d_x, size_t count, hipStream_t st, const char *who);
 int fhe_device_plan(const fhe_ntt_plan *plan, fhe::DevicePlan *dp);
 fhe::u64 fhe_batch_tile_for(const fhe_ntt_plan *plan);
 // grow-only scratch per (slot, device, stream); slot 0 = fhe_rq_mul_dev / bfv tensor, slot 1 = zring, glue

@@ -46,7 +46,7 @@ namespace fhe {
 // rows are 2^src_log_n arbitrary 64-bit words, reduced mod q and zero-padded to n in the load.
 // AR: 0 = q < 2^62 (Harvey [0,4q)), 1 = q < 2^61 (Shoup, compile-time bounds), 2 = pseudo-Mersenne q (zq_device.hpp:
 // five-multiply butterflies; `a.tw` then holds {w, w 2^32 mod q}; SRC_PLAIN only), 4 = q = 1 (mod 2^32) below 2^61 (word
-// Montgomery, `a.tw` = {w 2^32, w 2^64 mod q}; the FORWARD kernels only, SRC_PLAIN only).
+// Montgomery, `a.tw` = {w 2^32, w 2^64 mod q}; forward and inverse transforms and both Rq products; SRC_PLAIN only).
 template <int LP, bool FINAL, int AR, int SRC = SRC_PLAIN>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
     constexpr bool WIDE = AR == 1;
@@ -806,7 +806,7 @@ static hipError_t inv_contig_dispatch_mg(int lp, bool final, const PassArgs &a, 
     return hipErrorInvalidValue;
 }
 static hipError_t inv_contig_dispatch(int ar, int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st) {
-    if (ar == kArMontgomeryFwd) return mul_in ? hipErrorInvalidValue : inv_contig_dispatch_mg(lp, final, a, st);
+    if (ar == kArMontgomery) return mul_in ? hipErrorInvalidValue : inv_contig_dispatch_mg(lp, final, a, st);
     return ar == 2 ? inv_contig_dispatch_ar<2>(lp, final, mul_in, a, st)
          : ar == 1 ? inv_contig_dispatch_ar<1>(lp, final, mul_in, a, st)
                    : inv_contig_dispatch_ar<0>(lp, final, mul_in, a, st);
@@ -823,7 +823,7 @@ static hipError_t strided_dispatch_ar(int la, const PassArgs &a, hipStream_t st,
 }
 template <bool INV>
 static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
-    if (ar == kArMontgomeryFwd) return strided_dispatch_ar<INV, 4>(la, a, st, operands);
+    if (ar == kArMontgomery) return strided_dispatch_ar<INV, 4>(la, a, st, operands);
     return ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands)
          : ar == 1 ? strided_dispatch_ar<INV, 1>(la, a, st, operands)
                    : strided_dispatch_ar<INV, 0>(la, a, st, operands);
@@ -850,7 +850,7 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
     // n < 16: one thread per polynomial on the Shoup tables
     // q = 1 (mod 2^32): the forward kernels on the word-Montgomery table (AR = 4); every other entry point keeps p.arith
     const bool mg = L >= 4 && p.tw_fwd_mg != nullptr && p.arith == kArWide61;
-    const int ar = L < 4 ? (p.wide ? 1 : 0) : mg ? (int)kArMontgomeryFwd : p.arith;
+    const int ar = L < 4 ? (p.wide ? 1 : 0) : mg ? (int)kArMontgomery : p.arith;
     DevicePlan pt = p;
     pt.arith = mg ? (int)kArWide61 : ar;
     set_tables(a, pt, false);
@@ -947,7 +947,7 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
     for (u64 b0 = 0; b0 < batch; b0 += batch_tile) {
         const u64 nb = batch - b0 < batch_tile ? batch - b0 : batch_tile, o = b0 * n;
         const bool mg = plan_runs_montgomery(p);
-        const int ar = mg ? (int)kArMontgomeryFwd : p.arith;
+        const int ar = mg ? (int)kArMontgomery : p.arith;
         PassArgs f{};
         set_tables(f, p, false); f.batch = nb;
         if (mg) f.tw = p.tw_fwd_mg;
@@ -1071,7 +1071,7 @@ hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2
     const int L = p.log_n;
     // q = 1 (mod 2^32): a plain inverse transform (no product in its load) runs on the word-Montgomery table (AR = 4)
     const bool mg = L >= 4 && p.tw_inv_mg != nullptr && p.arith == kArWide61 && in2 == nullptr;
-    const int ar = L < 4 ? (p.wide ? 1 : 0) : mg ? (int)kArMontgomeryFwd : p.arith;
+    const int ar = L < 4 ? (p.wide ? 1 : 0) : mg ? (int)kArMontgomery : p.arith;
     DevicePlan pt = p;
     pt.arith = mg ? (int)kArWide61 : ar;
     set_tables(a, pt, true);

@@ -48,7 +48,7 @@ enum : int {
     kArWide61 = 1,      // q < 2^61: Shoup products, compile-time bounds up to 8q
     kArPMersenne = 2,   // q = 2^k - delta: five-multiply butterflies on {w, w 2^32 mod q}
     kArStrict63 = 3,    // 2^62 <= q < 2^63: strict butterflies in plain kernels (generic63.hip)
-    kArMontgomeryFwd = 4,   // never a plan's arith: what launch_ntt_forward / launch_ntt_inverse pass their kernels when tw_*_mg are set (q = 1 mod 2^32)
+    kArMontgomery = 4,   // never a plan's arith: what launch_ntt_forward / launch_ntt_inverse pass their kernels when tw_*_mg are set (q = 1 mod 2^32)
 };
 
 struct PassArgs {

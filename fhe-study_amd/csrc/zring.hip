@@ -565,11 +565,12 @@ static bool bfv32_small_f64_on() {
     static const bool on = [] { const char *e = getenv("FHE_BFV_SMALL_F64"); return !(e && e[0] == '0'); }();
     return on;
 }
-// the epilogue's quotient as reciprocal + two fma (bfv32.hip: exact_quotient) needs an ODD integer denominator below 2^53
+// the epilogue's quotient as reciprocal + two fma (bfv32.hip: exact_quotient) needs an ODD integer denominator; the argument
+// written there covers denominators below 2^48 (what is used: q < 2^21, p = q^2 < 2^42) — the gate is that, not 2^53
 // (FHE_BFV_FAST_DIV=0: the IEEE division sequence — the A/B)
 static double bfv32_rden(uint64_t den) {
     static const bool on = [] { const char *e = getenv("FHE_BFV_FAST_DIV"); return !(e && e[0] == '0'); }();
-    return (on && (den & 1ull) && den < (1ull << 53)) ? 1.0 / (double)den : 0.0;
+    return (on && (den & 1ull) && den < (1ull << 48)) ? 1.0 / (double)den : 0.0;
 }
 // q <= every prime in use: canonical source words need no reduction (FHE_BFV_BELOW_P=0: reduce anyway)
 static uint32_t bfv32_below_p(uint64_t q, const fhe::Bfv32Args &a, int primes) {
@@ -586,6 +587,8 @@ static int bfv32_tensor(uint64_t q, uint64_t n, uint64_t t, const void *d_ab, vo
     if ((rc = fhe_workspace_get(1, (u64)2 * 4 * batch * 2 * n * 4, st, &wsv)) != FHE_OK) return rc;
     a.src = (const u64 *)d_ab; a.fw = (uint32_t *)wsv; a.rows = 4 * (u64)batch; a.primes = 2; a.word32 = 1;   // q < 2^21
     a.below_p = bfv32_below_p(q, a, 2);
+    // below_p reads the source words as their own residues: the v < q contract, verified on request
+    if (a.below_p && (rc = fhe_check_canonical_words(q, d_ab, 4 * batch * n, st, "fhe_bfv_tensor_dev")) != FHE_OK) return rc;
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.batch = batch; a.out = (u64 *)d_c; a.q = q; a.qmu = ~0ull / q; a.numf = (double)t; a.denf = (double)q;
@@ -626,6 +629,7 @@ static int bfv32_relinearize(uint64_t q, uint64_t n, uint64_t pq, const void *d_
     a.park = (u64 *)((unsigned char *)wsv + x_bytes);
     a.src = (const u64 *)d_c + 2 * (u64)batch * n; a.fw = (uint32_t *)wsv; a.rows = batch; a.primes = 3; a.word32 = 1;
     a.below_p = bfv32_below_p(q, a, 3);
+    if (a.below_p && (rc = fhe_check_canonical_words(q, a.src, batch * n, st, "fhe_bfv_relinearize_dev (c2)")) != FHE_OK) return rc;
     hipError_t e = fhe::launch_bfv32_forward(a, st);
     if (e != hipSuccess) return fhe_hip_fail(e, "bfv32_forward_kernel");
     a.x = (const uint32_t *)wsv; a.key = (const uint32_t *)d_prep;

@@ -105,6 +105,17 @@ int main() {
     CHECK(fhe_shard_range(0, 1, 0, &b, &e) == FHE_OK && b == 0 && e == 0);
     CHECK(fhe_shard_range(10, 0, 0, &b, &e) == FHE_E_INVALID);
     CHECK(fhe_shard_range(10, 2, 2, &b, &e) == FHE_E_INVALID);
+    {   // the gather of shards: argument checks come before any device is needed; without a device it refuses to copy
+        int devs[2] = {0, 0};
+        uint64_t dummy[4] = {0, 0, 0, 0};
+        const void *shards[2] = {dummy, dummy};
+        CHECK(fhe_shard_gather_dev(4, 1, 0, devs, shards, 0, dummy, nullptr) == FHE_E_INVALID);
+        CHECK(fhe_shard_gather_dev(4, 1, 2, nullptr, shards, 0, dummy, nullptr) == FHE_E_NULL);
+        CHECK(fhe_shard_gather_dev(4, 1, 2, devs, nullptr, 0, dummy, nullptr) == FHE_E_NULL);
+        CHECK(fhe_shard_gather_dev(0, 1, 2, devs, shards, 0, nullptr, nullptr) == FHE_OK);          // nothing to move
+        CHECK(fhe_shard_gather_dev(4, 1, 2, devs, shards, 0, nullptr, nullptr) == FHE_E_NULL);
+        if (fhe_ntt_device_count() == 0) CHECK(fhe_shard_gather_dev(4, 1, 2, devs, shards, 0, dummy, nullptr) == FHE_E_NO_DEVICE);
+    }
     CHECK(fhe_shard_range(10, 2, 0, nullptr, &e) == FHE_E_NULL);
     {
         size_t total = ~(size_t)0 / 2, covered = 0;                      // no overflow at the top of size_t

@@ -377,6 +377,15 @@ int fhe_rq_decompose_dev(uint64_t q, uint64_t n, unsigned beta, unsigned l, cons
  * 79 x 7 + 77).  No collective is involved; gathering shards, where a consumer
  * needs them on one device, is the caller's (RCCL all-gather / hipMemcpyPeer). */
 int fhe_shard_range(size_t total, unsigned world, unsigned rank, size_t *begin, size_t *end);
+/* The one gather a block-partitioned batch may need ("only when a downstream op needs the full batch on one rank"), for a
+ * caller WITHOUT torch / RCCL — one host process driving several devices, as a Rust shim behind arith::Rq would: entry r
+ * of d_src_shards points at rank r's rows [begin_r, end_r) of fhe_shard_range(total_rows, world, r) on device
+ * src_devices[r]; they are copied, in rank order, into d_dst (total_rows x row_words 64-bit words on dst_device) with
+ * hipMemcpyPeerAsync (xGMI between devices, a plain copy on the same one) on `hip_stream`, a stream of dst_device.
+ * Ordering against the kernels that produced the shards on OTHER devices' streams is the caller's (events or a
+ * synchronise), as for any cross-device copy.  Empty shards (ranks past the end) may be NULL. */
+int fhe_shard_gather_dev(size_t total_rows, size_t row_words, unsigned world, const int *src_devices,
+                         const void *const *d_src_shards, int dst_device, void *d_dst, void *hip_stream);
 
 /* Library workspaces are kept per (device, stream, calling thread) until fhe_ntt_shutdown(): two host threads that
  * enqueue on one stream never share an intermediate.  A thread that exits leaves its buffers to the next thread that

@@ -165,3 +165,38 @@ def test_short_lived_threads_do_not_accumulate_workspaces(pkg, oracle):
     assert held[0] > 0 and held[-1] == held[0], held
     for dc in outs:
         assert np.array_equal(dc.cpu().numpy().view(np.uint64), want.reshape(-1))
+
+
+@pytest.mark.gpu
+def test_shard_gather_from_the_c_abi(pkg, oracle):
+    """fhe_shard_gather_dev: the optional gather of a block-partitioned batch for a caller without
+    torch / RCCL.  Three 'ranks' (all on device 0 here: a 1-GPU box) each transform their fhe_shard_range block of a
+    ragged batch in their own buffer; the gather puts them, in rank order, where the single-rank transform of the whole
+    batch puts its rows.  An empty shard (more ranks than rows) may be NULL."""
+    import torch
+
+    assert pkg.binding.device_count() >= 1, "no HIP device: -m gpu tests need a real MI355X"
+    B = pkg.binding
+    q, n, total, world = Q61, 4096, 37, 3
+    plan = pkg.Plan(q, n)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.empty(total * n, dtype=torch.int64, device="cuda:0")
+    B.fill_synthetic_dev(q, 0xF4E50777, 0, total * n, x.data_ptr(), st)
+    whole = torch.empty_like(x)
+    plan.forward_dev(x.data_ptr(), whole.data_ptr(), total, st)
+    shards = []
+    for r in range(world):
+        b, e = B.shard_range(total, world, r)
+        out = torch.empty((e - b) * n, dtype=torch.int64, device="cuda:0")
+        plan.forward_dev(x.data_ptr() + b * n * 8, out.data_ptr(), e - b, st)
+        shards.append(out)
+    gathered = torch.zeros_like(x)
+    B.shard_gather_dev(total, n, [0] * world, [s.data_ptr() for s in shards], 0, gathered.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(gathered, whole)
+    # more ranks than rows: the trailing shards are empty and may be NULL
+    tiny = torch.zeros(2 * n, dtype=torch.int64, device="cuda:0")
+    B.shard_gather_dev(2, n, [0] * 4, [whole.data_ptr(), whole.data_ptr() + n * 8, None, None], 0, tiny.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(tiny, whole[: 2 * n])
+    assert np.array_equal(whole[:n].cpu().numpy().view(np.uint64), oracle.ntt(q, n, x[:n].cpu().numpy().view(np.uint64)).reshape(-1))

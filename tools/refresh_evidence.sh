@@ -28,8 +28,9 @@ if [ "$2" = "collect" ]; then
   cp $OUT/isa_counters_a.json profiles/${TAG}_isa_counters_a.json 2>/dev/null || true
   cp $OUT/isa_counters_b.json profiles/${TAG}_isa_counters_b.json 2>/dev/null || true
   # the one-launch transform: one report per variant
-  python3 tools/persist_report.py $OUT ${TAG} || true
-  for f in bench_persist_A bench_persist_B bench_persist_E bench_rank_of_8 bench_mg bench_mg_shoup; do [ -s $OUT/$f.json ] && grep '^{' $OUT/$f.json | tail -1 > profiles/${TAG}_$f.json; done
+  [ -s $OUT/persist_bench.txt ] && { python3 tools/persist_report.py $OUT ${TAG} || true; }
+  for f in bench_persist_A bench_persist_B bench_persist_E bench_rank_of_8 bench_mg bench_mg_shoup bench_self_launch; do [ -s $OUT/$f.json ] && grep '^{' $OUT/$f.json | tail -1 > profiles/${TAG}_$f.json; done
+  [ -s $OUT/single_pass_bound.txt ] && cp $OUT/single_pass_bound.txt profiles/${TAG}_single_pass_bound.txt
   # JSON evidence files hold the JSON line only (RCCL prints banners on stdout)
   for f in profiles/${TAG}_bench_rccl_world1.json profiles/${TAG}_bench_2ranks_one_gpu.json; do [ -s $f ] && { grep '^{' $f | tail -1 > $f.tmp; mv $f.tmp $f; }; done
   sed -i '/amdgpu.ids/d' profiles/${TAG}_*.txt
@@ -120,7 +121,24 @@ python3 tools/pmc_isa.py $OUT/pmc3_a $OUT/config3_counters_a.json > /dev/null 2>
 python3 tools/pmc_isa.py $OUT/pmc3_b $OUT/config3_counters_b.json > /dev/null 2>&1 || true
 cat $OUT/kbench_16.txt $OUT/kbench_12.txt
 
-echo "[8] the one-launch transform (variants A and B): ms per step at three settings each, per-part profile, traffic, counters"; date
+# single-HBM-pass upper bounds on the production butterflies (tools/ubench_fused.hip) and the passes without their butterflies
+[ -x tools/ubench_fused ] && { timeout -k 10 300 ./tools/ubench_fused 8192 > $OUT/single_pass_bound.txt 2>&1 || true; }
+# q = 1 (mod 2^32): the word-Montgomery kernels against the Shoup ones on this box (NOT BASELINE's modulus); one rank of 8
+QMG=2305842979148922881
+timeout -k 10 300 python bench.py --q $QMG --no-cpu-baseline > $OUT/bench_mg.json 2> $OUT/bench_mg.err || true
+FHE_MG=0 timeout -k 10 300 python bench.py --q $QMG --no-cpu-baseline > $OUT/bench_mg_shoup.json 2> $OUT/bench_mg_shoup.err || true
+timeout -k 10 300 python bench.py --global-batch 8192 --steps 40 --no-cpu-baseline > $OUT/bench_rank_of_8.json 2> $OUT/bench_rank_of_8.err || true
+# `python bench.py --gpus 2` WITHOUT a launcher (it starts its own ranks; both share this GPU, gloo rendezvous)
+env -u RANK -u WORLD_SIZE -u LOCAL_RANK timeout -k 10 300 python bench.py --gpus 2 --steps 3 --warmup 1 --share-gpu --backend gloo --global-batch 4096 --no-cpu-baseline --parity-all-ranks > $OUT/bench_self_launch.json 2> $OUT/bench_self_launch.err || tail -5 $OUT/bench_self_launch.err
+if [ "${EVID_PERSIST:-0}" != "1" ]; then
+  for f in bench_rank_of_8 bench_mg bench_mg_shoup bench_self_launch; do python3 -c "
+import json
+o=json.loads([l for l in open('$OUT/$f.json') if l.startswith('{')][-1]); print('$f', round(o['value']), o['unit'], 'n_gpus', o['n_gpus'], 'ms/step', round(o['ms_per_step'],3), 'step_frac', round(o['roofline']['step_frac'],4))" || true; done
+  find $OUT -name "*.db" -delete 2>/dev/null || true
+  date
+  exit 0
+fi
+echo "[8] (EVID_PERSIST=1) the one-launch transform (variants A and B): ms per step at three settings each, per-part profile, traffic, counters"; date
 PERSIST_PROFILE=1 timeout -k 10 900 python tools/persist_bench.py 65536 A:16,1,0 A:64,1,0 A:256,1,0 B:1,1 B:2,1 B:4,1 D:1,1 D:2,1 E:2,1 E:3,1 E:4,1 E:6,1 > $OUT/persist_bench.txt 2>&1 || tail -5 $OUT/persist_bench.txt
 grep -E "^time|parity:" $OUT/persist_bench.txt || true
 for cfg in two-pass A:64,1,0 B:2,1 D:1,1 E:4,1; do

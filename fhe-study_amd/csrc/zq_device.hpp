@@ -181,16 +181,28 @@ constexpr int kPmRed = 17;    // pm_reduce(x) < q + q/16
 constexpr int kPmOne = 16;    // canonical
 constexpr int kPmCap = 128;   // 8q <= 2^64: every value stays below
 
-// x -> (x mod 2^k) + (x >> k) delta  =  x (mod q),  < 2^k + 2^(64-k) delta.  Plain C on purpose (the compiler emits
-// v_lshrrev / v_and / v_mad_u64_u32, often with a v_mov_b32 that builds the masked value in a fresh pair).  Round 5 tried
-// the three-instruction in-place form — shift, `x & mask` on x's own pair, `v_mad_u64_u32 %0, vcc, k, delta, %0` tied
-// ("+v") to it: -1.5 % vector instructions, but in rq_mul_mid_kernel (two operands live, 109 registers) hipcc 7.2 then
-// handed stage 3 of a round a stale register pair for v[0] (words 0..31 of every 256-block wrong; bisected to this
-// statement with tools/dbg_r5.py, gpurun_out/r5b) — not kept.
+// x -> (x mod 2^k) + (x >> k) delta  =  x (mod q),  < 2^k + 2^(64-k) delta.  Plain C, the SHIFT WRITTEN FIRST (round 5):
+// the compiler then masks the high word of x's own register pair and accumulates into it — v_lshrrev / v_and /
+// v_mad_u64_u32, three instructions.  With the mask written first (rounds 3-4) it built the masked value in a fresh pair:
+// a v_mov_b32 per reduction, 48 per thread of the contiguous pass, 231 of the fused product's 4900 instructions at N = 4096.
+// An inline-asm form of the same three instructions (`v_mad_u64_u32 %0, vcc, k, delta, %0` tied with "+v" to the masked
+// pair) was tried first and is NOT used: in rq_mul_mid_kernel (two operands live, 109 registers) hipcc 7.2 then handed
+// stage 3 of a round a stale register pair for v[0] — words 0..31 of every 256-block wrong, bisected to that statement
+// (gpurun_out/r5b).  This form leaves register allocation to the compiler and passes the whole GPU suite (259 tests:
+// every kernel that reduces, 2^4 <= n <= 2^20, gpurun_out/r5j); FHE_PM_REDUCE_SHIFT_FIRST=0 restores the old order.
+#ifndef FHE_PM_REDUCE_SHIFT_FIRST
+#define FHE_PM_REDUCE_SHIFT_FIRST 1
+#endif
 __device__ __forceinline__ u64 pm_reduce(u64 x, const Mod &m) {
+#if FHE_PM_REDUCE_SHIFT_FIRST
+    const u32 k = (u32)(x >> 32) >> m.pm_rsh;
+    const u64 lo = x & (((u64)m.pm_rmask << 32) | 0xffffffffull);
+    return (u64)k * (u64)m.pm_delta + lo;
+#else
     const u32 x1 = (u32)(x >> 32);
     const u64 lo = ((u64)(x1 & m.pm_rmask) << 32) | (u32)x;
     return (u64)(x1 >> m.pm_rsh) * (u64)m.pm_delta + lo;
+#endif
 }
 // any value below 2^64 -> canonical
 __device__ __forceinline__ u64 pm_canon(u64 x, const Mod &m) { return csub_neg(pm_reduce(x, m), m.nq); }

@@ -593,7 +593,21 @@ extern "C" int fhe_ntt_set_persist_grid(int workgroups) {
     g_persist_grid = workgroups > 0 ? workgroups : 0;
     return FHE_OK;
 }
-static int persist_host_err(uint32_t **dptr) {
+// Everything forward_persist needs from the process-wide settings, taken in ONE critical section (the grid
+// override, the profile buffer and the error word were read outside g_cfg_lock): the pinned error word (allocated on first
+// use, released in fhe_ntt_shutdown), whether an earlier launch left it set, the workgroup count for this (device,
+// variant) — an occupancy query, cached per DEVICE — or its override, and the profile buffer.
+struct PersistSnap {
+    uint32_t *d_err = nullptr;
+    uint32_t pending = 0;
+    unsigned grid = 0;
+    void *prof = nullptr;
+};
+static std::map<std::pair<int, int>, unsigned> g_persist_grids;      // (device, variant) -> workgroups the chip holds
+static int persist_snapshot(const fhe::PersistTune &tune, PersistSnap *s) {
+    int dev = 0;
+    int rc = fhe_current_device(&dev);
+    if (rc != FHE_OK) return rc;
     std::lock_guard<std::mutex> lk(g_cfg_lock);
     if (!g_persist_host_err) {
         void *h = nullptr;
@@ -603,8 +617,28 @@ static int persist_host_err(uint32_t **dptr) {
     }
     void *d = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d, g_persist_host_err, 0));
-    *dptr = (uint32_t *)d;
+    s->d_err = (uint32_t *)d;
+    s->pending = *(volatile uint32_t *)g_persist_host_err;
+    if (g_persist_grid < 0) { const char *e = getenv("FHE_NTT_PERSIST_GRID"); g_persist_grid = e ? atoi(e) : 0; }
+    if (g_persist_grid > 0) {
+        s->grid = (unsigned)g_persist_grid;      // tests: fewer workgroups than the chip holds
+    } else {
+        unsigned &grid = g_persist_grids[{dev, tune.teams ? ((tune.deep || tune.flow) ? 2 : 1) : 0}];
+        if (!grid) {
+            unsigned g = 0;
+            HIP_TRY(fhe::persist_grid(tune, &g));
+            grid = g;
+        }
+        s->grid = grid;
+    }
+    s->prof = g_persist_prof;
     return FHE_OK;
+}
+static void persist_free_all() {
+    std::lock_guard<std::mutex> lk(g_cfg_lock);
+    if (g_persist_host_err) (void)hipHostFree(g_persist_host_err);
+    g_persist_host_err = nullptr;
+    g_persist_grids.clear();
 }
 // FHE_OK, or FHE_E_HIP when a persistent launch that has FINISHED gave up a bounded wait (its outputs are then not valid);
 // reading clears the word.  Call after synchronising the stream.
@@ -640,31 +674,18 @@ static int persist_tables(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, c
 }
 static int forward_persist(const fhe_ntt_plan *plan, const fhe::DevicePlan &dp, const fhe::PersistTune &tune, const void *d_in,
                            void *d_out, size_t batch, hipStream_t st) {
-    if (g_persist_host_err && *(volatile uint32_t *)g_persist_host_err)
-        return fail(FHE_E_HIP, "an earlier persistent transform failed (fhe_ntt_persist_status())");
+    PersistSnap cfg;
+    int rc = persist_snapshot(tune, &cfg);
+    if (rc != FHE_OK) return rc;
+    if (cfg.pending) return fail(FHE_E_HIP, "an earlier persistent transform failed (fhe_ntt_persist_status())");
     const fhe::Tw *twc = nullptr;
     const u64 *twc8 = nullptr;
-    int rc = persist_tables(plan, dp, &twc, &twc8, st);
-    if (rc != FHE_OK) return rc;
-    uint32_t *herr = nullptr;
-    if ((rc = persist_host_err(&herr)) != FHE_OK) return rc;
-    static unsigned grids[3] = {0, 0, 0};
-    unsigned &grid = grids[tune.teams ? ((tune.deep || tune.flow) ? 2 : 1) : 0];
-    if (!grid) {
-        unsigned g = 0;
-        HIP_TRY(fhe::persist_grid(tune, &g));
-        grid = g;
-    }
-    {   // FHE_NTT_PERSIST_GRID / fhe_ntt_set_persist_grid: another number of workgroups (tests: fewer than the chip holds)
-        std::lock_guard<std::mutex> lk(g_cfg_lock);
-        if (g_persist_grid < 0) { const char *e = getenv("FHE_NTT_PERSIST_GRID"); g_persist_grid = e ? atoi(e) : 0; }
-    }
-    const unsigned use_grid = g_persist_grid > 0 ? (unsigned)g_persist_grid : grid;
-    const size_t cb = (fhe::persist_ctl_bytes(tune, batch, use_grid) + 255) & ~(size_t)255, rb = fhe::persist_ring_bytes(tune, use_grid);
+    if ((rc = persist_tables(plan, dp, &twc, &twc8, st)) != FHE_OK) return rc;
+    const size_t cb = (fhe::persist_ctl_bytes(tune, batch, cfg.grid) + 255) & ~(size_t)255, rb = fhe::persist_ring_bytes(tune, cfg.grid);
     void *w = nullptr;
     if ((rc = fhe_workspace_get(4, cb + rb, st, &w)) != FHE_OK) return rc;
     hipError_t e = fhe::launch_ntt_forward_persist(dp, twc, twc8, (const u64 *)d_in, (u64 *)d_out, batch, tune, (uint32_t *)w,
-                                                   rb ? (u64 *)((char *)w + cb) : nullptr, herr, (u64 *)g_persist_prof, use_grid, st);
+                                                   rb ? (u64 *)((char *)w + cb) : nullptr, cfg.d_err, (u64 *)cfg.prof, cfg.grid, st);
     if (e != hipSuccess) return hip_fail(e, "launch_ntt_forward_persist");
     return FHE_OK;
 }
@@ -1356,6 +1377,7 @@ extern "C" int fhe_ntt_shutdown(void) {
     }
     fhe_workspace_free_all();
     fhe_ext32_free_all();
+    persist_free_all();
     std::lock_guard<std::mutex> lk(g_plans_lock);
     for (auto &kv : g_plans) {
         fhe_ntt_plan *p = kv.second.get();

@@ -30,7 +30,7 @@ if [ "$2" = "collect" ]; then
   # the one-launch transform: one report per variant
   [ -s $OUT/persist_bench.txt ] && { python3 tools/persist_report.py $OUT ${TAG} || true; }
   for f in bench_persist_A bench_persist_B bench_persist_E bench_rank_of_8 bench_mg bench_mg_shoup bench_self_launch; do [ -s $OUT/$f.json ] && grep '^{' $OUT/$f.json | tail -1 > profiles/${TAG}_$f.json; done
-  [ -s $OUT/single_pass_bound.txt ] && cp $OUT/single_pass_bound.txt profiles/${TAG}_single_pass_bound.txt
+  [ -s $OUT/single_pass_bound.txt ] && { cat tools/single_pass_bound_reading.txt $OUT/single_pass_bound.txt > profiles/${TAG}_single_pass_bound.txt; }
   # JSON evidence files hold the JSON line only (RCCL prints banners on stdout)
   for f in profiles/${TAG}_bench_rccl_world1.json profiles/${TAG}_bench_2ranks_one_gpu.json; do [ -s $f ] && { grep '^{' $f | tail -1 > $f.tmp; mv $f.tmp $f; }; done
   sed -i '/amdgpu.ids/d' profiles/${TAG}_*.txt

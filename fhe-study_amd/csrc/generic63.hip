@@ -1,21 +1,20 @@
 // generic63.hip — NTT::ntt / intt / pointwise product for moduli 2^62 <= q < 2^63 (arith/src/ntt.rs:44-110,
-// ring_nq.rs:601-604).  The reference's Zq works for every q below 2^63 (its `self.v + rhs.v`, zq.rs:225, is the
-// limit); the lazy butterflies of ntt_kernels.hip need 4q < 2^64.  This range therefore runs STRICT butterflies —
-// every value canonical between stages, three conditional subtractions per butterfly — in plain kernels: up to four
-// stages per launch on 2^R coefficients per thread, in place in global memory, ceil(log2 n / 4) launches per transform
-// (two for n = 2^8, four for n = 2^16).  Correctness cover for a range no benchmark configuration uses, not a fast
-// path: 0.86 M NTT/s at n = 2^16, a third of the two-pass kernels' rate; 17 M at n = 2^12.
+// ring_nq.rs:601-604) in PLAIN kernels.  The reference's Zq works for every q below 2^63 (its `self.v + rhs.v`, zq.rs:225,
+// is the limit); the lazy butterflies of ntt_kernels.hip need 4q < 2^64, so this range runs STRICT butterflies — every
+// value canonical between stages, three conditional subtractions per butterfly (zq_device.hpp: ct_bfly63 / gs_bfly63).
+// Since round 5 the transforms and products of this range at n >= 16 run in the two-pass / fused kernels of
+// ntt_kernels.hip with those butterflies (AR = 3).  What stays here: the pointwise product, n < 16, and — under
+// FHE_G63_PLAIN=1 — the whole range as it ran until round 5: up to four stages per launch on 2^R coefficients per thread, in
+// place in global memory, ceil(log2 n / 4) launches per transform (0.86 M NTT/s at n = 2^16).  The two forms are compared
+// word for word by tests/test_round5.py::test_strict_moduli_two_builds_of_the_same_words.
 #include "ntt_kernels.hpp"
 
 namespace fhe {
 
 namespace {
 
-// x + y mod q and x - y mod q for canonical operands, q < 2^63 (x + y < 2^64)
-__device__ __forceinline__ u64 add63(u64 x, u64 y, const Mod &m) { return canon2(x + y, m); }
-__device__ __forceinline__ u64 sub63(u64 x, u64 y, const Mod &m) { return canon2(x + (m.q - y), m); }   // (0, 2q) -> [0, q)
-// y * w mod q, canonical: the Shoup product is exact in [0, 2q) for ANY 64-bit y, and 2q < 2^64
-__device__ __forceinline__ u64 mul63(u64 y, const Tw &w, const Mod &m) { return canon2(mul_shoup_lazy(y, w.w, w.wp, m), m); }
+// add63 / sub63 / mul63: zq_device.hpp (strict arithmetic, every value canonical)
+__device__ __forceinline__ u64 mul63(u64 y, const Tw &w, const Mod &m) { return mul63(y, w.w, w.wp, m); }
 
 // Stages s0 .. s0+R-1 of the forward transform (ntt.rs:49-70: m = 2^s, t = n / 2m, S = roots[m + i]) on the 2^R
 // coefficients j = hi * (tl << R) + k * tl + lo, k = 0 .. 2^R - 1, tl = n >> (s0 + R): stage s0 + i pairs the k that

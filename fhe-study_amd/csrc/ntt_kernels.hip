@@ -49,8 +49,8 @@ namespace fhe {
 // Montgomery, `a.tw` = {w 2^32, w 2^64 mod q}; forward and inverse transforms and both Rq products; SRC_PLAIN only).
 template <int LP, bool FINAL, int AR, int SRC = SRC_PLAIN>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassArgs a) {
-    constexpr bool WIDE = AR == 1;
-    static_assert((AR != 2 && AR != 4) || SRC == SRC_PLAIN, "transforming loads run on the Shoup tables");
+    constexpr int WIDE = AR == 1 ? 1 : AR == 3 ? kStrict : 0;
+    static_assert((AR != 2 && AR != 3 && AR != 4) || SRC == SRC_PLAIN, "transforming loads run on the Shoup tables, below 2^62");
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
     constexpr int ALAST = C::a_of(C::NR - 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const u64 x = !FINAL ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon8(v[k], m) : canon4(v[k], m);   // FINAL: < 4q in both Shoup modes, < 7q from the Montgomery rounds
+        const u64 x = !FINAL || AR == 3 ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon8(v[k], m) : canon4(v[k], m);   // FINAL: < 4q in both Shoup modes, < 7q from the Montgomery rounds; AR = 3: canonical throughout
         lds[pad16(w * C::M + field_of<ALAST>(tf, k))] = x;
     }
     __syncthreads();
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_fwd_contig_kernel(PassA
 // (the `evals` of the result, ring_nq.rs:606) is also written there.
 template <int LP, bool FINAL, bool MUL_IN, int AR>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassArgs a) {
-    constexpr bool WIDE = AR == 1;
+    constexpr int WIDE = AR == 1 ? 1 : AR == 3 ? kStrict : 0;
     static_assert(!(AR == 4 && MUL_IN), "a variable x variable product has no Montgomery table: the fused product runs on the Shoup tables");
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -236,6 +236,9 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
                     p.x = mul_var_pm(v[2 * j], y.x, a.mod);
                     p.y = mul_var_pm(v[2 * j + 1], y.y, a.mod);
                     if (a.out2) { p.x = pm_canon(p.x, a.mod); p.y = pm_canon(p.y, a.mod); }
+                } else if constexpr (AR == 3) {
+                    p.x = mul_mod_var63(v[2 * j], y.x, a.mod);
+                    p.y = mul_mod_var63(v[2 * j + 1], y.y, a.mod);
                 } else {
                     p.x = mul_mod_var(v[2 * j], y.x, a.mod);
                     p.y = mul_mod_var(v[2 * j + 1], y.y, a.mod);
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
     if (active) {
         if constexpr (FINAL) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m);   // AR == 4: products, below 3q
+            for (int k = 0; k < 16; k++) v[k] = AR == 3 ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m);   // AR == 4: products, below 3q
         }
         st16<false>(pout, C::A0, off + tf * 8u, v);   // field_of<A0>(tf, k) = (k << A0) + tf
     }
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void ntt_inv_contig_kernel(PassA
 // register window (field bits [0,4)) the inverse rounds start from, so nothing is rearranged
 // between the transforms.  Operands flagged as evals skip their forward transform.
 // ---------------------------------------------------------------------------
-template <int LP, bool WIDE, bool TILE_FRESH>
+template <int LP, int WIDE, bool TILE_FRESH>
 __device__ __forceinline__ void fwd_rounds_single(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 w,
                                                   u32 tf, const Mod &m) {
     using C = ContigCfg<LP>;
@@ -291,10 +294,10 @@ __device__ __forceinline__ void fwd_rounds_single(u64 (&v)[16], u64 *lds, const 
         round_fwd<4, WIDE, B3, C::NR == 4>(v, TW(C::in_lds(3)), (1u << LS) + (tf >> A), m);
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = canon4(v[k], m);   // the last stage left x', y' < 4q
+    for (int k = 0; k < 16; k++) v[k] = WIDE == kStrict ? v[k] : canon4(v[k], m);   // the last stage left x', y' < 4q (strict: canonical already)
 }
 
-template <int LP, bool WIDE>
+template <int LP, int WIDE>
 __device__ __forceinline__ void inv_rounds_single(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 w,
                                                   u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
     using C = ContigCfg<LP>;
@@ -321,7 +324,7 @@ __device__ __forceinline__ void inv_rounds_single(u64 (&v)[16], u64 *lds, const 
 
 template <int LP, int AR>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArgs a) {
-    constexpr bool WIDE = AR == 1;
+    constexpr int WIDE = AR == 1 ? 1 : AR == 3 ? kStrict : 0;
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -389,6 +392,9 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
 #pragma unroll
             for (int k = 0; k < 16; k++) va[k] = canon4(va[k], m);
         }
+    } else if constexpr (AR == 3) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = mul_mod_var63(va[k], vb[k], m);
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
     if (active) {
         u64 *__restrict__ pout = a.out + ubase;
 #pragma unroll
-        for (int k = 0; k < 16; k++) va[k] = AR == 2 ? pm_canon(va[k], m) : AR == 4 ? canon4(va[k], m) : canon2(va[k], m);
+        for (int k = 0; k < 16; k++) va[k] = AR == 3 ? va[k] : AR == 2 ? pm_canon(va[k], m) : AR == 4 ? canon4(va[k], m) : canon2(va[k], m);
         st16<false>(pout, C::A0, off + tf * 8u, va);
     }
 }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_fused_kernel(PassArg
 // ---------------------------------------------------------------------------
 template <int LP, int AR>
 __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs a) {
-    constexpr bool WIDE = AR == 1;
+    constexpr int WIDE = AR == 1 ? 1 : AR == 3 ? kStrict : 0;
     using C = ContigCfg<LP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
             else fwd_rounds_contig<LP, WIDE, true, kPassBound, decltype(fresh)::value>(v, lds, ltw_f, a.tw, s0, blk, w, tf, m);
             if (keep) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon8(v[k], m) : canon4(v[k], m);
+                for (int k = 0; k < 16; k++) v[k] = AR == 3 ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon8(v[k], m) : canon4(v[k], m);
             }
         }
     };
@@ -504,6 +510,9 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
 #pragma unroll
             for (int k = 0; k < 16; k++) va[k] = canon4(va[k], m);
         }
+    } else if constexpr (AR == 3) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) va[k] = mul_mod_var63(va[k], vb[k], m);
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) va[k] = mul_mod_var(va[k], vb[k], m);
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(ContigCfg<LP>::TH) void rq_mul_mid_kernel(PassArgs 
 // (see SRC_REDUCE above).
 template <int LA, int CW, int AR, bool RSRC = false>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kernel(PassArgs a) {
-    constexpr bool WIDE = AR == 1;
+    constexpr int WIDE = AR == 1 ? 1 : AR == 3 ? kStrict : 0;
     static_assert(AR != 2 || !RSRC, "reducing loads run on the Shoup tables");
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -583,7 +592,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_fwd_strided_kern
 
 template <int LA, int CW, int AR>
 __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kernel(PassArgs a) {
-    constexpr bool WIDE = AR == 1;
+    constexpr int WIDE = AR == 1 ? 1 : AR == 3 ? kStrict : 0;
     using C = StridedCfg<LA, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *lds = reinterpret_cast<u64 *>(smem_raw);
@@ -621,7 +630,7 @@ __global__ __launch_bounds__((StridedCfg<LA, CW>::TH)) void ntt_inv_strided_kern
     if constexpr (AR == 2 || AR == 4) round_inv_pm<C::R0, true, ar_inv_bound(AR), true, AR>(v, a.tw, 1u, m, a.ninv, a.s_ninv);   // uniform: scalar loads
     else round_inv_sel<C::R0, true, WIDE, 4>(v, tw, 1u, m, a.ninv, a.s_ninv);
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m);
+    for (int k = 0; k < 16; k++) v[k] = AR == 3 ? v[k] : AR == 2 ? pm_canon(v[k], m) : AR == 4 ? canon4(v[k], m) : canon2(v[k], m);
     st16<true>(pout, C::A0 + lb, ((field_of<C::A0>(tf, 0) << lb) + c) * 8u, v);
 }
 
@@ -772,6 +781,7 @@ static hipError_t fwd_contig_dispatch(int lp, bool final, int ar, const PassArgs
 #define X(LP_)                                                                                   \
     case LP_:                                                                                    \
         if (ar == 4) return final ? launch_fwd_contig<LP_, true, 4>(a, st) : launch_fwd_contig<LP_, false, 4>(a, st); \
+        if (ar == 3) return final ? launch_fwd_contig<LP_, true, 3>(a, st) : launch_fwd_contig<LP_, false, 3>(a, st); \
         if (ar == 2) return final ? launch_fwd_contig<LP_, true, 2>(a, st) : launch_fwd_contig<LP_, false, 2>(a, st); \
         if (ar == 1) return final ? launch_fwd_contig<LP_, true, 1>(a, st) : launch_fwd_contig<LP_, false, 1>(a, st); \
         return final ? launch_fwd_contig<LP_, true, 0>(a, st) : launch_fwd_contig<LP_, false, 0>(a, st);
@@ -807,7 +817,8 @@ static hipError_t inv_contig_dispatch_mg(int lp, bool final, const PassArgs &a, 
 }
 static hipError_t inv_contig_dispatch(int ar, int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st) {
     if (ar == kArMontgomery) return mul_in ? hipErrorInvalidValue : inv_contig_dispatch_mg(lp, final, a, st);
-    return ar == 2 ? inv_contig_dispatch_ar<2>(lp, final, mul_in, a, st)
+    return ar == 3 ? inv_contig_dispatch_ar<3>(lp, final, mul_in, a, st)
+         : ar == 2 ? inv_contig_dispatch_ar<2>(lp, final, mul_in, a, st)
          : ar == 1 ? inv_contig_dispatch_ar<1>(lp, final, mul_in, a, st)
                    : inv_contig_dispatch_ar<0>(lp, final, mul_in, a, st);
 }
@@ -824,13 +835,20 @@ static hipError_t strided_dispatch_ar(int la, const PassArgs &a, hipStream_t st,
 template <bool INV>
 static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
     if (ar == kArMontgomery) return strided_dispatch_ar<INV, 4>(la, a, st, operands);
-    return ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands)
+    return ar == 3 ? strided_dispatch_ar<INV, 3>(la, a, st, operands)
+         : ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands)
          : ar == 1 ? strided_dispatch_ar<INV, 1>(la, a, st, operands)
                    : strided_dispatch_ar<INV, 0>(la, a, st, operands);
 }
 // the tables and n^-1 constants a pass runs on: {w, w 2^32 mod q} for pseudo-Mersenne plans, {w, floor(w 2^64 / q)} otherwise
 static inline bool plan_runs_montgomery(const DevicePlan &p) {
     return p.log_n >= 4 && p.tw_fwd_mg != nullptr && p.tw_inv_mg != nullptr && p.arith == kArWide61;
+}
+// FHE_G63_PLAIN=1: 2^62 <= q < 2^63 on the plain strict kernels of generic63.hip at every size (what shipped until round 5:
+// ceil(log2 n / 4) launches); default: the two-pass / fused kernels above with AR = 3
+static bool g63_plain() {
+    static const bool v = [] { const char *e = getenv("FHE_G63_PLAIN"); return e && e[0] == '1'; }();
+    return v;
 }
 static inline void set_tables(PassArgs &a, const DevicePlan &p, bool inverse) {
     const bool pm = p.arith == kArPMersenne;
@@ -844,7 +862,7 @@ static inline void set_tables(PassArgs &a, const DevicePlan &p, bool inverse) {
 
 hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch,
                               u64 batch_tile, hipStream_t st) {
-    if (p.arith == kArStrict63) return launch_g63_forward(p, in, out, batch, st);   // 2^62 <= q < 2^63: generic63.hip
+    if (p.arith == kArStrict63 && (p.log_n < 4 || g63_plain())) return launch_g63_forward(p, in, out, batch, st);   // 2^62 <= q < 2^63 at n < 16 (or FHE_G63_PLAIN=1): generic63.hip
     PassArgs a{};
     const int L = p.log_n;
     // n < 16: one thread per polynomial on the Shoup tables
@@ -897,7 +915,7 @@ static hipError_t launch_rq_mul_fused_lp(const PassArgs &a, hipStream_t st) {
 hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_evals, const u64 *b_, bool b_is_evals,
                                u64 *c, u64 *c_evals, u64 *a_evals, u64 *b_evals, u64 batch, hipStream_t st) {
     const int L = p.log_n;
-    if (L < 4 || L > kMaxSinglePassLog || p.arith == kArStrict63) return hipErrorNotSupported;
+    if (L < 4 || L > kMaxSinglePassLog || (p.arith == kArStrict63 && g63_plain())) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     PassArgs a{};
     set_tables(a, p, false);
@@ -908,7 +926,7 @@ hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_eva
     a.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
     a.batch = batch;
     switch (L) {
-#define X(LP_) case LP_: return mg ? launch_rq_mul_fused_lp<LP_, 4>(a, st) : p.arith == 2 ? launch_rq_mul_fused_lp<LP_, 2>(a, st) : p.arith == 1 ? launch_rq_mul_fused_lp<LP_, 1>(a, st) : launch_rq_mul_fused_lp<LP_, 0>(a, st);
+#define X(LP_) case LP_: return mg ? launch_rq_mul_fused_lp<LP_, 4>(a, st) : p.arith == 3 ? launch_rq_mul_fused_lp<LP_, 3>(a, st) : p.arith == 2 ? launch_rq_mul_fused_lp<LP_, 2>(a, st) : p.arith == 1 ? launch_rq_mul_fused_lp<LP_, 1>(a, st) : launch_rq_mul_fused_lp<LP_, 0>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
@@ -936,7 +954,7 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
                                   u64 *c, u64 *c_evals, u64 *wa, bool keep_a_evals, u64 *wb, bool keep_b_evals,
                                   u64 batch, u64 batch_tile, hipStream_t st) {
     const int L = p.log_n;
-    if (L <= kMaxSinglePassLog || L > kMaxLog || p.arith == kArStrict63) return hipErrorNotSupported;
+    if (L <= kMaxSinglePassLog || L > kMaxLog || (p.arith == kArStrict63 && g63_plain())) return hipErrorNotSupported;
     if (batch == 0) return hipSuccess;
     const int LB = contig_bits(L), LA = L - LB;
     const u64 n = 1ull << L;
@@ -972,7 +990,7 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
         m.out4 = (keep_b_evals && !b_is_evals) ? wb + o : nullptr;
         m.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
         switch (LB) {
-#define X(LP_) case LP_: e = ar == 4 ? launch_rq_mul_mid_lp<LP_, 4>(m, st) : ar == 2 ? launch_rq_mul_mid_lp<LP_, 2>(m, st) : ar == 1 ? launch_rq_mul_mid_lp<LP_, 1>(m, st) : launch_rq_mul_mid_lp<LP_, 0>(m, st); break;
+#define X(LP_) case LP_: e = ar == 4 ? launch_rq_mul_mid_lp<LP_, 4>(m, st) : ar == 3 ? launch_rq_mul_mid_lp<LP_, 3>(m, st) : ar == 2 ? launch_rq_mul_mid_lp<LP_, 2>(m, st) : ar == 1 ? launch_rq_mul_mid_lp<LP_, 1>(m, st) : launch_rq_mul_mid_lp<LP_, 0>(m, st); break;
             X(8) X(9) X(10) X(11) X(12)
 #undef X
             default: return hipErrorInvalidValue;
@@ -1066,7 +1084,7 @@ hipError_t launch_ntt_forward_reduce(const DevicePlan &p, const u64 *in, u64 *ou
 // evals_out when that is non-null).
 hipError_t launch_ntt_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out,
                               u64 *out, u64 batch, u64 batch_tile, hipStream_t st) {
-    if (p.arith == kArStrict63) return launch_g63_inverse(p, in, in2, evals_out, out, batch, st);
+    if (p.arith == kArStrict63 && (p.log_n < 4 || g63_plain())) return launch_g63_inverse(p, in, in2, evals_out, out, batch, st);
     PassArgs a{};
     const int L = p.log_n;
     // q = 1 (mod 2^32): a plain inverse transform (no product in its load) runs on the word-Montgomery table (AR = 4)

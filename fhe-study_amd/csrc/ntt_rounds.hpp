@@ -26,6 +26,9 @@ namespace fhe {
 //   END6: the round's last stage also corrects when its inputs exceed 4q, so the round (the last
 //   of a strided pass) ends below 6q whatever its length — the bound the next pass starts from.
 //   otherwise (q < 2^62): Harvey's [0,4q) with a 2q correction in every butterfly.
+//   WIDE == kStrict (2^62 <= q < 2^63, AR = 3): no lazy range at all — ct_bfly63 / gs_bfly63 take canonical values to
+//   canonical values (zq_device.hpp); the bound parameters are carried along and ignored.
+constexpr int kStrict = 3;
 constexpr int fwd_stage_needs_csub(int bound_in) { return bound_in > 6; }
 constexpr int fwd_bound_out(int R, int bin) {
     int b = bin;
@@ -35,7 +38,7 @@ constexpr int fwd_bound_out(int R, int bin) {
 constexpr int kPassBound = 6;   // bound (in q) of what a forward strided pass hands to the contiguous pass
 // I0: the round's first I0 stages have been done by other means (the table look-ups of round0_bits):
 // run stages I0 .. R-1, BIN being the bound of what enters stage I0.
-template <int R, bool WIDE, int BIN = 6, bool TIGHT_LAST = false, bool END6 = false, int I0 = 0>
+template <int R, int WIDE, int BIN = 6, bool TIGHT_LAST = false, bool END6 = false, int I0 = 0>
 __device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0,
                                           const Mod &m) {
     static_assert(BIN >= 1 && BIN <= 8, "input bound out of range");
@@ -55,7 +58,8 @@ __device__ __forceinline__ void round_fwd(u64 (&v)[16], const Tw *__restrict__ t
 #pragma unroll
             for (int l = 0; l < span; l++) {
                 const int k = g * 2 * span + l;
-                if (!WIDE) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
+                if (WIDE == kStrict) ct_bfly63(v[k], v[k + span], t.w, t.wp, m);
+                else if (!WIDE) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
                 else if (tight && bin_i > 4) ct_bfly<6>(v[k], v[k + span], t.w, t.wp, m);
                 else if (tight && bin_i > 2) ct_bfly<2>(v[k], v[k + span], t.w, t.wp, m);
                 else if (tight) ct_bfly<kNone>(v[k], v[k + span], t.w, t.wp, m);
@@ -183,11 +187,38 @@ __device__ __forceinline__ void round_inv_w(u64 (&v)[16], const Tw *__restrict__
         if (S.fin[k]) v[k] = csub_neg(v[k], m.neg4q);
 }
 
+// the inverse round on canonical values (WIDE == kStrict); FOLD as in round_inv
+template <int R, bool FOLD>
+__device__ __forceinline__ void round_inv63(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m, const Tw ninv,
+                                            const Tw s_ninv) {
+#pragma unroll
+    for (int i = R - 1; i >= 0; i--) {
+        const int span = 8 >> i;
+#pragma unroll
+        for (int g = 0; g < (1 << i); g++) {
+            Tw t{};
+            if (!(FOLD && i == 0)) t = tw[(T0 << i) + g];
+#pragma unroll
+            for (int l = 0; l < span; l++) {
+                const int k = g * 2 * span + l;
+                if (FOLD && i == 0) {   // the sum and the difference go straight into the scaling products: any 64-bit multiplicand
+                    const u64 s = v[k] + v[k + span], d = v[k] + (m.q - v[k + span]);
+                    v[k] = mul63(s, ninv.w, ninv.wp, m);
+                    v[k + span] = mul63(d, s_ninv.w, s_ninv.wp, m);
+                } else {
+                    gs_bfly63(v[k], v[k + span], t.w, t.wp, m);
+                }
+            }
+        }
+    }
+}
+
 // WIDE: the bound-tracking rounds above (values below 4q between rounds); otherwise [0,2q) throughout
-template <int R, bool FOLD, bool WIDE, int BIN>
+template <int R, bool FOLD, int WIDE, int BIN>
 __device__ __forceinline__ void round_inv_sel(u64 (&v)[16], const Tw *__restrict__ tw, u32 T0, const Mod &m,
                                               const Tw ninv, const Tw s_ninv) {
-    if constexpr (WIDE) round_inv_w<R, FOLD, BIN, 4>(v, tw, T0, m, ninv, s_ninv);
+    if constexpr (WIDE == kStrict) round_inv63<R, FOLD>(v, tw, T0, m, ninv, s_ninv);
+    else if constexpr (WIDE == 1) round_inv_w<R, FOLD, BIN, 4>(v, tw, T0, m, ninv, s_ninv);
     else round_inv<R, FOLD>(v, tw, T0, m, ninv, s_ninv);
 }
 
@@ -339,7 +370,7 @@ __device__ __forceinline__ void round_inv_pm(u64 (&v)[16], const Tw *__restrict_
 // All entries canonical, so the stages that follow start from bound 1.
 constexpr int kDigitLutWords = 136;
 
-template <int R0, bool WIDE, bool TIGHT>
+template <int R0, int WIDE, bool TIGHT>
 __device__ __forceinline__ void round0_bits(u64 (&v)[16], const u64 *lut, const Tw *__restrict__ gtw, const Mod &m) {
     if constexpr (R0 == 1) {
 #pragma unroll
@@ -567,7 +598,7 @@ __device__ __forceinline__ void exchange_contig(u64 (&v)[16], u64 *lds, u32 w, u
 // leaves x', y' < 4q.  FRESH: nobody has read the LDS tile since the last barrier.
 // BITS: the inputs are 0/1 and the pass is the whole transform (s0 = blk = 0): round 0 by table
 // look-up (round0_bits; `lut` = the plan's digit tables in LDS, already published).
-template <int LP, bool WIDE, bool TIGHT, int BIN, bool FRESH, bool BITS = false>
+template <int LP, int WIDE, bool TIGHT, int BIN, bool FRESH, bool BITS = false>
 __device__ __forceinline__ void fwd_rounds_contig(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
                                                   u32 w, u32 tf, const Mod &m, const u64 *lut = nullptr) {
     using C = ContigCfg<LP>;
@@ -605,7 +636,7 @@ __device__ __forceinline__ void fwd_rounds_contig(u64 (&v)[16], u64 *lds, const 
 // round that runs starts from bound 2, later ones from the normalised 4) up to window [LP-4, LP).
 // FOLD: the pass holds the transform's last GS stage (s0 = 0) with the n^-1 scaling folded in.
 // FRESH as above (an exchange precedes every round but the first).
-template <int LP, bool WIDE, bool FOLD, bool FRESH>
+template <int LP, int WIDE, bool FOLD, bool FRESH>
 __device__ __forceinline__ void inv_rounds_contig(u64 (&v)[16], u64 *lds, const Tw *ltw, const Tw *gtw, u32 s0, u32 blk,
                                                   u32 w, u32 tf, const Mod &m, const Tw ninv, const Tw s_ninv) {
     using C = ContigCfg<LP>;

@@ -497,6 +497,27 @@ __device__ __forceinline__ u64 reduce128_63(u64 hi, u64 lo, const Mod &m) {
 }
 __device__ __forceinline__ u64 mul_mod_var63(u64 a, u64 b, const Mod &m) { return reduce128_63(__umul64hi(a, b), a * b, m); }
 
+// ---- strict arithmetic for 2^62 <= q < 2^63 (AR = 3) -------------------------------------------------------------------
+// The reference's Zq works for every q below 2^63 (`self.v + rhs.v`, zq.rs:225, is its limit); a lazy range needs 4q (Harvey)
+// or at least the sum of two values below 2q to fit a word, and 4q >= 2^64 here.  So every value is canonical between
+// butterflies: the Shoup product is exact in [0, 2q) for ANY 64-bit multiplicand and 2q < 2^64, a sum of two canonical values
+// is below 2q, and canon2's sign test (x - q as a signed word) holds for x < 2^63 + q.  Three conditional subtractions per
+// butterfly; ~33 instructions against 21 for the lazy Shoup butterfly.
+__device__ __forceinline__ u64 add63(u64 x, u64 y, const Mod &m) { return canon2(x + y, m); }
+__device__ __forceinline__ u64 sub63(u64 x, u64 y, const Mod &m) { return canon2(x + (m.q - y), m); }   // (0, 2q) -> [0, q)
+__device__ __forceinline__ u64 mul63(u64 y, u64 w, u64 wp, const Mod &m) { return canon2(mul_shoup_lazy(y, w, wp, m), m); }
+// ntt.rs:57-62 / 91-96 on canonical values
+__device__ __forceinline__ void ct_bfly63(u64 &x, u64 &y, u64 w, u64 wp, const Mod &m) {
+    const u64 u = x, t = mul63(y, w, wp, m);
+    x = add63(u, t, m);
+    y = sub63(u, t, m);
+}
+__device__ __forceinline__ void gs_bfly63(u64 &x, u64 &y, u64 w, u64 wp, const Mod &m) {
+    const u64 u = x, t = y;
+    x = add63(u, t, m);
+    y = mul63(sub63(u, t, m), w, wp, m);
+}
+
 // Sum of products of canonical operands, reduced once per kMacChunk terms instead of once per
 // term: a term is < q^2 < 2^124, so 8 of them plus a canonical carry-over stay below 2^128.
 // One term costs 4 multiplies and a 128-bit add here, against ~18 multiplies for mul_mod_var.

@@ -54,12 +54,14 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks(pkg):
 @pytest.mark.gpu
 @pytest.mark.parametrize("q,log_n", [(Q61, 4), (Q61, 6), (Q61, 8), (Q61, 9), (Q61, 12), (Q61, 13), (Q61, 14), (Q61, 16), (Q61, 17),
                                      (Q16, 8), (Q16, 14), (4611686018425815041, 10), (4611686018425815041, 15),
-                                     (0x1ffffff900000001, 12), (0x1ffffff900000001, 16)])
+                                     (0x1ffffff900000001, 12), (0x1ffffff900000001, 16),
+                                     (9223372036844421121, 8), (9223372036844421121, 13), (4611686018429485057, 14),
+                                     (9223372036844421121, 16), (4611686018429485057, 18)])
 def test_every_group_shape_full_and_ragged(pkg, oracle, q, log_n):
     """a workgroup of the contiguous kernels holds W = 16 .. 1 polynomials: batches that fill every group (the uniform
     load / store path: one lane offset, scalar bases) and batches that leave the last group ragged (the per-lane path),
     forward, inverse and the product, on every arithmetic (pseudo-Mersenne, Shoup below and above 2^61, word Montgomery,
-    the 32-bit kernels)"""
+    the 32-bit kernels, and — since round 5 in the same kernels — the strict arithmetic of 2^62 <= q < 2^63)"""
     assert pkg.binding.device_count() >= 1, "no HIP device: -m gpu tests need a real MI355X"
     n = 1 << log_n
     plan = pkg.Plan(q, n)
@@ -200,3 +202,44 @@ def test_shard_gather_from_the_c_abi(pkg, oracle):
     torch.cuda.synchronize()
     assert torch.equal(tiny, whole[: 2 * n])
     assert np.array_equal(whole[:n].cpu().numpy().view(np.uint64), oracle.ntt(q, n, x[:n].cpu().numpy().view(np.uint64)).reshape(-1))
+
+
+_G63_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+import fhe_study_amd as pkg
+h = hashlib.sha256()
+for q in (9223372036752015361, 4611686018429485057):       # the largest / smallest prime = 1 (mod 2^21) in [2^62, 2^63)
+    for log_n, batch in ((4, 33), (9, 17), (13, 3), (14, 3), (16, 2), (18, 1), (20, 1)):
+        n = 1 << log_n
+        plan = pkg.Plan(q, n)
+        rng = np.random.default_rng(q %% 1000 + log_n)
+        a = rng.integers(0, q, size=(batch, n), dtype=np.uint64); a[0, :] = q - 1
+        b = rng.integers(0, q, size=(batch, n), dtype=np.uint64); b[-1, ::3] = q - 1
+        A = plan.forward(a)
+        h.update(np.ascontiguousarray(A).tobytes())
+        h.update(np.ascontiguousarray(plan.inverse(A)).tobytes())
+        for x in plan.rq_mul(a, b):
+            h.update(np.ascontiguousarray(x).tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_strict_moduli_two_builds_of_the_same_words(pkg):
+    """2^62 <= q < 2^63 (NTT::ntt / intt / Rq x Rq, arith/src/ntt.rs:44-110, ring_nq.rs:586-607; Zq's limit zq.rs:225): since
+    round 5 the range runs in the two-pass / fused kernels with strict butterflies (AR = 3) instead of ceil(log2 n / 4) plain
+    launches.  The plain kernels are still in the library (n < 16, and everything under FHE_G63_PLAIN=1): both forms must
+    produce the same words — forward, inverse and product (c, c_evals, a_evals, b_evals), single-pass and two-pass sizes,
+    ragged batches.  (Each form against the oracle: test_moduli_between_2_62_and_2_63, test_every_group_shape_full_and_ragged.)"""
+    assert pkg.binding.device_count() >= 1, "no HIP device: -m gpu tests need a real MI355X"
+    script = _G63_SCRIPT % (ROOT,)
+    digests = []
+    for plain in ("0", "1"):
+        env = _clean_env()
+        env["FHE_G63_PLAIN"] = plain
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1], digests

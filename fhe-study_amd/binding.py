@@ -14,8 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FHE_NTT_LIB") or os.path.join(_HERE, "libfhe_ntt.so")  # env: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "ntt_kernels.hip", "ntt_persist.hip", "digit_mac.hip", "digit32.hip", "bfv32.hip", "smallq.hip", "generic63.hip", "zring.hip", "glue.hip"]
-HEADERS = ["ntt_kernels.hpp", "ntt_rounds.hpp", "ntt_persist.hpp", "persist_sched.hpp", "digit_mac.hpp", "digit32.hpp", "bfv32.hpp", "smallq.hpp", "ntt32_rounds.hpp", "ntt32_big.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp",
+SOURCES = ["capi.hip", "ntt_kernels.hip", "ntt_kernels_q62.hip", "ntt_persist.hip", "digit_mac.hip", "digit32.hip", "bfv32.hip", "smallq.hip", "generic63.hip", "zring.hip", "glue.hip"]
+HEADERS = ["ntt_kernels.hpp", "ntt_rounds.hpp", "ntt_persist.hpp", "persist_sched.hpp", "digit_mac.hpp", "digit32.hpp", "bfv32.hpp", "smallq.hpp", "ntt32_rounds.hpp", "ntt32_big.hpp", "zq_device.hpp", "capi_internal.hpp", "mac_kernel.hpp", "ntt_kernels.hip",
            os.path.join("..", "..", "include", "fhe_ntt.h"), os.path.join("..", "..", "include", "fhe_ntt_experimental.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
 # -ffp-contract=off: zring.hip restates the reference's f64 scale-and-round (one IEEE rounding

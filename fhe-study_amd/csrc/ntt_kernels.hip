@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256) void ntt_tiny_kernel(PassArgs a) {
     }
 }
 
+#ifndef FHE_NTT_TU_Q62   // (non-template kernels: the main translation unit only)
 // ---------------------------------------------------------------------------
 // element-wise kernels
 // ---------------------------------------------------------------------------
@@ -711,6 +712,8 @@ __global__ __launch_bounds__(256) void check_canonical_kernel(const u64 *__restr
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) bad |= (x[i] >= q);
     if (bad) atomicOr(flag, 1);
 }
+
+#endif
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -775,16 +778,114 @@ static hipError_t launch_strided(const PassArgs &a, hipStream_t st, unsigned ope
 #define CONTIG_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #endif
 
+template <int LP, int AR>
+static hipError_t launch_rq_mul_fused_lp(const PassArgs &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    const u64 grid = (a.batch + C::W - 1) / C::W;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = C::LDS_BYTES + (size_t)C::LTW_N * sizeof(Tw);   // a second twiddle tile
+    if (hipError_t e = allow_big_lds((const void *)rq_mul_fused_kernel<LP, AR>, lds_bytes)) return e;
+    KernelTimer kt("rq_mul_fused", LP, st);
+    hipLaunchKernelGGL((rq_mul_fused_kernel<LP, AR>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
+    return post_launch();
+}
+
+template <int LP, int AR>
+static hipError_t launch_rq_mul_mid_lp(const PassArgs &a, hipStream_t st) {
+    using C = ContigCfg<LP>;
+    const u64 nb = 1ull << (a.log_n - LP);
+    const u64 grid = nb * ((a.batch + C::W - 1) / C::W);
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = C::LDS_BYTES + (FHE_MID_ONE_TILE ? 0 : (size_t)C::LTW_N * sizeof(Tw));   // ONE twiddle tile: four workgroups per CU
+    if (hipError_t e = allow_big_lds((const void *)rq_mul_mid_kernel<LP, AR>, lds_bytes)) return e;
+    KernelTimer kt("rq_mul_mid", LP, st);
+    hipLaunchKernelGGL((rq_mul_mid_kernel<LP, AR>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
+    return post_launch();
+}
+
+// ---- two translation units ------------------------------------------------------------------------------------------------
+// Every kernel above is instantiated per arithmetic AR, per size and per variant; one translation unit for all of them was
+// the library's longest compile by far.  The arithmetics with the narrow headroom — AR = 0 (2^61 <= q < 2^62, Harvey) and
+// AR = 3 (2^62 <= q < 2^63, strict) — are instantiated in ntt_kernels_q62.hip, which includes this file with
+// FHE_NTT_TU_Q62 defined and provides the five entry points below; this unit keeps AR = 1, 2, 4 and the public launchers.
+hipError_t q62_fwd_contig(int ar, int lp, bool final, const PassArgs &a, hipStream_t st);
+hipError_t q62_inv_contig(int ar, int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st);
+hipError_t q62_strided(int ar, bool inv, int la, const PassArgs &a, hipStream_t st, unsigned operands);
+hipError_t q62_rq_mul_fused(int ar, int lp, const PassArgs &a, hipStream_t st);
+hipError_t q62_rq_mul_mid(int ar, int lp, const PassArgs &a, hipStream_t st);
+
+#ifdef FHE_NTT_TU_Q62
+template <int AR>
+static hipError_t q62_fwd_contig_ar(int lp, bool final, const PassArgs &a, hipStream_t st) {
+    switch (lp) {
+#define X(LP_) case LP_: return final ? launch_fwd_contig<LP_, true, AR>(a, st) : launch_fwd_contig<LP_, false, AR>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+template <int AR>
+static hipError_t q62_inv_contig_ar(int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st) {
+    switch (lp) {
+#define X(LP_)                                                                                   \
+    case LP_:                                                                                    \
+        if (final) return mul_in ? launch_inv_contig<LP_, true, true, AR>(a, st)                 \
+                                 : launch_inv_contig<LP_, true, false, AR>(a, st);               \
+        return mul_in ? launch_inv_contig<LP_, false, true, AR>(a, st)                           \
+                      : launch_inv_contig<LP_, false, false, AR>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+template <bool INV, int AR>
+static hipError_t q62_strided_ar(int la, const PassArgs &a, hipStream_t st, unsigned operands) {
+    switch (la) {
+        case 6: return launch_strided<6, 128, INV, AR>(a, st, operands);
+        case 7: return launch_strided<7, 64, INV, AR>(a, st, operands);
+        case 8: return launch_strided<8, FHE_STRIDED_CW8, INV, AR>(a, st, operands);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t q62_fwd_contig(int ar, int lp, bool final, const PassArgs &a, hipStream_t st) {
+    return ar == 3 ? q62_fwd_contig_ar<3>(lp, final, a, st) : q62_fwd_contig_ar<0>(lp, final, a, st);
+}
+hipError_t q62_inv_contig(int ar, int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st) {
+    return ar == 3 ? q62_inv_contig_ar<3>(lp, final, mul_in, a, st) : q62_inv_contig_ar<0>(lp, final, mul_in, a, st);
+}
+hipError_t q62_strided(int ar, bool inv, int la, const PassArgs &a, hipStream_t st, unsigned operands) {
+    if (ar == 3) return inv ? q62_strided_ar<true, 3>(la, a, st, operands) : q62_strided_ar<false, 3>(la, a, st, operands);
+    return inv ? q62_strided_ar<true, 0>(la, a, st, operands) : q62_strided_ar<false, 0>(la, a, st, operands);
+}
+hipError_t q62_rq_mul_fused(int ar, int lp, const PassArgs &a, hipStream_t st) {
+    switch (lp) {
+#define X(LP_) case LP_: return ar == 3 ? launch_rq_mul_fused_lp<LP_, 3>(a, st) : launch_rq_mul_fused_lp<LP_, 0>(a, st);
+        CONTIG_CASES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t q62_rq_mul_mid(int ar, int lp, const PassArgs &a, hipStream_t st) {
+    switch (lp) {
+#define X(LP_) case LP_: return ar == 3 ? launch_rq_mul_mid_lp<LP_, 3>(a, st) : launch_rq_mul_mid_lp<LP_, 0>(a, st);
+        X(8) X(9) X(10) X(11) X(12)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+#else   // ---- the main translation unit: AR = 1, 2, 4, the dispatchers and the public launchers -------------------------------
+
 // ar: the kernels' AR (0 / 1 = Shoup tables, 2 = pseudo-Mersenne tables: DevicePlan::arith)
 static hipError_t fwd_contig_dispatch(int lp, bool final, int ar, const PassArgs &a, hipStream_t st) {
+    if (ar == 0 || ar == 3) return q62_fwd_contig(ar, lp, final, a, st);
     switch (lp) {
 #define X(LP_)                                                                                   \
     case LP_:                                                                                    \
         if (ar == 4) return final ? launch_fwd_contig<LP_, true, 4>(a, st) : launch_fwd_contig<LP_, false, 4>(a, st); \
-        if (ar == 3) return final ? launch_fwd_contig<LP_, true, 3>(a, st) : launch_fwd_contig<LP_, false, 3>(a, st); \
         if (ar == 2) return final ? launch_fwd_contig<LP_, true, 2>(a, st) : launch_fwd_contig<LP_, false, 2>(a, st); \
-        if (ar == 1) return final ? launch_fwd_contig<LP_, true, 1>(a, st) : launch_fwd_contig<LP_, false, 1>(a, st); \
-        return final ? launch_fwd_contig<LP_, true, 0>(a, st) : launch_fwd_contig<LP_, false, 0>(a, st);
+        return final ? launch_fwd_contig<LP_, true, 1>(a, st) : launch_fwd_contig<LP_, false, 1>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
@@ -817,10 +918,8 @@ static hipError_t inv_contig_dispatch_mg(int lp, bool final, const PassArgs &a, 
 }
 static hipError_t inv_contig_dispatch(int ar, int lp, bool final, bool mul_in, const PassArgs &a, hipStream_t st) {
     if (ar == kArMontgomery) return mul_in ? hipErrorInvalidValue : inv_contig_dispatch_mg(lp, final, a, st);
-    return ar == 3 ? inv_contig_dispatch_ar<3>(lp, final, mul_in, a, st)
-         : ar == 2 ? inv_contig_dispatch_ar<2>(lp, final, mul_in, a, st)
-         : ar == 1 ? inv_contig_dispatch_ar<1>(lp, final, mul_in, a, st)
-                   : inv_contig_dispatch_ar<0>(lp, final, mul_in, a, st);
+    if (ar == 0 || ar == 3) return q62_inv_contig(ar, lp, final, mul_in, a, st);
+    return ar == 2 ? inv_contig_dispatch_ar<2>(lp, final, mul_in, a, st) : inv_contig_dispatch_ar<1>(lp, final, mul_in, a, st);
 }
 
 template <bool INV, int AR>
@@ -835,10 +934,8 @@ static hipError_t strided_dispatch_ar(int la, const PassArgs &a, hipStream_t st,
 template <bool INV>
 static hipError_t strided_dispatch(int ar, int la, const PassArgs &a, hipStream_t st, unsigned operands = 1) {
     if (ar == kArMontgomery) return strided_dispatch_ar<INV, 4>(la, a, st, operands);
-    return ar == 3 ? strided_dispatch_ar<INV, 3>(la, a, st, operands)
-         : ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands)
-         : ar == 1 ? strided_dispatch_ar<INV, 1>(la, a, st, operands)
-                   : strided_dispatch_ar<INV, 0>(la, a, st, operands);
+    if (ar == 0 || ar == 3) return q62_strided(ar, INV, la, a, st, operands);
+    return ar == 2 ? strided_dispatch_ar<INV, 2>(la, a, st, operands) : strided_dispatch_ar<INV, 1>(la, a, st, operands);
 }
 // the tables and n^-1 constants a pass runs on: {w, w 2^32 mod q} for pseudo-Mersenne plans, {w, floor(w 2^64 / q)} otherwise
 static inline bool plan_runs_montgomery(const DevicePlan &p) {
@@ -899,19 +996,6 @@ hipError_t launch_ntt_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 
     return hipSuccess;
 }
 
-template <int LP, int AR>
-static hipError_t launch_rq_mul_fused_lp(const PassArgs &a, hipStream_t st) {
-    using C = ContigCfg<LP>;
-    const u64 grid = (a.batch + C::W - 1) / C::W;
-    if (grid == 0) return hipSuccess;
-    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    constexpr size_t lds_bytes = C::LDS_BYTES + (size_t)C::LTW_N * sizeof(Tw);   // a second twiddle tile
-    if (hipError_t e = allow_big_lds((const void *)rq_mul_fused_kernel<LP, AR>, lds_bytes)) return e;
-    KernelTimer kt("rq_mul_fused", LP, st);
-    hipLaunchKernelGGL((rq_mul_fused_kernel<LP, AR>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
-    return post_launch();
-}
-
 hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_evals, const u64 *b_, bool b_is_evals,
                                u64 *c, u64 *c_evals, u64 *a_evals, u64 *b_evals, u64 batch, hipStream_t st) {
     const int L = p.log_n;
@@ -925,26 +1009,13 @@ hipError_t launch_rq_mul_fused(const DevicePlan &p, const u64 *a_, bool a_is_eva
     a.in = a_; a.in2 = b_; a.out = c; a.out2 = c_evals; a.out3 = a_evals; a.out4 = b_evals;
     a.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
     a.batch = batch;
+    if (!mg && (p.arith == 0 || p.arith == 3)) return q62_rq_mul_fused(p.arith, L, a, st);
     switch (L) {
-#define X(LP_) case LP_: return mg ? launch_rq_mul_fused_lp<LP_, 4>(a, st) : p.arith == 3 ? launch_rq_mul_fused_lp<LP_, 3>(a, st) : p.arith == 2 ? launch_rq_mul_fused_lp<LP_, 2>(a, st) : p.arith == 1 ? launch_rq_mul_fused_lp<LP_, 1>(a, st) : launch_rq_mul_fused_lp<LP_, 0>(a, st);
+#define X(LP_) case LP_: return mg ? launch_rq_mul_fused_lp<LP_, 4>(a, st) : p.arith == 2 ? launch_rq_mul_fused_lp<LP_, 2>(a, st) : launch_rq_mul_fused_lp<LP_, 1>(a, st);
         CONTIG_CASES(X)
 #undef X
     }
     return hipErrorInvalidValue;
-}
-
-template <int LP, int AR>
-static hipError_t launch_rq_mul_mid_lp(const PassArgs &a, hipStream_t st) {
-    using C = ContigCfg<LP>;
-    const u64 nb = 1ull << (a.log_n - LP);
-    const u64 grid = nb * ((a.batch + C::W - 1) / C::W);
-    if (grid == 0) return hipSuccess;
-    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    constexpr size_t lds_bytes = C::LDS_BYTES + (FHE_MID_ONE_TILE ? 0 : (size_t)C::LTW_N * sizeof(Tw));   // ONE twiddle tile: four workgroups per CU
-    if (hipError_t e = allow_big_lds((const void *)rq_mul_mid_kernel<LP, AR>, lds_bytes)) return e;
-    KernelTimer kt("rq_mul_mid", LP, st);
-    hipLaunchKernelGGL((rq_mul_mid_kernel<LP, AR>), dim3((unsigned)grid), dim3(C::TH), lds_bytes, st, a);
-    return post_launch();
 }
 
 // c = a * b at two-pass sizes: [strided(a) | strided(b)] (one launch) -> middle kernel -> strided^-1.
@@ -989,8 +1060,9 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a_, bool a_is_
         m.out3 = (keep_a_evals && !a_is_evals) ? wa + o : nullptr;
         m.out4 = (keep_b_evals && !b_is_evals) ? wb + o : nullptr;
         m.flags = (a_is_evals ? 1u : 0u) | (b_is_evals ? 2u : 0u);
-        switch (LB) {
-#define X(LP_) case LP_: e = ar == 4 ? launch_rq_mul_mid_lp<LP_, 4>(m, st) : ar == 3 ? launch_rq_mul_mid_lp<LP_, 3>(m, st) : ar == 2 ? launch_rq_mul_mid_lp<LP_, 2>(m, st) : ar == 1 ? launch_rq_mul_mid_lp<LP_, 1>(m, st) : launch_rq_mul_mid_lp<LP_, 0>(m, st); break;
+        if (ar == 0 || ar == 3) e = q62_rq_mul_mid(ar, LB, m, st);
+        else switch (LB) {
+#define X(LP_) case LP_: e = ar == 4 ? launch_rq_mul_mid_lp<LP_, 4>(m, st) : ar == 2 ? launch_rq_mul_mid_lp<LP_, 2>(m, st) : launch_rq_mul_mid_lp<LP_, 1>(m, st); break;
             X(8) X(9) X(10) X(11) X(12)
 #undef X
             default: return hipErrorInvalidValue;
@@ -1178,5 +1250,7 @@ bool ntt_kernels_ablated() {
     return false;
 #endif
 }
+
+#endif   // FHE_NTT_TU_Q62
 
 }  // namespace fhe

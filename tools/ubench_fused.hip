@@ -19,6 +19,9 @@
 //   mode 3  16 stages, no HBM at all (tile synthesised in registers, result kept in LDS):
 //           the VALU/LDS ceiling at the clock the chip then holds
 //   ref     the production two-pass transform through launch_ntt_forward
+// Build (in-tree, the binary travels to the GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w '-DCONTIG_CASES(X)=X(8)' -o tools/ubench_fused \
+//         tools/ubench_fused.hip fhe-study_amd/csrc/generic63.hip fhe-study_amd/csrc/ntt_kernels_q62.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

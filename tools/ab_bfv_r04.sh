@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 B=fhe-study_amd/build; mkdir -p $B/abl
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=off"
-OBJS="$B/capi.o $B/ntt_kernels.o $B/ntt_persist.o $B/digit_mac.o $B/digit32.o $B/smallq.o $B/generic63.o $B/zring.o $B/glue.o"
+OBJS="$B/capi.o $B/ntt_kernels.o $B/ntt_kernels_q62.o $B/ntt_persist.o $B/digit_mac.o $B/digit32.o $B/smallq.o $B/generic63.o $B/zring.o $B/glue.o"
 build() {   # tag, defines
   /opt/rocm/bin/hipcc $F $2 -c -o $B/abl/bfv32_$1.o fhe-study_amd/csrc/bfv32.hip
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $B/abl/libfhe_ntt_bfv_$1.so $B/abl/bfv32_$1.o $OBJS

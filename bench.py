@@ -63,8 +63,8 @@ PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffi
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per config, see CONFIG_STEPS)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: per config)")
     ap.add_argument("--config", type=int, default=5, choices=[2, 3, 4, 5],
                     help="BASELINE.json configuration (1-based; 5 = the headline, the contract line)")
     ap.add_argument("--log-n", type=int, default=None)
@@ -345,6 +345,14 @@ def workload_extprod(args, pkg, torch, dev, st, rank, world):
     }
 
 
+# Default (steps, warm-up) per config when the flags are not given.  The headline step is 23 ms: 2 + 10 steps are 0.28 s.  The
+# other configurations' steps are 0.15 - 2.2 ms, and the chip takes 50 - 100 ms of load to reach its sustained clocks: with
+# 2 + 10 steps config 3 reads 0.93 M ct-mul/s and config 4 1.95 M products/s where the sustained rates are 1.00 M and 2.25 M
+# (same box, same process order; profiles/r05_warmup_effect.txt).  Their defaults therefore warm up for >= 0.1 s and time
+# >= 0.2 s; the driver's own --steps / --warmup always win.
+CONFIG_STEPS = {5: (10, 2), 2: (2000, 1000), 3: (100, 50), 4: (1000, 500)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N ranks here — as a child
     `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` — BEFORE this process has imported
@@ -367,6 +375,10 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.steps is None:
+        args.steps = CONFIG_STEPS[args.config][0]
+    if args.warmup is None:
+        args.warmup = CONFIG_STEPS[args.config][1]
     if args.gpus < 1:
         print(f"[bench] --gpus {args.gpus}: need at least one GPU", file=sys.stderr)
         sys.exit(2)

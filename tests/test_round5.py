@@ -243,3 +243,4 @@ def test_strict_moduli_two_builds_of_the_same_words(pkg):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
     assert digests[0] == digests[1], digests
+

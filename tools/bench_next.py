@@ -15,12 +15,7 @@ dev = "cuda:0"
 U64 = 1 << 64
 
 
-def timeit(f, reps=5):
-    f(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps): f()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
+from _timing import timeit                           # warm clocks: tools/_timing.py
 
 
 def bfv(n=8192, q=65537, t=2, batch=256):

@@ -5,6 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import fhe_study_amd as pkg
+from _timing import timeit
 
 B = pkg.binding
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -21,13 +22,7 @@ for mode in ("fwd", "inv"):
         B.set_batch_tile(tile)
         f = (lambda: plan.forward_dev(x.data_ptr(), y.data_ptr(), batch, st)) if mode == "fwd" else \
             (lambda: plan.inverse_dev(x.data_ptr(), y.data_ptr(), batch, st))
-        for _ in range(2): f()
-        torch.cuda.synchronize()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps): f()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt = timeit(f)                               # warm clocks: tools/_timing.py
         B.kernel_timing_reset(); B.kernel_timing_enable(True)
         f(); torch.cuda.synchronize()
         kt = B.kernel_timing_read(); B.kernel_timing_enable(False)

@@ -6,6 +6,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import fhe_study_amd as pkg
+from _timing import timeit
 
 B = pkg.binding
 st = torch.cuda.current_stream().cuda_stream
@@ -22,13 +23,7 @@ for log_n, batch in sizes:
     B.fill_synthetic_dev(q, 2, 0, batch * n, b.data_ptr(), st)
     work = torch.empty(max(16, plan.workspace_bytes(batch) // 8), dtype=torch.int64, device="cuda:0")
     f = lambda: plan.rq_mul_dev(a.data_ptr(), b.data_ptr(), c.data_ptr(), batch, d_c_evals=ce.data_ptr(), d_work=work.data_ptr(), stream=st)
-    for _ in range(3): f()
-    torch.cuda.synchronize()
-    reps = 20 if batch > 1 else 200
-    t0 = time.perf_counter()
-    for _ in range(reps): f()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    dt = timeit(f)                                   # warm clocks: tools/_timing.py
     B.kernel_timing_reset(); B.kernel_timing_enable(True)
     f(); torch.cuda.synchronize()
     kt = B.kernel_timing_read(); B.kernel_timing_enable(False)

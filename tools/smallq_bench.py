@@ -5,6 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fhe_study_amd as pkg
+from _timing import timeit
 rng = np.random.default_rng(1)
 for q, n, batch in ((65537, 1024, 262144), (65537, 4096, 65536), (65537, 8192, 32768), (65537, 16384, 16384), (65537, 32768, 8192),
                     (786433, 65536, 4096), (786433, 131072, 2048)):
@@ -16,11 +17,6 @@ for q, n, batch in ((65537, 1024, 262144), (65537, 4096, 65536), (65537, 8192, 3
            ("inverse", lambda: plan.inverse_dev(a.data_ptr(), o.data_ptr(), batch))]
     ops.append(("Rq x Rq", lambda: plan.rq_mul_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), batch)))
     for name, f in ops:
-        for _ in range(3): f()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10): f()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10
+        dt = timeit(f)                               # warm clocks: tools/_timing.py
         by = (16 if name != "Rq x Rq" else 24) * n * batch
         print(f"FHE_EXT32={os.environ.get('FHE_EXT32', '1')} q={q} n={n} batch={batch} {name:8s}: {dt*1e3:7.3f} ms  {batch/dt/1e6:8.2f} M/s  {by/dt/1e12:5.2f} TB/s algorithmic")

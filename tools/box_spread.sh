@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/box_spread.sh <tag> — one line per box of the pool: the contract bench and configs 2-4 on whatever box this call got
-# (boxes differ by +-2-3 %: clocks, HBM stacks).  Appends to gpurun_out/spread_<tag>.txt; run it in several gpurun calls:
-#   /usr/local/graft/bin/gpurun --timeout 400 -- 'bash tools/box_spread.sh r05'
+# (boxes differ by +-2 % on the headline).  Prints the line (and writes gpurun_out/spread_<tag>.txt on the box: gpurun merges
+# that file back over the local one, so collect the printed lines):
+#   /usr/local/graft/bin/gpurun --timeout 400 -- 'bash tools/box_spread.sh r05' | tail -1 >> profiles/<tag>_box_spread_lines.txt
 set -eo pipefail
 TAG=${1:-r05}
 OUT=gpurun_out/spread_$TAG.txt

@@ -47,7 +47,7 @@ enum : int {
     kArShoup62 = 0,     // q < 2^62: Harvey [0, 4q), Shoup products
     kArWide61 = 1,      // q < 2^61: Shoup products, compile-time bounds up to 8q
     kArPMersenne = 2,   // q = 2^k - delta: five-multiply butterflies on {w, w 2^32 mod q}
-    kArStrict63 = 3,    // 2^62 <= q < 2^63: strict butterflies in plain kernels (generic63.hip)
+    kArStrict63 = 3,    // 2^62 <= q < 2^63: strict butterflies (every value canonical) in the same kernels; n < 16 in generic63.hip
     kArMontgomery = 4,   // never a plan's arith: what launch_ntt_forward / launch_ntt_inverse pass their kernels when tw_*_mg are set (q = 1 mod 2^32)
 };
 
@@ -120,9 +120,10 @@ hipError_t launch_rq_mul_two_pass(const DevicePlan &p, const u64 *a, bool a_is_e
                                   u64 batch, u64 batch_tile, hipStream_t st);
 hipError_t launch_pointwise_mul(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count,
                                 hipStream_t st);
-// 2^62 <= q < 2^63 (DevicePlan::arith == 3, generic63.hip): strict butterflies, up to four stages per launch in global
-// memory.  launch_ntt_forward / launch_ntt_inverse / launch_pointwise_mul route here; the fused and transforming-load
-// entry points return hipErrorNotSupported for such a plan and their callers compose these three.
+// 2^62 <= q < 2^63 (DevicePlan::arith == 3) in PLAIN kernels (generic63.hip): strict butterflies, up to four stages per
+// launch in global memory.  Since round 5 the transforms and products of such a plan run in the two-pass / fused kernels
+// (AR = 3); launch_ntt_forward / launch_ntt_inverse route here only for n < 16 or under FHE_G63_PLAIN=1, launch_pointwise_mul
+// always; the transforming-load entry points still return hipErrorNotSupported for such a plan and their callers compose.
 hipError_t launch_g63_forward(const DevicePlan &p, const u64 *in, u64 *out, u64 batch, hipStream_t st);
 hipError_t launch_g63_inverse(const DevicePlan &p, const u64 *in, const u64 *in2, u64 *evals_out, u64 *out, u64 batch, hipStream_t st);
 hipError_t launch_g63_pointwise(const DevicePlan &p, const u64 *x, const u64 *y, u64 *z, u64 count, hipStream_t st);

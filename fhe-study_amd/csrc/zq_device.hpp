@@ -37,7 +37,7 @@ struct Tw {  // one twiddle: w and its Shoup companion floor(w*2^64/q)
 struct Tw32 { uint32_t w, wp; };   // the small-modulus kernels (digit32 / bfv32 / smallq): twiddle and floor(w * 2^32 / p)
 
 struct Mod {
-    u64 q;      // modulus, 3 <= q < 2^63 (2^62 and above: generic63.hip only — the fields below that hold 4q are then unused)
+    u64 q;      // modulus, 3 <= q < 2^63 (2^62 and above: the strict arithmetic, AR = 3 — the fields below that hold 2q / 4q are then unused)
     u64 q2;     // 2q
     u64 nq;     // -q      mod 2^64
     u64 neg2q;  // -2q     mod 2^64
@@ -488,7 +488,7 @@ __device__ __forceinline__ u64 mul_mod_var(u64 a, u64 b, const Mod &m) {
     return reduce128(__umul64hi(a, b), a * b, m);
 }
 
-// The same for 2^62 <= q < 2^63 (generic63.hip; 4q no longer fits a word): every partial result canonical before the
+// The same for 2^62 <= q < 2^63 (AR = 3 and generic63.hip; 4q no longer fits a word): every partial result canonical before the
 // next addition.  canon2's sign test needs x < 2^63 + q, which x < 2q gives for every q < 2^63.
 __device__ __forceinline__ u64 reduce128_63(u64 hi, u64 lo, const Mod &m) {
     const u64 l = canon2(lo - __umul64hi(lo, m.onep) * m.q, m);

@@ -559,9 +559,9 @@ def test_bfv_epilogue_forms_give_the_same_words(pkg, oracle, need_gpu):
     assert outs["general"] == outs["f64"] == outs["int"] == outs["ieee-division"] == outs["ieee-division-general"]
 
 
-# ---- the top of the reference's modulus range: 2^62 <= q < 2^63 (csrc/generic63.hip) ------------------------------------
+# ---- the top of the reference's modulus range: 2^62 <= q < 2^63 (AR = 3 of ntt_kernels.hip; csrc/generic63.hip) ----------
 # Zq::add computes `self.v + rhs.v` in a u64 (arith/src/zq.rs:225): the reference works for every q below 2^63.  The lazy
-# kernels need 4q < 2^64; this range runs strict butterflies in plain kernels, ceil(log2 n / 4) launches per transform.
+# kernels need 4q < 2^64; this range runs strict butterflies (round 5: in the two-pass / fused kernels; before: plain launches).
 Q63_TOP = 9223372036844421121      # largest prime = 1 (mod 2^17) below 2^63
 Q63_BOTTOM = 4611686018429485057   # smallest one above 2^62
 

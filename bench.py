@@ -75,6 +75,8 @@ def parse():
                          "scaling).  Config 5 defaults to 65536 = configs[4]; config 4: 630 = configs[3]")
     ap.add_argument("--q", type=int, default=None)
     ap.add_argument("--batch-tile", type=int, default=0, help="polynomials per launch (0 = library default)")
+    ap.add_argument("--prewarm", type=float, default=0.15,
+                    help="seconds of untimed steps BEFORE the --warmup steps, so that the chip is at its sustained clocks (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-parity", action="store_true")
@@ -432,14 +434,29 @@ def main():
         W = workload_extprod(args, pkg, torch, dev, st, rank, world)
     step = W["step"]
 
-    for _ in range(args.warmup):
-        step()
-
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # Pre-warm (untimed, before the W warm-up steps): the chip needs 50 - 100 ms of load to reach its sustained clocks
+    # (profiles/r05_warmup_effect.txt).  One rank's step at N = 8 is 3 ms, so W = 2 warm-up steps would start the timed
+    # region on a cold chip — and a rank that finished its set-up early would have idled at the barrier below.  So: align
+    # the ranks, run the step for args.prewarm seconds, then the contract's W warm-up steps, fence, K timed steps.
+    prewarm_steps = 0
+    if args.prewarm > 0:
+        fence()
+        tp = time.perf_counter()
+        burst = 1
+        while time.perf_counter() - tp < args.prewarm:
+            for _ in range(burst):
+                step()
+            torch.cuda.synchronize()
+            prewarm_steps += burst
+            burst = min(2 * burst, 64)
+    for _ in range(args.warmup):
+        step()
 
     fence()
     t0 = time.perf_counter()
@@ -530,7 +547,8 @@ def main():
                 "transform_achieved": step_achieved, "transform_frac": step_achieved / HBM_PEAK_GBS})
         out = {
             "metric": W["metric"], "value": value, "unit": W["unit"], "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "warmup": args.warmup, "prewarm": {"seconds": args.prewarm, "steps": prewarm_steps, "what": "untimed steps before the warm-up steps (clock ramp)"},
+            "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": W.get("scaling", "weak"), "vs_baseline": None,
             "dtype": W.get("dtype", "u64"), "data": "synthetic", "config": W["config"], "roofline": roofline,
         }

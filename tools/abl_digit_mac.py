@@ -17,8 +17,8 @@ out = torch.empty_like(c)
 prep = torch.empty(L.fhe_tggsw_prepared_words(n, k, l), dtype=torch.int64, device="cuda")
 B._check(L.fhe_tggsw_prepare_dev(n, k, l, g.data_ptr(), prep.data_ptr(), None))
 f = lambda: B._check(L.fhe_tggsw_external_product_prepared_dev(n, k, l, prep.data_ptr(), c.data_ptr(), out.data_ptr(), batch, None))
-for _ in range(3): f()
-torch.cuda.synchronize()
+from _timing import timeit
+timeit(f)                                            # warm clocks (tools/_timing.py)
 B.kernel_timing_reset(); B.kernel_timing_enable(True)
 for _ in range(10): f()
 torch.cuda.synchronize()

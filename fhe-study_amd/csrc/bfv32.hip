@@ -61,6 +61,23 @@ __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
 #ifndef FHE_B32_FWD_WAVES
 #define FHE_B32_FWD_WAVES 4      // forward kernels: waves per SIMD the register allocation must allow
 #endif
+// Round 5: the TWO-prime forward kernel (the tensor's four source polynomials: the largest of the step's forward work) at SIX
+// waves per SIMD — three workgroups of 512 threads per CU instead of two, as the tensor's inverse kernel already runs — with
+// the twiddles read as they go (no registers held across the exchange: no spills at 80 registers): 502 -> 453 us per 2048
+// pairs at N = 8192.  The three-prime kernel (c2) spills at six waves and is slower there (181 -> 196 / 210 us): it keeps
+// FHE_B32_FWD_WAVES / FHE_B32_FWD_PRELOAD.  profiles/r05_bfv_occupancy_ab.txt.
+#ifndef FHE_B32_FWD2_WAVES
+#define FHE_B32_FWD2_WAVES 6
+#endif
+#ifndef FHE_B32_FWD2_PRELOAD
+#define FHE_B32_FWD2_PRELOAD 0
+#endif
+constexpr int fwd_waves(int npr) { return npr == 2 ? FHE_B32_FWD2_WAVES : FHE_B32_FWD_WAVES; }
+constexpr bool fwd_preload(int npr) { return npr == 2 ? FHE_B32_FWD2_PRELOAD != 0 : FHE_B32_FWD_PRELOAD != 0; }
+#ifndef FHE_B32_PARK_LDS
+#define FHE_B32_PARK_LDS 1       // inverse kernels: as many of the parked words as fit the occupancy's LDS share stay in LDS (round 5)
+#endif
+constexpr int kRelinWps = 4;     // waves per SIMD of the relinearisation kernel (120 registers: -Rpass-analysis=kernel-resource-usage)
 #ifndef FHE_B32_INV_LOOSE
 #define FHE_B32_INV_LOOSE 1      // inverse rounds without a conditional subtraction per butterfly (ntt32_rounds.hpp: round_inv32_loose); modes 1 / 2 only
 #endif
@@ -79,6 +96,19 @@ struct Blk {
     using C = Big32<LB>;                                        // the n-point block: VT = 1, TH = n / 16 threads
     static constexpr u32 M = C::M, TH = C::TH;
     static constexpr size_t LDS(int tables) { return C::TILE_BYTES + (size_t)tables * C::TW_BYTES; }
+    // Round 5: the words the inverse kernels park between primes (the tensor's first-prime residues, Garner's digits) go
+    // to HBM and back — 0.4 / 0.8 GB per step of 2048 pairs, they do not stay in the L2 (profiles/
+    // r05_config3_pmc_traffic.txt).  In the relinearisation kernel the first park_lds(...) words per thread of plane 0 (the
+    // one read twice) live in the LDS the workgroup may use WITHOUT lowering the occupancy, behind the tile and the twiddle
+    // tables; the rest keep their place in memory: 722 -> 677 us per 2048 pairs at N = 8192.
+    // WPS = waves per SIMD the kernel's registers allow (relinearisation: 120 registers, 4)
+    static constexpr int park_lds(int tables, int words, int wps) {
+        const long wgs = (4L * wps * 64) / (long)TH;                         // workgroups per CU at that occupancy
+        const long budget = 160L * 1024 / (wgs < 1 ? 1 : wgs) - 1024;        // LDS per workgroup, with a margin
+        const long k = (budget - (long)LDS(tables)) / (8L * (long)TH);
+        return k < 0 ? 0 : (k > words ? words : (int)k);
+    }
+    static constexpr size_t LDS_PARKED(int tables, int words, int wps) { return LDS(tables) + (size_t)park_lds(tables, words, wps) * 8 * TH; }
     static __device__ __forceinline__ Tw32 *table(unsigned char *smem, int i) { return reinterpret_cast<Tw32 *>(smem + C::TILE_BYTES + i * C::TW_BYTES); }
 };
 
@@ -87,7 +117,7 @@ struct Blk {
 // Workgroup ids 16 g + 8 blk + (row % 8): the two blocks of a row read the same words through ONE XCD's L2.
 // BELOWP: ... and q <= every prime: a canonical word (v < q, the library's input contract) is its own residue — no reduction
 template <int LB, int NPR, bool WORD32, bool BELOWP = false>
-__global__ __launch_bounds__((Big32<LB>::TH), FHE_B32_FWD_WAVES) void bfv32_forward_kernel(Bfv32Args a) {
+__global__ __launch_bounds__((Big32<LB>::TH), fwd_waves(NPR)) void bfv32_forward_kernel(Bfv32Args a) {
     static_assert(!BELOWP || WORD32, "words below a 27-bit prime are below 2^32");
     using C = Big32<LB>;
     using K = Blk<LB>;
@@ -117,7 +147,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), FHE_B32_FWD_WAVES) void bfv32_forw
 #pragma unroll
         for (int k = 0; k < 16; k++)
             v[0][k] = BELOWP ? (u32)x[k] : WORD32 ? csub_u32(barrett2p_32((u32)x[k], p, a.t.bq[pr]), p) : reduce64_32(x[k], p, a.t.mu[pr]);
-        fwd_big<LB, 0, 1, FHE_B32_FWD_PRELOAD != 0>(v, lds, K::table(smem_raw, i), a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr], 1u, blk);
+        fwd_big<LB, 0, 1, fwd_preload(NPR)>(v, lds, K::table(smem_raw, i), a.t.tw_fwd[pr], tf, p, p2, a.t.bq[pr], 1u, blk);
         // stored order (internal to this file): quad j of logical thread t at j * (M / 4) + 4 t of its block — a wave's
         // 16-byte accesses are contiguous (with the natural 16 t + 4 j every access would touch a quarter of each line)
         u32 *__restrict__ dst = a.fw + (((u64)pr * a.rows + row) << (LB + 1)) + blk * K::M + tf * 4u;
@@ -286,6 +316,9 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
         u64 psa = reinterpret_cast<u64>(po);
         asm volatile("" : "+v"(psa));
         const gu64 *ps = reinterpret_cast<const gu64 *>(psa);
+        // (Round 5 tried keeping some of these 16 words per thread in LDS, as the relinearisation kernel now does with its
+        // first plane: 2 or 9 words, 50 or 78 KiB per workgroup — this kernel got 6 % SLOWER either way, 665 against 626 us;
+        // profiles/r05_bfv_occupancy_ab.txt.  The words stay in memory.)
         if constexpr (pr == 1) parked = ps[0];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -374,17 +407,23 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
         u64 psa0 = reinterpret_cast<u64>(park0), psa1 = reinterpret_cast<u64>(park1);
         asm volatile("" : "+v"(psa0), "+v"(psa1));              // (here, not at the top: no registers held across the transforms)
         const gu64 *ps0 = reinterpret_cast<const gu64 *>(psa0), *ps1 = reinterpret_cast<const gu64 *>(psa1);   // global, not flat: see the tensor kernel
-        if constexpr (pr >= 1) pk0 = ps0[0];
+        // (round 5) plane 0 is read twice (primes 1 and 2): the first KL of its 16 words per thread stay in LDS, behind the
+        // tile and the six tables; plane 1 keeps its place in memory
+        constexpr int KL = FHE_B32_PARK_LDS ? K::park_lds(6, 16, kRelinWps) : 0;
+        u64 *lpark = reinterpret_cast<u64 *>(smem_raw + K::LDS(6)) + tf;
+        auto park0_load = [&](int k) __attribute__((always_inline)) { return k < KL ? lpark[(u32)k * C::TH] : ps0[(u32)k * C::TH]; };
+        if constexpr (pr >= 1) pk0 = park0_load(0);
         if constexpr (pr == 2) pk1 = ps1[0];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u32 r2[2] = {v0[0][k], v1[0][k]};                    // [0] = coefficient j, [1] = coefficient j + n
             last_stage<last_in_of<FHE_B32_INV_R>()>(r2[0], r2[1], ni, w1ni, p);
             if constexpr (pr == 0) {
-                park0[(u32)k * C::TH] = ((u64)r2[1] << 32) | r2[0];
+                if (k < KL) lpark[(u32)k * C::TH] = ((u64)r2[1] << 32) | r2[0];
+                else park0[(u32)k * C::TH] = ((u64)r2[1] << 32) | r2[0];
             } else if constexpr (pr == 1) {
                 const u32 g0[2] = {(u32)pk0, (u32)(pk0 >> 32)};
-                if (k + 1 < 16) pk0 = ps0[(u32)(k + 1) * C::TH];
+                if (k + 1 < 16) pk0 = park0_load(k + 1);
                 u32 g1[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -394,7 +433,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel
                 park1[(u32)k * C::TH] = ((u64)g1[1] << 32) | g1[0];
             } else {
                 const u32 g0[2] = {(u32)pk0, (u32)(pk0 >> 32)}, g1[2] = {(u32)pk1, (u32)(pk1 >> 32)};
-                if (k + 1 < 16) { pk0 = ps0[(u32)(k + 1) * C::TH]; pk1 = ps1[(u32)(k + 1) * C::TH]; }
+                if (k + 1 < 16) { pk0 = park0_load(k + 1); pk1 = ps1[(u32)(k + 1) * C::TH]; }
                 long long R2[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -448,12 +487,13 @@ static hipError_t launch_big(K kernel, const char *name, int lp, size_t lds, uns
     return hipGetLastError();
 }
 // a.log_n2 = log2(2n); the kernels are instantiated on the block size n = 2^(log_n2 - 1); TABLES local twiddle tiles
-#define FHE_BIG_SWITCH(KERNEL, NAME, GRID, GRIDY, TABLES)                                                                      \
+// PARKW: words per thread the kernel would like to park in LDS (0: none) — Blk::LDS_PARKED
+#define FHE_BIG_SWITCH(KERNEL, NAME, GRID, GRIDY, TABLES, PARKW, WPS)                                                               \
     switch (a.log_n2) {                                                                                                      \
-        case 11: return launch_big(KERNEL<10>, NAME, 11, Blk<10>::LDS(TABLES), Big32<10>::TH, GRID, a, st, GRIDY); \
-        case 12: return launch_big(KERNEL<11>, NAME, 12, Blk<11>::LDS(TABLES), Big32<11>::TH, GRID, a, st, GRIDY); \
-        case 13: return launch_big(KERNEL<12>, NAME, 13, Blk<12>::LDS(TABLES), Big32<12>::TH, GRID, a, st, GRIDY); \
-        case 14: return launch_big(KERNEL<13>, NAME, 14, Blk<13>::LDS(TABLES), Big32<13>::TH, GRID, a, st, GRIDY); \
+        case 11: return launch_big(KERNEL<10>, NAME, 11, Blk<10>::LDS_PARKED(TABLES, PARKW, WPS), Big32<10>::TH, GRID, a, st, GRIDY); \
+        case 12: return launch_big(KERNEL<11>, NAME, 12, Blk<11>::LDS_PARKED(TABLES, PARKW, WPS), Big32<11>::TH, GRID, a, st, GRIDY); \
+        case 13: return launch_big(KERNEL<12>, NAME, 13, Blk<12>::LDS_PARKED(TABLES, PARKW, WPS), Big32<12>::TH, GRID, a, st, GRIDY); \
+        case 14: return launch_big(KERNEL<13>, NAME, 14, Blk<13>::LDS_PARKED(TABLES, PARKW, WPS), Big32<13>::TH, GRID, a, st, GRIDY); \
     }                                                                                                                        \
     return hipErrorNotSupported;
 
@@ -464,26 +504,26 @@ template <int LB> static constexpr auto bfv32_forward3b = bfv32_forward_kernel<L
 template <int LB> static constexpr auto bfv32_forward1w = bfv32_forward_kernel<LB, 1, false>;
 hipError_t launch_bfv32_forward(const Bfv32Args &a, hipStream_t st) {
     const u64 grid = 16 * ((a.rows + 7) / 8);                                                   // (row, block) pairs, 8 rows x 2 blocks per group
-    if (a.primes == 2 && a.word32 && a.below_p) { FHE_BIG_SWITCH(bfv32_forward2b, "bfv32_forward", grid, 1, 2) }
-    if (a.primes == 3 && a.word32 && a.below_p) { FHE_BIG_SWITCH(bfv32_forward3b, "bfv32_forward3", grid, 1, 3) }
-    if (a.primes == 2 && a.word32) { FHE_BIG_SWITCH(bfv32_forward2, "bfv32_forward", grid, 1, 2) }
-    if (a.primes == 3 && a.word32) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", grid, 1, 3) }
-    if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward1w, "bfv32_forward_key", grid, 3, 1) }      // grid (row-blocks, primes)
+    if (a.primes == 2 && a.word32 && a.below_p) { FHE_BIG_SWITCH(bfv32_forward2b, "bfv32_forward", grid, 1, 2, 0, 4) }
+    if (a.primes == 3 && a.word32 && a.below_p) { FHE_BIG_SWITCH(bfv32_forward3b, "bfv32_forward3", grid, 1, 3, 0, 4) }
+    if (a.primes == 2 && a.word32) { FHE_BIG_SWITCH(bfv32_forward2, "bfv32_forward", grid, 1, 2, 0, 4) }
+    if (a.primes == 3 && a.word32) { FHE_BIG_SWITCH(bfv32_forward3, "bfv32_forward3", grid, 1, 3, 0, 4) }
+    if (a.primes == 3) { FHE_BIG_SWITCH(bfv32_forward1w, "bfv32_forward_key", grid, 3, 1, 0, 4) }      // grid (row-blocks, primes)
     return hipErrorNotSupported;
 }
 template <int LB> static constexpr auto bfv32_tensor_inverse_f64 = bfv32_tensor_inverse_kernel<LB, false, false>;
 template <int LB> static constexpr auto bfv32_tensor_inverse_f64s = bfv32_tensor_inverse_kernel<LB, false, true>;
 template <int LB> static constexpr auto bfv32_tensor_inverse_int = bfv32_tensor_inverse_kernel<LB, true, false>;
 hipError_t launch_bfv32_tensor_inverse(const Bfv32Args &a, hipStream_t st) {
-    if (a.int_num) { FHE_BIG_SWITCH(bfv32_tensor_inverse_int, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4) }
-    if (a.small_f64) { FHE_BIG_SWITCH(bfv32_tensor_inverse_f64s, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4) }
-    FHE_BIG_SWITCH(bfv32_tensor_inverse_f64, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4)
+    if (a.int_num) { FHE_BIG_SWITCH(bfv32_tensor_inverse_int, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4, 0, 4) }
+    if (a.small_f64) { FHE_BIG_SWITCH(bfv32_tensor_inverse_f64s, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4, 0, 4) }
+    FHE_BIG_SWITCH(bfv32_tensor_inverse_f64, "bfv32_tensor_inverse", 24 * ((a.batch + 7) / 8), 1, 4, 0, 4)
 }
 template <int LB> static constexpr auto bfv32_relin_inverse_gen = bfv32_relin_inverse_kernel<LB, false>;
 template <int LB> static constexpr auto bfv32_relin_inverse_small = bfv32_relin_inverse_kernel<LB, true>;
 hipError_t launch_bfv32_relin_inverse(const Bfv32Args &a, hipStream_t st) {
-    if (a.small_f64) { FHE_BIG_SWITCH(bfv32_relin_inverse_small, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1, 6) }
-    FHE_BIG_SWITCH(bfv32_relin_inverse_gen, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1, 6)
+    if (a.small_f64) { FHE_BIG_SWITCH(bfv32_relin_inverse_small, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1, 6, (FHE_B32_PARK_LDS ? 16 : 0), kRelinWps) }
+    FHE_BIG_SWITCH(bfv32_relin_inverse_gen, "bfv32_relin_inverse", 16 * ((a.batch + 7) / 8), 1, 6, (FHE_B32_PARK_LDS ? 16 : 0), kRelinWps)
 }
 #undef FHE_BIG_SWITCH
 

@@ -15,10 +15,10 @@ ab = torch.from_numpy(rng.integers(0, q, (4, batch, n), dtype=np.int64)).cuda()
 rlk = torch.from_numpy(rng.integers(0, pq, (2, n), dtype=np.int64)).cuda()
 out = torch.empty((2, batch, n), dtype=torch.int64, device="cuda")
 f = lambda: B._check(L.fhe_bfv_mul_dev(q, n, t, pq, rlk.data_ptr(), ab.data_ptr(), out.data_ptr(), batch, None))
-for _ in range(2): f()
-torch.cuda.synchronize()
+from _timing import timeit
+timeit(f)                                            # warm clocks (tools/_timing.py)
 B.kernel_timing_reset(); B.kernel_timing_enable(True)
-for _ in range(5): f()
+for _ in range(20): f()
 torch.cuda.synchronize()
-tm = {k: round(v[0] / 5 * 1e3, 1) for k, v in B.kernel_timing_read().items()}
+tm = {k: round(v[0] / 20 * 1e3, 1) for k, v in B.kernel_timing_read().items()}
 print(os.path.basename(os.environ.get("FHE_NTT_LIB", "default")), tm, "sum", round(sum(tm.values()), 1), "us per step")

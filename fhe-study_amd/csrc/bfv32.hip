@@ -66,6 +66,9 @@ __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
 // the twiddles read as they go (no registers held across the exchange: no spills at 80 registers): 502 -> 453 us per 2048
 // pairs at N = 8192.  The three-prime kernel (c2) spills at six waves and is slower there (181 -> 196 / 210 us): it keeps
 // FHE_B32_FWD_WAVES / FHE_B32_FWD_PRELOAD.  profiles/r05_bfv_occupancy_ab.txt.
+#ifndef FHE_B32_RELIN_WAVES
+#define FHE_B32_RELIN_WAVES 4    // relinearisation kernel: waves per SIMD its registers must allow (6 = three workgroups per CU: spills, measured slower)
+#endif
 #ifndef FHE_B32_FWD2_WAVES
 #define FHE_B32_FWD2_WAVES 6
 #endif
@@ -358,7 +361,7 @@ __global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_tensor_inverse_kerne
 //      Z_q, fold, + c0 / c1 (lib.rs:204-277) --------------------------------------------------------------------------------
 // workgroup = (ciphertext b, output polynomial o)
 template <int LB, bool SMALL>
-__global__ __launch_bounds__((Big32<LB>::TH), 4) void bfv32_relin_inverse_kernel(Bfv32Args a) {
+__global__ __launch_bounds__((Big32<LB>::TH), FHE_B32_RELIN_WAVES) void bfv32_relin_inverse_kernel(Bfv32Args a) {
     using C = Big32<LB>;
     using K = Blk<LB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -75,7 +75,16 @@ __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
 #ifndef FHE_B32_FWD2_PRELOAD
 #define FHE_B32_FWD2_PRELOAD 0
 #endif
-constexpr int fwd_waves(int npr) { return npr == 2 ? FHE_B32_FWD2_WAVES : FHE_B32_FWD_WAVES; }
+// The THREE-prime forward kernel (c2, ahead of the relinearisation) at six waves: its 16 source words are then not kept in
+// registers across the primes but read again before each (FHE_B32_FWD3_RELOAD; an L1 / L2 hit).
+#ifndef FHE_B32_FWD3_WAVES
+#define FHE_B32_FWD3_WAVES 4
+#endif
+#ifndef FHE_B32_FWD3_RELOAD
+#define FHE_B32_FWD3_RELOAD 0
+#endif
+constexpr int fwd_waves(int npr) { return npr == 2 ? FHE_B32_FWD2_WAVES : npr == 3 ? FHE_B32_FWD3_WAVES : FHE_B32_FWD_WAVES; }
+constexpr bool fwd_reload(int npr) { return npr == 3 && FHE_B32_FWD3_RELOAD != 0; }
 constexpr bool fwd_preload(int npr) { return npr == 2 ? FHE_B32_FWD2_PRELOAD != 0 : FHE_B32_FWD_PRELOAD != 0; }
 #ifndef FHE_B32_PARK_LDS
 #define FHE_B32_PARK_LDS 1       // inverse kernels: as many of the parked words as fit the occupancy's LDS share stay in LDS (round 5)
@@ -146,6 +155,15 @@ __global__ __launch_bounds__((Big32<LB>::TH), fwd_waves(NPR)) void bfv32_forward
     for (int i = 0; i < NPR; i++) {
         const u32 pr = NPR == 1 ? blockIdx.y : (u32)i;
         const u32 p = a.t.p[pr], p2 = 2u * p;
+        if constexpr (fwd_reload(NPR)) {
+            if (i > 0) {                                        // the source words again, through a pointer the compiler cannot see through
+                u64 sa = reinterpret_cast<u64>(src);
+                asm volatile("" : "+s"(sa));
+                const gu64 *ps = reinterpret_cast<const gu64 *>(sa);
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = (typename std::conditional<WORD32, u32, u64>::type)ps[(u32)k * C::TH + tf];
+            }
+        }
         u32 v[1][16];
 #pragma unroll
         for (int k = 0; k < 16; k++)

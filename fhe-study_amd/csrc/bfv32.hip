@@ -44,7 +44,8 @@ __device__ __forceinline__ u64 crt2(u32 rA, u32 rB, u32 pA, u32 pB, Tw32 crt) {
 // words.  Likewise the inverse: stages L-1 .. 1 act inside the halves and only the last one (roots_inv[1]) pairs point j of
 // half 0 with point j of half 1 — coefficients j and j + n of the 2n-word product, exactly the pair the epilogues need
 // together (scale, round, X^n+1 fold).  So a workgroup is n / 16 threads (512 at n = 8192) around a 34 KiB tile instead
-// of 1024 around 68 KiB, and a CU holds two of them (128 registers): one computes while the other waits at a barrier or
+// of 1024 around 68 KiB, and a CU holds two of them at 128 registers — three at 80, which the tensor's inverse kernel
+// and (round 5) the two-prime forward kernel run at: one computes while the others wait at a barrier or
 // for its loads.  Until round 2 one 1024-thread workgroup per CU left every load phase and barrier exposed (2048
 // products: 2.75 ms).
 // how the block kernels run their inverse rounds (shape experiments: -DFHE_B32_INV_T=.. / -DFHE_B32_INV_R=..):
